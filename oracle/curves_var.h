@@ -1,0 +1,507 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY. Not part of the shipped product path.
+// Restatement of ark-r1cs-std ^0.4.0 short-Weierstrass group gadgets (third-party, not vendored):
+//   groups/curves/short_weierstrass/mod.rs  (ProjectiveVar: complete RCB-2015 formulas, to_affine,
+//       new_variable with the Witness-mode prime-order check, scalar_mul_le / fixed_scalar_mul_le, EqGadget)
+//   groups/curves/short_weierstrass/non_zero_affine.rs (NonZeroAffineVar: incomplete affine add/double)
+// Call sites in the reference: constraints.rs:99,206,226,245; hasher.rs:656,672.  Rules: SURVEY.md App. A.5, A.6.
+#pragma once
+#include "fields_var.h"
+
+namespace orc {
+
+// scalar constants
+static const uint64_t FR_MODULUS[4] = {0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL, 0x73eda753299d7d48ULL};
+static const uint64_t G1_COFACTOR[2] = {0x8c00aaab0000aaabULL, 0x396c8c005555e156ULL};
+// G1 cofactor^{-1} mod r (checked in tests/test_oracle_constants.py: h * h_inv = 1 mod r)
+static const uint64_t G1_COFACTOR_INV[4] = {0xec0000020005fffbULL, 0xd07c8ff73bf14809ULL, 0xe34f0b31458fbb21ULL, 0x73eda753299d7d44ULL};
+
+// Field-var traits so that ProjectiveVar<F> covers G1 (FpVar) and G2 (Fp2Var)
+struct FpT {
+    typedef FpVar V;
+    typedef Fp N;
+    static V add(const V& a, const V& b) { return fadd(a, b); }
+    static V sub(const V& a, const V& b) { return fsub(a, b); }
+    static V neg(const V& a) { return fneg(a); }
+    static V dbl(const V& a) { return fdbl(a); }
+    static V mul(const V& a, const V& b) { return fmul(a, b); }
+    static V sqr(const V& a) { return fsqr(a); }
+    static V mulc(const V& a, const N& c) { return fmulc(a, c); }
+    static V constant(const N& c) { return fconst(c); }
+    static V witness(const N& c) { return fwitness(c); }
+    static V zero() { return fconst(fp_zero()); }
+    static V one() { return fconst(fp_one()); }
+    static bool is_const(const V& a) { return a.konst; }
+    static N val(const V& a) { return a.v; }
+    static Bool is_eq(const V& a, const V& b) { return fis_eq(a, b); }
+    static Bool is_zero(const V& a) { return fis_eq(a, zero()); }
+    static V select(const Bool& c, const V& t, const V& f) { return fselect(c, t, f); }
+    static void mul_equals(const V& a, const V& b, const V& r) { fmul_equals(a, b, r); }
+    static V from_bool(const Bool& b) { return ffrom_bool(b); }
+    static V mul_by_inverse_unchecked(const V& self, const V& d) {
+        Fp rv = fp_mul(self.v, fp_inv(d.v));
+        if (self.konst && d.konst) return fconst(rv);
+        V r = fwitness(rv);
+        fmul_equals(r, d, self);
+        return r;
+    }
+    static N ninv(const N& a) { return fp_inv(a); }
+    static N nzero() { return fp_zero(); }
+    static N none() { return fp_one(); }
+    static N nmul(const N& a, const N& b) { return fp_mul(a, b); }
+    static N nadd(const N& a, const N& b) { return fp_add(a, b); }
+    static N nsub(const N& a, const N& b) { return fp_sub(a, b); }
+    static N nneg(const N& a) { return fp_neg(a); }
+    static bool nis_zero(const N& a) { return fp_is_zero(a); }
+    static bool neq(const N& a, const N& b) { return fp_eq(a, b); }
+    static N coeff_b() { return fp_from_u64(4); }
+};
+struct Fp2T {
+    typedef Fp2Var V;
+    typedef Fp2 N;
+    static V add(const V& a, const V& b) { return f2add(a, b); }
+    static V sub(const V& a, const V& b) { return f2sub(a, b); }
+    static V neg(const V& a) { return f2neg(a); }
+    static V dbl(const V& a) { return f2dbl(a); }
+    static V mul(const V& a, const V& b) { return f2mul(a, b); }
+    static V sqr(const V& a) { return f2sqr(a); }
+    static V mulc(const V& a, const N& c) { return f2mulc(a, c); }
+    static V constant(const N& c) { return f2const(c); }
+    static V witness(const N& c) { return f2witness(c); }
+    static V zero() { return f2zero(); }
+    static V one() { return f2one(); }
+    static bool is_const(const V& a) { return a.is_const(); }
+    static N val(const V& a) { return a.val(); }
+    static Bool is_eq(const V& a, const V& b) { return f2is_eq(a, b); }
+    static Bool is_zero(const V& a) { return f2is_zero(a); }
+    static V select(const Bool& c, const V& t, const V& f) { return f2select(c, t, f); }
+    static void mul_equals(const V& a, const V& b, const V& r) { f2mul_equals(a, b, r); }
+    static V from_bool(const Bool& b) { return f2from_bool(b); }
+    static V mul_by_inverse_unchecked(const V& self, const V& d) { return f2mul_by_inverse_unchecked(self, d); }
+    static N ninv(const N& a) { return fp2_inv(a); }
+    static N nzero() { return fp2_zero(); }
+    static N none() { return fp2_one(); }
+    static N nmul(const N& a, const N& b) { return fp2_mul(a, b); }
+    static N nadd(const N& a, const N& b) { return fp2_add(a, b); }
+    static N nsub(const N& a, const N& b) { return fp2_sub(a, b); }
+    static N nneg(const N& a) { return fp2_neg(a); }
+    static bool nis_zero(const N& a) { return fp2_is_zero(a); }
+    static bool neq(const N& a, const N& b) { return fp2_eq(a, b); }
+    static N coeff_b() { return {fp_from_u64(4), fp_from_u64(4)}; }
+};
+
+// ------------------------------------------------------------------ native affine / Jacobian arithmetic (a = 0)
+template <class T>
+struct Aff {
+    typename T::N x, y;
+    bool inf;
+};
+template <class T>
+struct Jac {
+    typename T::N x, y, z;
+};
+template <class T>
+Jac<T> jac_identity() { return {T::none(), T::none(), T::nzero()}; }
+template <class T>
+Jac<T> jac_from_aff(const Aff<T>& a) {
+    if (a.inf) return jac_identity<T>();
+    return {a.x, a.y, T::none()};
+}
+template <class T>
+Aff<T> jac_to_aff(const Jac<T>& p) {
+    if (T::nis_zero(p.z)) return {T::nzero(), T::nzero(), true};
+    auto zi = T::ninv(p.z);
+    auto zi2 = T::nmul(zi, zi);
+    return {T::nmul(p.x, zi2), T::nmul(p.y, T::nmul(zi2, zi)), false};
+}
+template <class T>
+Jac<T> jac_dbl(const Jac<T>& p) {
+    if (T::nis_zero(p.z)) return p;
+    auto A = T::nmul(p.x, p.x), B = T::nmul(p.y, p.y), C = T::nmul(B, B);
+    auto t = T::nadd(p.x, B);
+    auto D = T::nsub(T::nsub(T::nmul(t, t), A), C);
+    D = T::nadd(D, D);
+    auto E = T::nadd(T::nadd(A, A), A);
+    auto F = T::nmul(E, E);
+    auto x3 = T::nsub(F, T::nadd(D, D));
+    auto c8 = T::nadd(C, C);
+    c8 = T::nadd(c8, c8);
+    c8 = T::nadd(c8, c8);
+    auto y3 = T::nsub(T::nmul(E, T::nsub(D, x3)), c8);
+    auto z3 = T::nmul(p.y, p.z);
+    z3 = T::nadd(z3, z3);
+    return {x3, y3, z3};
+}
+template <class T>
+Jac<T> jac_add(const Jac<T>& p, const Jac<T>& q) {
+    if (T::nis_zero(p.z)) return q;
+    if (T::nis_zero(q.z)) return p;
+    auto z1z1 = T::nmul(p.z, p.z), z2z2 = T::nmul(q.z, q.z);
+    auto u1 = T::nmul(p.x, z2z2), u2 = T::nmul(q.x, z1z1);
+    auto s1 = T::nmul(T::nmul(p.y, q.z), z2z2), s2 = T::nmul(T::nmul(q.y, p.z), z1z1);
+    if (T::neq(u1, u2)) {
+        if (T::neq(s1, s2)) return jac_dbl<T>(p);
+        return jac_identity<T>();
+    }
+    auto h = T::nsub(u2, u1);
+    auto i = T::nadd(h, h);
+    i = T::nmul(i, i);
+    auto j = T::nmul(h, i);
+    auto r = T::nsub(s2, s1);
+    r = T::nadd(r, r);
+    auto v = T::nmul(u1, i);
+    auto x3 = T::nsub(T::nsub(T::nmul(r, r), j), T::nadd(v, v));
+    auto s1j = T::nmul(s1, j);
+    auto y3 = T::nsub(T::nmul(r, T::nsub(v, x3)), T::nadd(s1j, s1j));
+    auto zz = T::nadd(p.z, q.z);
+    auto z3 = T::nmul(T::nsub(T::nsub(T::nmul(zz, zz), z1z1), z2z2), h);
+    return {x3, y3, z3};
+}
+template <class T>
+Jac<T> jac_mul(const Jac<T>& p, const uint64_t* k, int nlimbs) {
+    Jac<T> r = jac_identity<T>();
+    for (int i = nlimbs * 64 - 1; i >= 0; i--) {
+        r = jac_dbl<T>(r);
+        if ((k[i / 64] >> (i % 64)) & 1) r = jac_add<T>(r, p);
+    }
+    return r;
+}
+template <class T>
+bool aff_on_curve(const Aff<T>& a) {
+    if (a.inf) return true;
+    auto lhs = T::nmul(a.y, a.y);
+    auto rhs = T::nadd(T::nmul(T::nmul(a.x, a.x), a.x), T::coeff_b());
+    return T::neq(lhs, rhs);
+}
+template <class T>
+bool aff_in_subgroup(const Aff<T>& a) {
+    Jac<T> r = jac_mul<T>(jac_from_aff<T>(a), FR_MODULUS, 4);
+    return T::nis_zero(r.z);
+}
+typedef Aff<FpT> G1Aff;
+typedef Aff<Fp2T> G2Aff;
+inline G1Aff g1_generator() {
+    return {fp_from_hex("17f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb"),
+            fp_from_hex("08b3f481e3aaa0f1a09e30ed741d8ae4fcf5e095d5d00af600db18cb2c04b3edd03cc744a2888ae40caa232946c5e7e1"), false};
+}
+
+// ------------------------------------------------------------------ gadget side
+template <class T>
+struct NonZeroAffineVar {
+    typename T::V x, y;
+};
+template <class T>
+struct AffineVar {
+    typename T::V x, y;
+    Bool infinity;
+};
+template <class T>
+struct ProjectiveVar {
+    typedef typename T::V V;
+    V x, y, z;
+    bool is_const() const { return T::is_const(x) && T::is_const(y) && T::is_const(z); }
+    bool value_is_zero() const { return T::nis_zero(T::val(z)); }
+    // native affine value
+    Aff<T> value_affine() const {
+        auto zv = T::val(z);
+        if (T::nis_zero(zv)) return {T::nzero(), T::nzero(), true};
+        auto zi = T::ninv(zv);
+        return {T::nmul(T::val(x), zi), T::nmul(T::val(y), zi), false};
+    }
+};
+template <class T>
+ProjectiveVar<T> pv_zero() { return {T::zero(), T::one(), T::zero()}; }
+template <class T>
+ProjectiveVar<T> pv_constant(const Aff<T>& a) {
+    if (a.inf) return pv_zero<T>();
+    return {T::constant(a.x), T::constant(a.y), T::one()};
+}
+template <class T>
+ProjectiveVar<T> pv_negate(const ProjectiveVar<T>& p) { return {p.x, T::neg(p.y), p.z}; }
+template <class T>
+typename T::N three_b() {
+    auto b = T::coeff_b();
+    return T::nadd(T::nadd(b, b), b);
+}
+// complete doubling, RCB-2015 Alg. 3 with a = 0 (mul_by_coeff_a returns the constant zero)
+template <class T>
+ProjectiveVar<T> pv_double(const ProjectiveVar<T>& p) {
+    typedef typename T::V V;
+    auto b3 = three_b<T>();
+    V xx = T::sqr(p.x);
+    V yy = T::sqr(p.y);
+    V zz = T::sqr(p.z);
+    V xy2 = T::dbl(T::mul(p.x, p.y));
+    V xz2 = T::dbl(T::mul(p.x, p.z));
+    V axz2 = T::zero();
+    V bzz3_part = T::add(axz2, T::mulc(zz, b3));
+    V yy_m = T::sub(yy, bzz3_part);
+    V yy_p = T::add(yy, bzz3_part);
+    V y_frag = T::mul(yy_p, yy_m);
+    V x_frag = T::mul(yy_m, xy2);
+    V bxz3 = T::mulc(xz2, b3);
+    V azz = T::zero();
+    V b3_xz_pairs = T::add(T::zero() /* a*(xx-azz) */, bxz3);
+    V xx3_p_azz = T::mul(T::add(T::add(T::dbl(xx), xx), azz), b3_xz_pairs);
+    V y = T::add(y_frag, xx3_p_azz);
+    V yz2 = T::dbl(T::mul(p.y, p.z));
+    V t = T::mul(b3_xz_pairs, yz2);
+    V x = T::sub(x_frag, t);
+    V z = T::dbl(T::dbl(T::mul(yz2, yy)));
+    return {x, y, z};
+}
+// complete mixed addition, RCB-2015 Alg. 2 (other has z = 1)
+template <class T>
+ProjectiveVar<T> pv_add_mixed(const ProjectiveVar<T>& p, const typename T::V& x2, const typename T::V& y2) {
+    typedef typename T::V V;
+    auto b3 = three_b<T>();
+    V xx = T::mul(p.x, x2);
+    V yy = T::mul(p.y, y2);
+    V t0 = T::mul(T::add(p.x, p.y), T::add(x2, y2));
+    V xy_pairs = T::sub(t0, T::add(xx, yy));
+    V t1 = T::mul(x2, p.z);
+    V xz_pairs = T::add(t1, p.x);
+    V t2 = T::mul(y2, p.z);
+    V yz_pairs = T::add(t2, p.y);
+    V bz3_part = T::add(T::zero(), T::mulc(p.z, b3));
+    V yy_m = T::sub(yy, bz3_part);
+    V yy_p = T::add(yy, bz3_part);
+    V azz = T::zero();
+    V xx3_p_azz = T::add(T::add(T::dbl(xx), xx), azz);
+    V bxz3 = T::mulc(xz_pairs, b3);
+    V b3_xz_pairs = T::add(T::zero(), bxz3);
+    V m0 = T::mul(yy_m, xy_pairs);
+    V m1 = T::mul(yz_pairs, b3_xz_pairs);
+    V x = T::sub(m0, m1);
+    V m2 = T::mul(yy_p, yy_m);
+    V m3 = T::mul(xx3_p_azz, b3_xz_pairs);
+    V y = T::add(m2, m3);
+    V m4 = T::mul(yy_p, yz_pairs);
+    V m5 = T::mul(xy_pairs, xx3_p_azz);
+    V z = T::add(m4, m5);
+    return {x, y, z};
+}
+// complete addition, RCB-2015 Alg. 1, with arkworks' constant special-casing
+template <class T>
+ProjectiveVar<T> pv_add(const ProjectiveVar<T>& a_, const ProjectiveVar<T>& b_) {
+    typedef typename T::V V;
+    const ProjectiveVar<T>* self = &a_;
+    const ProjectiveVar<T>* other = &b_;
+    if (self->is_const()) std::swap(self, other);
+    if (other->is_const()) {
+        if (other->value_is_zero()) return *self;
+        Aff<T> ov = other->value_affine();
+        return pv_add_mixed<T>(*self, T::constant(ov.x), T::constant(ov.y));
+    }
+    auto b3 = three_b<T>();
+    const V &x1 = self->x, &y1 = self->y, &z1 = self->z, &x2 = other->x, &y2 = other->y, &z2 = other->z;
+    V xx = T::mul(x1, x2);
+    V yy = T::mul(y1, y2);
+    V zz = T::mul(z1, z2);
+    V t0 = T::mul(T::add(x1, y1), T::add(x2, y2));
+    V xy_pairs = T::sub(t0, T::add(xx, yy));
+    V t1 = T::mul(T::add(x1, z1), T::add(x2, z2));
+    V xz_pairs = T::sub(t1, T::add(xx, zz));
+    V t2 = T::mul(T::add(y1, z1), T::add(y2, z2));
+    V yz_pairs = T::sub(t2, T::add(yy, zz));
+    V bzz3_part = T::add(T::zero(), T::mulc(zz, b3));
+    V yy_m = T::sub(yy, bzz3_part);
+    V yy_p = T::add(yy, bzz3_part);
+    V azz = T::zero();
+    V xx3_p_azz = T::add(T::add(T::dbl(xx), xx), azz);
+    V bxz3 = T::mulc(xz_pairs, b3);
+    V b3_xz_pairs = T::add(T::zero(), bxz3);
+    V m0 = T::mul(yy_m, xy_pairs);
+    V m1 = T::mul(yz_pairs, b3_xz_pairs);
+    V x = T::sub(m0, m1);
+    V m2 = T::mul(yy_p, yy_m);
+    V m3 = T::mul(xx3_p_azz, b3_xz_pairs);
+    V y = T::add(m2, m3);
+    V m4 = T::mul(yy_p, yz_pairs);
+    V m5 = T::mul(xy_pairs, xx3_p_azz);
+    V z = T::add(m4, m5);
+    return {x, y, z};
+}
+template <class T>
+ProjectiveVar<T> pv_select(const Bool& c, const ProjectiveVar<T>& t, const ProjectiveVar<T>& f) {
+    auto x = T::select(c, t.x, f.x);
+    auto y = T::select(c, t.y, f.y);
+    auto z = T::select(c, t.z, f.z);
+    return {x, y, z};
+}
+template <class T>
+Bool pv_is_zero(const ProjectiveVar<T>& p) { return T::is_zero(p.z); }
+// ProjectiveVar::to_affine
+template <class T>
+AffineVar<T> pv_to_affine(const ProjectiveVar<T>& p) {
+    typedef typename T::V V;
+    if (p.is_const()) {
+        Aff<T> a = p.value_affine();
+        return {T::constant(a.x), T::constant(a.y), bconst(a.inf)};
+    }
+    Bool infinity = pv_is_zero<T>(p);
+    auto zv = T::val(p.z);
+    V z_inv = T::witness(T::nis_zero(zv) ? T::nzero() : T::ninv(zv));
+    T::mul_equals(z_inv, p.z, T::from_bool(bnot(infinity)));
+    V nzx = T::mul(p.x, z_inv);
+    V nzy = T::mul(p.y, z_inv);
+    V x = T::select(infinity, T::zero(), nzx);
+    V y = T::select(infinity, T::zero(), nzy);
+    return {x, y, infinity};
+}
+// EqGadget for ProjectiveVar
+template <class T>
+Bool pv_is_eq(const ProjectiveVar<T>& a, const ProjectiveVar<T>& b) {
+    typedef typename T::V V;
+    V l0 = T::mul(a.x, b.z);
+    V r0 = T::mul(b.x, a.z);
+    Bool x_equal = T::is_eq(l0, r0);
+    V l1 = T::mul(a.y, b.z);
+    V r1 = T::mul(b.y, a.z);
+    Bool y_equal = T::is_eq(l1, r1);
+    Bool coordinates_equal = band(x_equal, y_equal);
+    Bool za = pv_is_zero<T>(a);
+    Bool zb = pv_is_zero<T>(b);
+    Bool both_are_zero = band(za, zb);
+    return bor(both_are_zero, coordinates_equal);
+}
+template <class T>
+void pv_enforce_equal(const ProjectiveVar<T>& a, const ProjectiveVar<T>& b) {
+    Bool e = pv_is_eq<T>(a, b);
+    benforce_equal_const(e, true);
+}
+template <class T>
+void pv_enforce_not_equal(const ProjectiveVar<T>& a, const ProjectiveVar<T>& b) {
+    Bool e = pv_is_eq<T>(a, b);  // is_equal.and(Constant(true)) == is_equal
+    benforce_equal_const(e, false);
+}
+
+// NonZeroAffineVar::{double, add_unchecked}
+template <class T>
+NonZeroAffineVar<T> nz_double(const NonZeroAffineVar<T>& p) {
+    typedef typename T::V V;
+    if (T::is_const(p.x) && T::is_const(p.y)) {
+        Aff<T> r = jac_to_aff<T>(jac_dbl<T>(jac_from_aff<T>({T::val(p.x), T::val(p.y), false})));
+        return {T::constant(r.x), T::constant(r.y)};
+    }
+    V x1_sqr = T::sqr(p.x);
+    V numerator = T::add(T::dbl(x1_sqr), x1_sqr);  // + COEFF_A (=0, constant)
+    V denominator = T::dbl(p.y);
+    V lambda = T::mul_by_inverse_unchecked(numerator, denominator);
+    V l2 = T::sqr(lambda);
+    V x3 = T::sub(l2, T::dbl(p.x));
+    V t = T::mul(lambda, T::sub(p.x, x3));
+    V y3 = T::sub(t, p.y);
+    return {x3, y3};
+}
+template <class T>
+NonZeroAffineVar<T> nz_add_unchecked(const NonZeroAffineVar<T>& p, const NonZeroAffineVar<T>& q) {
+    typedef typename T::V V;
+    if (T::is_const(p.x) && T::is_const(p.y) && T::is_const(q.x) && T::is_const(q.y)) {
+        Aff<T> r = jac_to_aff<T>(jac_add<T>(jac_from_aff<T>({T::val(p.x), T::val(p.y), false}), jac_from_aff<T>({T::val(q.x), T::val(q.y), false})));
+        return {T::constant(r.x), T::constant(r.y)};
+    }
+    V numerator = T::sub(q.y, p.y);
+    V denominator = T::sub(q.x, p.x);
+    V lambda = T::mul_by_inverse_unchecked(numerator, denominator);
+    V l2 = T::sqr(lambda);
+    V x3 = T::sub(T::sub(l2, p.x), q.x);
+    V t = T::mul(lambda, T::sub(p.x, x3));
+    V y3 = T::sub(t, p.y);
+    return {x3, y3};
+}
+template <class T>
+ProjectiveVar<T> nz_into_projective(const NonZeroAffineVar<T>& p) { return {p.x, p.y, T::one()}; }
+
+// ProjectiveVar::fixed_scalar_mul_le (bits little-endian, at most 255 of them)
+template <class T>
+void pv_fixed_scalar_mul_le(ProjectiveVar<T>& mul_result, NonZeroAffineVar<T>& mopt, const Bool* bits, size_t nbits) {
+    const size_t scalar_modulus_bits = 255;
+    size_t split_len = std::min(scalar_modulus_bits - 2, nbits);
+    NonZeroAffineVar<T> accumulator = mopt;
+    ProjectiveVar<T> initial_acc_value = nz_into_projective<T>(accumulator);
+    mopt = nz_double<T>(mopt);
+    for (size_t i = 1; i < split_len; i++) {
+        const Bool& bit = bits[i];
+        if (bit.is_const()) {
+            if (bit.val) accumulator = nz_add_unchecked<T>(accumulator, mopt);
+        } else {
+            NonZeroAffineVar<T> temp = nz_add_unchecked<T>(accumulator, mopt);
+            auto sx = T::select(bit, temp.x, accumulator.x);
+            auto sy = T::select(bit, temp.y, accumulator.y);
+            accumulator = {sx, sy};
+        }
+        mopt = nz_double<T>(mopt);
+    }
+    ProjectiveVar<T> result = nz_into_projective<T>(accumulator);
+    ProjectiveVar<T> subtrahend = pv_select<T>(bits[0], pv_zero<T>(), initial_acc_value);
+    ProjectiveVar<T> diff = pv_add<T>(result, pv_negate<T>(subtrahend));
+    mul_result = pv_add<T>(mul_result, diff);
+    for (size_t i = split_len; i < nbits; i++) {
+        const Bool& bit = bits[i];
+        if (bit.is_const()) {
+            if (bit.val) mul_result = pv_add<T>(mul_result, nz_into_projective<T>(mopt));
+        } else {
+            ProjectiveVar<T> temp = pv_add<T>(mul_result, nz_into_projective<T>(mopt));
+            mul_result = pv_select<T>(bit, temp, mul_result);
+        }
+        mopt = nz_double<T>(mopt);
+    }
+}
+// ProjectiveVar::scalar_mul_le
+template <class T>
+ProjectiveVar<T> pv_scalar_mul_le(const ProjectiveVar<T>& self, std::vector<Bool> bits) {
+    if (self.is_const() && self.value_is_zero()) return self;
+    AffineVar<T> aff = pv_to_affine<T>(self);
+    NonZeroAffineVar<T> nz = {aff.x, aff.y};
+    if (bits.empty()) return pv_zero<T>();
+    while (!bits.empty() && bits.back().is_const() && !bits.back().val) bits.pop_back();
+    ProjectiveVar<T> mul_result = pv_zero<T>();
+    NonZeroAffineVar<T> mopt = nz;
+    for (size_t off = 0; off < bits.size(); off += 255) {
+        size_t n = std::min((size_t)255, bits.size() - off);
+        pv_fixed_scalar_mul_le<T>(mul_result, mopt, bits.data() + off, n);
+    }
+    return pv_select<T>(aff.infinity, pv_zero<T>(), mul_result);
+}
+
+// ProjectiveVar::new_variable(Witness): allocation + in-circuit prime-order check (App. A.6)
+// use_cofactor_path: G1 (cofactor weight 48 < weight(r-1) = 133) -> true; G2 (247 >= 133) -> false
+template <class T>
+ProjectiveVar<T> pv_new_witness_omit_check(const Aff<T>& a) {
+    typedef typename T::V V;
+    V x = T::witness(a.inf ? T::nzero() : a.x);
+    V y = T::witness(a.inf ? T::none() : a.y);
+    V z = T::witness(a.inf ? T::nzero() : T::none());
+    return {x, y, z};
+}
+template <class T>
+ProjectiveVar<T> pv_mul_bits_be(const ProjectiveVar<T>& ge, const uint64_t* k, int nlimbs) {
+    // result = zero; for b in BitIteratorBE::without_leading_zeros(k): result.double(); if b: result += ge
+    ProjectiveVar<T> result = pv_zero<T>();
+    int top = nlimbs * 64 - 1;
+    while (top >= 0 && !((k[top / 64] >> (top % 64)) & 1)) top--;
+    for (int i = top; i >= 0; i--) {
+        result = pv_double<T>(result);
+        if ((k[i / 64] >> (i % 64)) & 1) result = pv_add<T>(result, ge);
+    }
+    return result;
+}
+inline ProjectiveVar<FpT> g1_new_witness(const G1Aff& g) {
+    // allocate g * (cofactor^{-1} mod r), then multiply by the cofactor in-circuit and return the product
+    Aff<FpT> pre = jac_to_aff<FpT>(jac_mul<FpT>(jac_from_aff<FpT>(g), G1_COFACTOR_INV, 4));
+    ProjectiveVar<FpT> ge = pv_new_witness_omit_check<FpT>(pre);
+    return pv_mul_bits_be<FpT>(ge, G1_COFACTOR, 2);
+}
+inline ProjectiveVar<Fp2T> g2_new_witness(const G2Aff& g) {
+    // allocate g, multiply by r-1 in-circuit, then `ge.enforce_equal(&ge)` (sic, ark-r1cs-std 0.4.0) and return ge
+    ProjectiveVar<Fp2T> ge = pv_new_witness_omit_check<Fp2T>(g);
+    uint64_t rm1[4];
+    memcpy(rm1, FR_MODULUS, 32);
+    rm1[0] -= 1;
+    ProjectiveVar<Fp2T> result = pv_mul_bits_be<Fp2T>(ge, rm1, 4);
+    (void)result;
+    pv_enforce_equal<Fp2T>(ge, ge);
+    return ge;
+}
+
+}  // namespace orc
