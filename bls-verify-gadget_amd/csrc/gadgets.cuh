@@ -1,0 +1,163 @@
+// Witness-emitting field "gadgets" for one instance per lane.
+// Each helper computes the value(s) that ark-r1cs-std ^0.4.0 would push onto
+// ConstraintSystem::witness_assignment for the corresponding Var x Var operation, in the same order,
+// and stores them (48 B, Montgomery, little-endian limbs) at the lane's cursor.
+// Operations with a constant operand are linear combinations in the circuit (no witness): callers use
+// the plain value functions of fp.cuh for those.  Rules: SURVEY.md App. A.1, A.2.
+#pragma once
+#include "fp.cuh"
+
+namespace blsw {
+
+struct Emitter {
+    uint32_t* base;  // this instance's witness vector (12 u32 per element), 16-byte aligned
+    uint32_t pos;    // element index of the next witness
+    BLSW_HD void put(const Fp& v) {
+        if (base == nullptr) {  // value-only mode (hash_to_g2 batch): no store, cursor still advances
+            pos++;
+            return;
+        }
+#if defined(__HIP_DEVICE_COMPILE__)
+        uint4* d = reinterpret_cast<uint4*>(base + (size_t)pos * 12);
+        d[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+        d[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+        d[2] = make_uint4(v.l[8], v.l[9], v.l[10], v.l[11]);
+#else
+        uint32_t* d = base + (size_t)pos * 12;
+        for (int i = 0; i < 12; i++) d[i] = v.l[i];
+#endif
+        pos++;
+    }
+    BLSW_HD void put_bool(bool b) {
+        Fp one = fp_one();
+        Fp v;
+#pragma unroll
+        for (int i = 0; i < 12; i++) v.l[i] = b ? one.l[i] : 0u;
+        put(v);
+    }
+};
+
+// ---- FpVar
+BLSW_HD Fp fp_mul_w(Emitter& e, const Fp& a, const Fp& b) {
+    Fp r = fp_mul(a, b);
+    e.put(r);
+    return r;
+}
+// AllocatedFp::is_neq(self, other): witnesses = [is_not_equal (boolean), multiplier]; returns is_eq.
+// Orientation matters: (Var v).is_eq(Constant c) is evaluated as c.is_eq(v), i.e. diff = c - v.
+BLSW_HD bool fp_is_eq_w(Emitter& e, const Fp& self, const Fp& other) {
+    Fp diff = fp_sub(self, other);
+    bool ne = !fp_is_zero(diff);
+    e.put_bool(ne);
+    Fp m = fp_inv(diff);  // uniform instruction stream: computed even when equal (result discarded)
+    e.put(ne ? m : fp_one());
+    return !ne;
+}
+BLSW_HD Fp fp_select_w(Emitter& e, bool cond, const Fp& t, const Fp& f) {
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < 12; i++) r.l[i] = cond ? t.l[i] : f.l[i];
+    e.put(r);
+    return r;
+}
+
+// ---- Fp2Var (QuadExtVar over FpVar)
+BLSW_HD Fp2 fp2_mul_w(Emitter& e, const Fp2& a, const Fp2& b) {
+    Fp v0 = fp_mul_w(e, a.c0, b.c0);
+    Fp v1 = fp_mul_w(e, a.c1, b.c1);
+    Fp s = fp_mul_w(e, fp_add(a.c0, a.c1), fp_add(b.c0, b.c1));
+    return {fp_sub(v0, v1), fp_sub(fp_sub(s, v0), v1)};
+}
+BLSW_HD Fp2 fp2_sqr_w(Emitter& e, const Fp2& a) {
+    Fp v2 = fp_mul_w(e, a.c0, a.c1);
+    Fp t = fp_mul_w(e, fp_sub(a.c0, a.c1), fp_add(a.c0, a.c1));
+    return {t, fp_dbl(v2)};
+}
+// QuadExtVar::inverse: witnesses inv.c0, inv.c1, then mul_equals' v1 = a.c1 * inv.c1
+BLSW_HD Fp2 fp2_inv_w(Emitter& e, const Fp2& a) {
+    Fp2 inv = fp2_inv(a);
+    e.put(inv.c0);
+    e.put(inv.c1);
+    fp_mul_w(e, a.c1, inv.c1);
+    return inv;
+}
+// FieldVar::mul_by_inverse_unchecked: witnesses r = num/den (c0, c1), then v1 = r.c1 * den.c1
+BLSW_HD Fp2 fp2_div_w(Emitter& e, const Fp2& num, const Fp2& den) {
+    Fp2 r = fp2_mul(num, fp2_inv(den));
+    e.put(r.c0);
+    e.put(r.c1);
+    fp_mul_w(e, r.c1, den.c1);
+    return r;
+}
+BLSW_HD bool fp2_is_eq_w(Emitter& e, const Fp2& self, const Fp2& other) {
+    bool b0 = fp_is_eq_w(e, self.c0, other.c0);
+    bool b1 = fp_is_eq_w(e, self.c1, other.c1);
+    bool r = b0 && b1;  // Not(ne0) AND Not(ne1) -> nor witness
+    e.put_bool(r);
+    return r;
+}
+// v.is_eq(Constant zero) / v.is_zero(): evaluated as zero.is_eq(v)
+BLSW_HD bool fp2_is_zero_w(Emitter& e, const Fp2& v) { return fp2_is_eq_w(e, fp2_zero(), v); }
+BLSW_HD Fp2 fp2_select_w(Emitter& e, bool cond, const Fp2& t, const Fp2& f) {
+    Fp c0 = fp_select_w(e, cond, t.c0, f.c0);
+    Fp c1 = fp_select_w(e, cond, t.c1, f.c1);
+    return {c0, c1};
+}
+
+// ---- FpVar::to_bits_le on a variable: 381 boolean witnesses (LSB first) followed by
+// Boolean::enforce_in_field_le's AND chain against p-1. Returns bit 0.
+BLSW_HD bool fp_to_bits_le_w(Emitter& e, const Fp& a) {
+    constexpr uint32_t P[12] = BLSW_P_LIMBS;
+    Fp c = fp_to_canonical(a);
+#pragma unroll 1
+    for (int i = 0; i < 381; i++) e.put_bool((c.l[i >> 5] >> (i & 31)) & 1);
+    // walk p-1 from the top bit; last_run starts as the constant true
+    bool last_run = true, last_is_const = true;
+    bool run_acc = true;
+    int run_len = 0;
+#pragma unroll 1
+    for (int i = 380; i >= 0; i--) {
+        uint32_t w = P[i >> 5];
+        if (i < 32) w -= 1;
+        bool pb = (w >> (i & 31)) & 1;
+        bool ab = (c.l[i >> 5] >> (i & 31)) & 1;
+        if (pb) {
+            // kary_and of the run is built left to right: each further element costs one AND witness
+            if (run_len == 0)
+                run_acc = ab;
+            else {
+                run_acc = run_acc && ab;
+            }
+            run_len++;
+            // AND witnesses inside a run are emitted when the run closes (order: run elements, then last_run)
+        } else {
+            if (run_len > 0) {
+                // kary_and([run..., last_run]): re-walk the run to emit its (run_len-1) partial ANDs in order
+                bool acc = true;
+                for (int k = 0; k < run_len; k++) {
+                    int bi = i + run_len - k;  // bits i+run_len .. i+1, high to low
+                    bool bb = (c.l[bi >> 5] >> (bi & 31)) & 1;
+                    if (k == 0)
+                        acc = bb;
+                    else {
+                        acc = acc && bb;
+                        e.put_bool(acc);
+                    }
+                }
+                if (!last_is_const) {
+                    acc = acc && last_run;
+                    e.put_bool(acc);
+                }
+                last_run = acc;
+                last_is_const = false;
+                run_len = 0;
+            }
+            // enforce_kary_nand([last_run, a]) -> one AND witness unless last_run is still the constant
+            if (!last_is_const) e.put_bool(last_run && ab);
+        }
+    }
+    (void)run_acc;
+    return c.l[0] & 1;
+}
+
+}  // namespace blsw

@@ -1,0 +1,69 @@
+// Witness-vector segment table (host side). Segment sizes are properties of the circuit shape:
+// the SHA-256 segment is obtained by running the mask propagation of sha.cuh in count-only mode
+// (no values, no stores); the field segments are the fixed constants below (pinned by tests against
+// the CPU oracle's allocation trace).
+#pragma once
+#include <vector>
+#include "../../include/blsw.h"
+#include "sha.cuh"
+
+namespace blsw {
+
+enum : uint32_t {
+    SEG_PK_ALLOC = 1942,     // 3 + 125 doublings * 11 + 47 additions * 12
+    SEG_SIG_ALLOC = 12413,   // 6 + 254 * 30 + 132 * 36 + 35 (enforce_equal)
+    SEG_PK_NOT_ZERO = 8,
+    SEG_MAP = 5889,
+    SEG_ADD = 36,
+    SEG_COFACTOR = 8979,
+    SEG_PREP_G2 = 1096,      // 18 + 63 * 16 + 5 * 14
+    SEG_PREP_PK = 7,
+    SEG_MILLER = 6826,       // 62 * 36 + 68 * (30 + 38) - 30
+    SEG_FINAL_EXP = 7848,
+    SEG_IS_ONE = 35,
+};
+
+inline void make_layout(uint32_t msg_len, blsw_layout_t* L) {
+    std::vector<uint8_t> msg(msg_len ? msg_len : 1, 0);
+    BitSink s;
+    s.init(nullptr, 0);
+    uint32_t uw[64];
+    expand_message_w(s, msg.data(), msg_len, false, uw);
+    L->msg_len = msg_len;
+    L->n_instance_vars = 1;
+    L->sha_bits = (uint32_t)s.nbits;
+    uint32_t o = 0;
+    L->off_msg = o;
+    o += 8 * msg_len;
+    L->off_pk_alloc = o;
+    o += SEG_PK_ALLOC;
+    L->off_sig_alloc = o;
+    o += SEG_SIG_ALLOC;
+    L->off_pk_not_zero = o;
+    o += SEG_PK_NOT_ZERO;
+    L->off_expand = o;
+    o += L->sha_bits;
+    L->off_map0 = o;
+    o += SEG_MAP;
+    L->off_map1 = o;
+    o += SEG_MAP;
+    L->off_add = o;
+    o += SEG_ADD;
+    L->off_cofactor = o;
+    o += SEG_COFACTOR;
+    L->off_prep_h = o;
+    o += SEG_PREP_G2;
+    L->off_prep_pk = o;
+    o += SEG_PREP_PK;
+    L->off_prep_sig = o;
+    o += SEG_PREP_G2;
+    L->off_miller = o;
+    o += SEG_MILLER;
+    L->off_final_exp = o;
+    o += SEG_FINAL_EXP;
+    L->off_is_one = o;
+    o += SEG_IS_ONE;
+    L->n_witness = o;
+}
+
+}  // namespace blsw

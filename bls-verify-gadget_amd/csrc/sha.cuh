@@ -1,0 +1,322 @@
+// In-circuit expand_message_xmd / hash_to_field of the reference (src/hasher.rs:58-173), one message per lane.
+// The SHA-256 gadget (ark-crypto-primitives ^0.4.0 crh/sha256/constraints.rs) allocates one
+// boolean witness per AND / XOR on variables and 33/34/35 booleans per UInt32::addmany; bits that are constants
+// (padding, DST, the all-constant Z_pad block, initial state) fold away. Which positions are constant is a
+// property of the circuit shape, identical for every lane; it is tracked in uniform masks next to the per-lane
+// values, so the kernel emits exactly the bits arkworks would allocate, in allocation order.
+// Output of this stage is a BITSTREAM (1 bit per boolean witness); sha_expand turns it into 48-byte Fp elements.
+#pragma once
+#include "fp.cuh"
+
+namespace blsw {
+
+struct W32 {
+    uint32_t v;   // boolean values of the 32 bits (negation applied)
+    uint32_t cm;  // 1 = bit is Boolean::Constant
+    uint32_t nm;  // 1 = bit is Boolean::Not(var)   (0 where constant)
+};
+BLSW_HD W32 w_const(uint32_t v) { return {v, 0xffffffffu, 0u}; }
+BLSW_HD uint32_t rotr32(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+BLSW_HD W32 w_rotr(const W32& a, int n) { return {rotr32(a.v, n), rotr32(a.cm, n), rotr32(a.nm, n)}; }
+BLSW_HD W32 w_shr(const W32& a, int n) { return {a.v >> n, (a.cm >> n) | ~(0xffffffffu >> n), a.nm >> n}; }
+BLSW_HD W32 w_not(const W32& a) { return {~a.v, a.cm, ~a.nm & ~a.cm}; }
+
+BLSW_HD uint32_t pext32(uint32_t v, uint32_t m) {
+    if (m == 0xffffffffu) return v;
+    if ((m & (m + 1)) == 0) return v & m;  // contiguous low mask
+    uint32_t r = 0, k = 0;
+    while (m) {
+        uint32_t low = m & (0u - m);
+        r |= ((v & low) ? 1u : 0u) << k;
+        k++;
+        m ^= low;
+    }
+    return r;
+}
+BLSW_HD int popc32(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __popc(x);
+#else
+    return __builtin_popcount(x);
+#endif
+}
+
+// Bit sink: either counts bits (layout) or packs them into 32-bit words stored at out[word * stride]
+struct BitSink {
+    uint32_t* out;    // nullptr = count only
+    uint64_t stride;  // distance (in u32) between consecutive words of this lane's stream
+    uint64_t acc;
+    uint32_t fill;
+    uint32_t widx;
+    uint64_t nbits;
+    BLSW_HD void init(uint32_t* o, uint64_t s) {
+        out = o;
+        stride = s;
+        acc = 0;
+        fill = 0;
+        widx = 0;
+        nbits = 0;
+    }
+    BLSW_HD void push(uint32_t bits, uint32_t n) {  // n <= 32, bits above n must be zero
+        nbits += n;
+        acc |= (uint64_t)bits << fill;
+        fill += n;
+        if (fill >= 32) {
+            if (out) out[(uint64_t)widx * stride] = (uint32_t)acc;
+            widx++;
+            acc >>= 32;
+            fill -= 32;
+        }
+    }
+    BLSW_HD void flush() {
+        if (fill) {
+            if (out) out[(uint64_t)widx * stride] = (uint32_t)acc;
+            widx++;
+            acc = 0;
+            fill = 0;
+        }
+    }
+};
+
+BLSW_HD W32 w_xor(BitSink& s, const W32& a, const W32& b) {
+    uint32_t wm = ~a.cm & ~b.cm;
+    if (wm) s.push(pext32((a.v ^ a.nm) ^ (b.v ^ b.nm), wm), popc32(wm));
+    W32 r;
+    r.v = a.v ^ b.v;
+    r.cm = a.cm & b.cm;
+    r.nm = (a.nm ^ b.nm ^ (a.cm & a.v) ^ (b.cm & b.v)) & ~r.cm;
+    return r;
+}
+BLSW_HD W32 w_and(BitSink& s, const W32& a, const W32& b) {
+    uint32_t wm = ~a.cm & ~b.cm;
+    if (wm) s.push(pext32(a.v & b.v, wm), popc32(wm));
+    W32 r;
+    r.v = a.v & b.v;
+    uint32_t a_false = a.cm & ~a.v, b_false = b.cm & ~b.v, a_true = a.cm & a.v, b_true = b.cm & b.v;
+    r.cm = (a.cm & b.cm) | a_false | b_false;
+    r.nm = ((a_true & b.nm) | (b_true & a.nm)) & ~r.cm;
+    return r;
+}
+// UInt32::addmany over k operands
+BLSW_HD W32 w_addmany(BitSink& s, const W32* ops, int k) {
+    uint64_t sum = 0;
+    uint32_t allc = 0xffffffffu;
+    for (int i = 0; i < k; i++) {
+        sum += ops[i].v;
+        allc &= ops[i].cm;
+    }
+    if (allc == 0xffffffffu) return w_const((uint32_t)sum);
+    int nbits = (k == 2) ? 33 : (k <= 4 ? 34 : 35);
+    s.push((uint32_t)sum, 32);
+    s.push((uint32_t)(sum >> 32), nbits - 32);
+    return {(uint32_t)sum, 0u, 0u};
+}
+
+#define BLSW_SHA_K                                                                                                                                  \
+    {                                                                                                                                               \
+        0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be,         \
+            0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa,     \
+            0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85,     \
+            0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3,     \
+            0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f,     \
+            0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2                              \
+    }
+#define BLSW_SHA_H0                                                                                          \
+    {                                                                                                        \
+        0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19 \
+    }
+
+// Sha256Gadget::update_state
+BLSW_HD void sha_block_w(BitSink& s, W32 st[8], const W32 data[16]) {
+    constexpr uint32_t K[64] = BLSW_SHA_K;
+    W32 w[64];
+    for (int i = 0; i < 16; i++) w[i] = data[i];
+#pragma unroll 1
+    for (int i = 16; i < 64; i++) {
+        W32 a1 = w_xor(s, w_rotr(w[i - 15], 7), w_rotr(w[i - 15], 18));
+        W32 s0 = w_xor(s, a1, w_shr(w[i - 15], 3));
+        W32 b1 = w_xor(s, w_rotr(w[i - 2], 17), w_rotr(w[i - 2], 19));
+        W32 s1 = w_xor(s, b1, w_shr(w[i - 2], 10));
+        W32 ops[4] = {w[i - 16], s0, w[i - 7], s1};
+        w[i] = w_addmany(s, ops, 4);
+    }
+    W32 h[8];
+    for (int i = 0; i < 8; i++) h[i] = st[i];
+#pragma unroll 1
+    for (int i = 0; i < 64; i++) {
+        W32 c1 = w_and(s, h[4], h[5]);
+        W32 c2 = w_and(s, w_not(h[4]), h[6]);
+        W32 ch = w_xor(s, c1, c2);
+        W32 m1 = w_and(s, h[0], h[1]);
+        W32 m2 = w_and(s, h[0], h[2]);
+        W32 m3 = w_and(s, h[1], h[2]);
+        W32 m12 = w_xor(s, m1, m2);
+        W32 ma = w_xor(s, m12, m3);
+        W32 p1 = w_xor(s, w_rotr(h[0], 2), w_rotr(h[0], 13));
+        W32 s0 = w_xor(s, p1, w_rotr(h[0], 22));
+        W32 q1 = w_xor(s, w_rotr(h[4], 6), w_rotr(h[4], 11));
+        W32 s1 = w_xor(s, q1, w_rotr(h[4], 25));
+        W32 o5[5] = {h[7], s1, ch, w_const(K[i]), w[i]};
+        W32 t0 = w_addmany(s, o5, 5);
+        W32 o2[2] = {s0, ma};
+        W32 t1 = w_addmany(s, o2, 2);
+        h[7] = h[6];
+        h[6] = h[5];
+        h[5] = h[4];
+        W32 o3[2] = {h[3], t0};
+        h[4] = w_addmany(s, o3, 2);
+        h[3] = h[2];
+        h[2] = h[1];
+        h[1] = h[0];
+        W32 o4[2] = {t0, t1};
+        h[0] = w_addmany(s, o4, 2);
+    }
+    for (int i = 0; i < 8; i++) {
+        W32 o[2] = {st[i], h[i]};
+        st[i] = w_addmany(s, o, 2);
+    }
+}
+
+#define BLSW_DST "BLS_SIG_BLS12381G2_XMD:SHA-256_SSWU_RO_POP_"
+#define BLSW_DST_LEN 43
+
+// byte k of msg_prime = Z_pad(64) | msg | I2OSP(256,2) (witness) | 0 | DST | len(DST), followed by SHA padding
+BLSW_HD void b0_byte(const uint8_t* msg, uint32_t msg_len, bool msg_const, uint32_t k, uint32_t total, uint32_t& val, bool& konst) {
+    const char dst[] = BLSW_DST;
+    konst = true;
+    val = 0;
+    if (k < 64) return;
+    uint32_t o = k - 64;
+    if (o < msg_len) {
+        val = msg[o];
+        konst = msg_const;
+        return;
+    }
+    o -= msg_len;
+    if (o < 2) {  // lib_str = 0x0100, allocated as witness bytes (hasher.rs:130-132)
+        val = (o == 0) ? 1 : 0;
+        konst = false;
+        return;
+    }
+    o -= 2;
+    if (o == 0) return;  // the single zero byte
+    o -= 1;
+    if (o < BLSW_DST_LEN) {
+        val = (uint8_t)dst[o];
+        return;
+    }
+    if (o == BLSW_DST_LEN) {
+        val = BLSW_DST_LEN;
+        return;
+    }
+    // SHA padding of a `total`-byte message
+    uint32_t padded = ((total + 9 + 63) / 64) * 64;
+    if (k == total) {
+        val = 0x80;
+        return;
+    }
+    if (k >= padded - 8) {
+        uint64_t bitlen = (uint64_t)total * 8;
+        val = (uint32_t)(bitlen >> (8 * (padded - 1 - k))) & 0xff;
+    }
+}
+
+// Runs the whole expand_message_xmd (len_in_bytes = 256) gadget for one message.
+// Emits the 16 lib_str booleans first (they are allocated before the first digest), then every SHA witness.
+// out_words: the 8 digests b1..b8 as 64 big-endian words (uniform_bytes).
+BLSW_HD void expand_message_w(BitSink& s, const uint8_t* msg, uint32_t msg_len, bool msg_const, uint32_t uniform_words[64]) {
+    constexpr uint32_t H0[8] = BLSW_SHA_H0;
+    const char dst[] = BLSW_DST;
+    // lib_str_var: two witness bytes, little-endian bit order each: 0x01, 0x00
+    s.push(0x0001u, 16);
+    // ---- b0
+    W32 st[8];
+    for (int i = 0; i < 8; i++) st[i] = w_const(H0[i]);
+    uint32_t total = 64 + msg_len + 3 + BLSW_DST_LEN + 1;
+    uint32_t nblocks = (total + 9 + 63) / 64;
+#pragma unroll 1
+    for (uint32_t blk = 0; blk < nblocks; blk++) {
+        W32 data[16];
+        for (int wi = 0; wi < 16; wi++) {
+            uint32_t v = 0, cm = 0;
+            for (int b = 0; b < 4; b++) {
+                uint32_t bv;
+                bool bc;
+                b0_byte(msg, msg_len, msg_const, blk * 64 + wi * 4 + b, total, bv, bc);
+                v |= bv << (8 * (3 - b));
+                if (bc) cm |= 0xffu << (8 * (3 - b));
+            }
+            data[wi] = {v, cm, 0u};
+        }
+        sha_block_w(s, st, data);
+    }
+    W32 b0[8];
+    for (int i = 0; i < 8; i++) b0[i] = st[i];
+    // ---- b1 .. b8 : H(prev(32) | i | DST') ; 77 bytes -> 2 blocks
+    W32 last[8];
+#pragma unroll 1
+    for (uint32_t i = 1; i <= 8; i++) {
+        W32 in[8];
+        if (i == 1) {
+            for (int k = 0; k < 8; k++) in[k] = b0[k];
+        } else {
+            // bytewise UInt8 xor of b0 and b_(i-1): witnesses in byte order (big-endian bytes of each word),
+            // little-endian bits inside a byte
+            for (int k = 0; k < 8; k++) {
+                const W32 &a = b0[k], &b = last[k];
+                uint32_t wm = ~a.cm & ~b.cm;
+                uint32_t x = (a.v ^ a.nm) ^ (b.v ^ b.nm);
+                for (int by = 3; by >= 0; by--) {
+                    uint32_t m8 = (wm >> (8 * by)) & 0xff;
+                    if (m8) s.push(pext32((x >> (8 * by)) & 0xff, m8), popc32(m8));
+                }
+                in[k].v = a.v ^ b.v;
+                in[k].cm = a.cm & b.cm;
+                in[k].nm = (a.nm ^ b.nm ^ (a.cm & a.v) ^ (b.cm & b.v)) & ~in[k].cm;
+            }
+        }
+        for (int k = 0; k < 8; k++) st[k] = w_const(H0[k]);
+        // bytes 32..76: i, DST(43), 43 ; byte 77: 0x80 ; bytes 120..127: bit length 616
+        uint8_t tailb[96];
+        for (int k = 0; k < 96; k++) tailb[k] = 0;
+        tailb[0] = (uint8_t)i;
+        for (int k = 0; k < BLSW_DST_LEN; k++) tailb[1 + k] = (uint8_t)dst[k];
+        tailb[1 + BLSW_DST_LEN] = BLSW_DST_LEN;
+        tailb[2 + BLSW_DST_LEN] = 0x80;
+        tailb[94] = (uint8_t)((77 * 8) >> 8);
+        tailb[95] = (uint8_t)((77 * 8) & 0xff);
+        W32 data[16];
+        for (int k = 0; k < 8; k++) data[k] = in[k];
+        for (int k = 0; k < 8; k++)
+            data[8 + k] = w_const(((uint32_t)tailb[4 * k] << 24) | ((uint32_t)tailb[4 * k + 1] << 16) | ((uint32_t)tailb[4 * k + 2] << 8) | tailb[4 * k + 3]);
+        sha_block_w(s, st, data);
+        for (int k = 0; k < 16; k++)
+            data[k] = w_const(((uint32_t)tailb[32 + 4 * k] << 24) | ((uint32_t)tailb[33 + 4 * k] << 16) | ((uint32_t)tailb[34 + 4 * k] << 8) | tailb[35 + 4 * k]);
+        sha_block_w(s, st, data);
+        for (int k = 0; k < 8; k++) {
+            last[k] = st[k];
+            uniform_words[(i - 1) * 8 + k] = st[k].v;
+        }
+    }
+    s.flush();
+}
+
+// hash_to_field (hasher.rs:58-107): element j (0..3) = OS2IP(uniform_bytes[64j .. 64j+64)) mod p as
+// head(47 high bytes) * 256^17 + tail(17 low bytes); linear combinations only (no witnesses).
+BLSW_HD Fp hash_to_field_elem(const uint32_t* W /*16 big-endian words*/) {
+    constexpr uint32_t R2[12] = BLSW_R2_LIMBS;
+    uint32_t L[16];
+    for (int i = 0; i < 16; i++) L[i] = W[15 - i];
+    Fp tail = fp_zero(), head = fp_zero(), r2;
+    for (int i = 0; i < 12; i++) r2.l[i] = R2[i];
+    for (int i = 0; i < 4; i++) tail.l[i] = L[i];
+    tail.l[4] = L[4] & 0xff;
+    for (int k = 0; k < 11; k++) head.l[k] = (L[k + 4] >> 8) | (L[k + 5] << 24);
+    head.l[11] = L[15] >> 8;
+    Fp two136 = fp_zero();  // 2^136 as a canonical integer
+    two136.l[4] = 1u << 8;
+    Fp hm = fp_mul(head, r2), tm = fp_mul(tail, r2), km = fp_mul(two136, r2);
+    return fp_add(fp_mul(hm, km), tm);
+}
+
+}  // namespace blsw

@@ -1,0 +1,73 @@
+/* blsw — MI355X-native batched witness generation for the BLS12-381 signature-verify R1CS gadget.
+ *
+ * C ABI of libblsw.so (HIP, gfx950). The reference (lightec-xyz/bls-verify-gadget) has NO FFI: the path sits
+ * behind the arkworks trait surface
+ *     impl SigVerifyGadget<BLS<P>, P::Fp> for BlsSignatureVerifyGadget<P>::verify     src/constraints.rs:79-128
+ *     AllocVar for ParametersVar / PublicKeyVar / SignatureVar                         src/constraints.rs:194-249
+ *     hash_to_g2_with_cons(cs, &[UInt8]) -> G2Var                                      src/hasher.rs:727-740
+ * and the data an arkworks prover consumes from it is ConstraintSystem::witness_assignment (Vec<Fq>, Montgomery
+ * form, allocation order). These entry points replace exactly that side effect, batched over instances; they are
+ * what a Rust `extern "C"` shim binds.
+ *
+ * Conventions: caller-allocated buffers, integer return codes (0 = ok), no exceptions across the ABI,
+ * re-entrant per (device, stream). All `d_*` pointers are DEVICE pointers on the current HIP device.
+ * A field element is 6 little-endian u64 limbs in Montgomery form (R = 2^384) == arkworks' in-memory Fq.
+ */
+#ifndef BLSW_H
+#define BLSW_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BLSW_OK 0
+#define BLSW_ERR_ARG 1
+#define BLSW_ERR_WORKSPACE 2
+#define BLSW_ERR_HIP 3
+#define BLSW_ERR_NO_DEVICE 4
+
+/* per-instance input status (mirrors src/bls.rs:434-447 and the deserialization fixtures) */
+#define BLSW_ST_OK 0
+#define BLSW_ST_BAD_ENCODING 1
+#define BLSW_ST_NOT_ON_CURVE 2
+#define BLSW_ST_NOT_IN_SUBGROUP 3
+#define BLSW_ST_IDENTITY 4
+
+/* Segment table of one instance's witness vector for the circuit of src/constraints.rs:335-366
+ * (msg witness bytes, params Constant, pk Witness, sig Witness, then verify). Offsets are in field elements. */
+typedef struct {
+    uint32_t msg_len;
+    uint32_t n_instance_vars; /* 1: the constant one (this gadget allocates no public input) */
+    uint32_t n_witness;       /* witness_assignment length */
+    uint32_t sha_bits;        /* boolean witnesses of the expand_message segment (16 lib_str bits + SHA-256 gadget) */
+    uint32_t off_msg, off_pk_alloc, off_sig_alloc, off_pk_not_zero, off_expand, off_map0, off_map1, off_add, off_cofactor, off_prep_h, off_prep_pk,
+        off_prep_sig, off_miller, off_final_exp, off_is_one;
+} blsw_layout_t;
+
+/* layout(circuit shape) — replaces reading cs.num_witness_variables() after synthesis (constraints.rs:369-373). Host only. */
+int blsw_layout(uint32_t msg_len, blsw_layout_t* out);
+
+/* bytes of device workspace blsw_witness_batch needs for n instances */
+int blsw_workspace_bytes(uint64_t n, uint32_t msg_len, uint64_t* bytes);
+
+/* Fills the witness vectors of n independent (pk, msg, sig) instances.
+ *   d_pk_xy   [n][12] u64  affine G1 (x, y) Montgomery; (0,0) = point at infinity      (PublicKeyVar, constraints.rs:214-232)
+ *   d_sig_xy  [n][24] u64  affine G2 (x.c0, x.c1, y.c0, y.c1); all zero = infinity     (SignatureVar, constraints.rs:234-249)
+ *   d_msg     [n][msg_len] bytes                                                        (UInt8::new_witness_vec, constraints.rs:341)
+ *   d_witness [n][witness_stride] field elements (48 B each), witness_stride >= layout.n_witness; may be NULL (results only)
+ *   d_result  [n] int32: value of the gadget's output Boolean (constraints.rs:127)
+ * Asynchronous on `stream` (hipStream_t, may be NULL). */
+int blsw_witness_batch(const uint64_t* d_pk_xy, const uint64_t* d_sig_xy, const uint8_t* d_msg, uint32_t msg_len, uint64_t n, uint64_t* d_witness,
+                       uint64_t witness_stride, int32_t* d_result, void* d_workspace, uint64_t workspace_bytes, void* stream);
+
+/* hash_to_g2 only (src/hasher.rs:727-740 / src/bls.rs:477-493): d_out_affine [n][24] u64 (x.c0, x.c1, y.c0, y.c1) Montgomery */
+int blsw_hash_to_g2_batch(const uint8_t* d_msg, uint32_t msg_len, uint64_t n, uint64_t* d_out_affine, void* d_workspace, uint64_t workspace_bytes,
+                          void* stream);
+
+/* Stage timing hooks for bench.py: runs only the named stage (0 = all). See DESIGN.md. */
+int blsw_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

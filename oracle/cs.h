@@ -130,7 +130,7 @@ inline Bool bxor(const Bool& a, const Bool& b) {
     // both allocated: witness = xor of the underlying variables; (2a)*b = a + b - c
     bool va = bvarval(a), vb = bvarval(b);
     Bool r = balloc_nocheck(va ^ vb);
-    CSREF.enforce(lc_scale(lc_var(a.var), fp_from_u64(2)), lc_var(b.var),
+    CSREF.enforce(recording() ? lc_scale(lc_var(a.var), fp_from_u64(2)) : nullptr, lc_var(b.var),
                   lc_sub(lc_add(lc_var(a.var), lc_var(b.var)), lc_var(r.var)));
     if (a.kind != b.kind) return bnot(r);
     return r;

@@ -1,0 +1,69 @@
+// TEST HARNESS ONLY (never linked into libblsw.so): compiles the device headers of
+// bls-verify-gadget_amd/csrc for the HOST with g++ and runs the witness chains for ONE instance on one
+// "lane", so that kernel logic can be checked against the CPU oracle without a GPU (pytest -m "not gpu").
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include "../../bls-verify-gadget_amd/csrc/chains.cuh"
+#include "../../bls-verify-gadget_amd/csrc/layout.h"
+
+using namespace blsw;
+
+static Fp load_fp(const uint64_t* p) {
+    Fp r;
+    memcpy(r.l, p, 48);
+    return r;
+}
+
+extern "C" {
+int hostsim_layout(uint32_t msg_len, blsw_layout_t* L) {
+    make_layout(msg_len, L);
+    return 0;
+}
+// out: n_witness * 6 u64. returns gadget result (0/1); seg_ends (optional, 16 u32): cursor after each chain
+int hostsim_witness(const uint64_t* pk_xy, const uint8_t* msg, uint32_t msg_len, const uint64_t* sig_xy, uint64_t* out, uint32_t* seg_ends) {
+    blsw_layout_t L;
+    make_layout(msg_len, &L);
+    uint32_t* base = reinterpret_cast<uint32_t*>(out);
+    // msg bits (UInt8::new_witness_vec)
+    Emitter em = {base, L.off_msg};
+    for (uint32_t i = 0; i < msg_len; i++)
+        for (int j = 0; j < 8; j++) em.put_bool((msg[i] >> j) & 1);
+    // G1 / G2 allocation
+    Fp pkx = load_fp(pk_xy), pky = load_fp(pk_xy + 6);
+    G1ChainOut g1 = chain_g1_alloc({base, L.off_pk_alloc}, {base, L.off_pk_not_zero}, {base, L.off_prep_pk}, pkx, pky);
+    Fp2 sx = {load_fp(sig_xy), load_fp(sig_xy + 6)}, sy = {load_fp(sig_xy + 12), load_fp(sig_xy + 18)};
+    chain_g2_alloc({base, L.off_sig_alloc}, sx, sy);
+    // expand_message: bitstream then expansion
+    std::vector<uint32_t> bits((L.sha_bits + 31) / 32 + 1, 0);
+    BitSink s;
+    s.init(bits.data(), 1);
+    uint32_t uw[64];
+    expand_message_w(s, msg, msg_len, false, uw);
+    if (s.nbits != L.sha_bits) return -1;
+    Emitter ex = {base, L.off_expand};
+    for (uint32_t i = 0; i < L.sha_bits; i++) ex.put_bool((bits[i >> 5] >> (i & 31)) & 1);
+    Fp2 u0 = {hash_to_field_elem(uw), hash_to_field_elem(uw + 16)};
+    Fp2 u1 = {hash_to_field_elem(uw + 32), hash_to_field_elem(uw + 48)};
+    Proj<OpsFp2> q0 = chain_map_to_curve({base, L.off_map0}, u0);
+    Proj<OpsFp2> q1 = chain_map_to_curve({base, L.off_map1}, u1);
+    Proj<OpsFp2> h = chain_cofactor({base, L.off_add}, {base, L.off_cofactor}, q0, q1);
+    std::vector<Fp> ch(68 * 4), cs(68 * 4);
+    chain_prepare_g2({base, L.off_prep_h}, h, ch.data());
+    bool sinf = fp2_is_zero(sx) && fp2_is_zero(sy);
+    Proj<OpsFp2> sp = {sinf ? fp2_zero() : sx, sinf ? fp2_one() : sy, sinf ? fp2_zero() : fp2_one()};
+    chain_prepare_g2({base, L.off_prep_sig}, sp, cs.data());
+    bool res = chain_pairing({base, L.off_miller}, {base, L.off_final_exp}, {base, L.off_is_one}, g1.ax, g1.ay, cs.data(), ch.data());
+    (void)seg_ends;
+    return res ? 1 : 0;
+}
+// field micro-checks
+void hostsim_fp_mul(const uint64_t* a, const uint64_t* b, uint64_t* r) {
+    Fp z = fp_mul(load_fp(a), load_fp(b));
+    memcpy(r, z.l, 48);
+}
+void hostsim_fp_inv(const uint64_t* a, uint64_t* r) {
+    Fp z = fp_inv(load_fp(a));
+    memcpy(r, z.l, 48);
+}
+}
