@@ -332,12 +332,18 @@ BLSW_HD Proj<OpsFp2> chain_cofactor(Emitter e_add, Emitter e, const Proj<OpsFp2>
 }
 
 // ------------------------------------------------------------------------------------------------ prepare_g2
-// coeffs: 68 pairs (c0, c1), written to `out` as 4 Fp each in the order c0.c0, c0.c1, c1.c0, c1.c1
-BLSW_HD void chain_prepare_g2(Emitter e, const Proj<OpsFp2>& q_, Fp* out) {
+// coeffs: 68 pairs (c0, c1) handed to `out.st(4k + j, .)` in the order c0.c0, c0.c1, c1.c0, c1.c1
+struct CoeffLinear {  // plain array (host harness)
+    Fp* p;
+    BLSW_HD void st(uint32_t idx, const Fp& v) const { p[idx] = v; }
+    BLSW_HD Fp ld(uint32_t idx) const { return p[idx]; }
+};
+template <class C>
+BLSW_HD void chain_prepare_g2(Emitter e, const Proj<OpsFp2>& q_, const C& out) {
     Aff2Inf q = g2_to_affine_w(e, q_);
     const Fp two_inv = K_TWO_INV();
     Fp2 rx = q.x, ry = q.y;
-    int k = 0;
+    uint32_t k = 0;
 #pragma unroll 1
     for (int i = 62; i >= 0; i--) {
         {  // double
@@ -353,10 +359,10 @@ BLSW_HD void chain_prepare_g2(Emitter e, const Proj<OpsFp2>& q_, Fp* out) {
             Fp2 f = fp2_neg(c);
             rx = x3;
             ry = y3;
-            out[4 * k + 0] = ee.c0;
-            out[4 * k + 1] = ee.c1;
-            out[4 * k + 2] = f.c0;
-            out[4 * k + 3] = f.c1;
+            out.st(4 * k + 0, ee.c0);
+            out.st(4 * k + 1, ee.c1);
+            out.st(4 * k + 2, f.c0);
+            out.st(4 * k + 3, f.c1);
             k++;
         }
         if ((BLSW_X_ABS >> i) & 1) {  // add
@@ -371,28 +377,29 @@ BLSW_HD void chain_prepare_g2(Emitter e, const Proj<OpsFp2>& q_, Fp* out) {
             Fp2 f = fp2_neg(c);
             rx = x3;
             ry = y3;
-            out[4 * k + 0] = g.c0;
-            out[4 * k + 1] = g.c1;
-            out[4 * k + 2] = f.c0;
-            out[4 * k + 3] = f.c1;
+            out.st(4 * k + 0, g.c0);
+            out.st(4 * k + 1, g.c1);
+            out.st(4 * k + 2, f.c0);
+            out.st(4 * k + 3, f.c1);
             k++;
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------ pairing
-BLSW_HD Fp2 load_fp2(const Fp* p) { return {p[0], p[1]}; }
 // ell for the pair (-g1 constant, sig): c1 * p.x is a linear combination, d1 = (p.y, 0) constant
-BLSW_HD Fp12 ell_const_p_w(Emitter& e, const Fp12& f, const Fp* coeff, bool f_is_const) {
-    Fp2 c0 = load_fp2(coeff), c1 = load_fp2(coeff + 2);
+template <class C>
+BLSW_HD Fp12 ell_const_p_w(Emitter& e, const Fp12& f, const C& coeff, uint32_t k, bool f_is_const) {
+    Fp2 c0 = {coeff.ld(4 * k + 0), coeff.ld(4 * k + 1)}, c1 = {coeff.ld(4 * k + 2), coeff.ld(4 * k + 3)};
     const Fp px = K_G1_GEN_X(), py = K_G1_GEN_NEG_Y();
     c1 = fp2_mul_fp(c1, px);
     if (f_is_const) return fp12_mul_by_014_const_f(f, c0, c1, py);
     return fp12_mul_by_014_w<false>(e, f, c0, c1, py);
 }
 // ell for the pair (pk variable, H(m)): c1.c0*p.x and c1.c1*p.x are witnesses, d1 = (p.y, 0) with p.y variable
-BLSW_HD Fp12 ell_var_p_w(Emitter& e, const Fp12& f, const Fp* coeff, const Fp& px, const Fp& py) {
-    Fp2 c0 = load_fp2(coeff), c1 = load_fp2(coeff + 2);
+template <class C>
+BLSW_HD Fp12 ell_var_p_w(Emitter& e, const Fp12& f, const C& coeff, uint32_t k, const Fp& px, const Fp& py) {
+    Fp2 c0 = {coeff.ld(4 * k + 0), coeff.ld(4 * k + 1)}, c1 = {coeff.ld(4 * k + 2), coeff.ld(4 * k + 3)};
     Fp k0 = fp_mul_w(e, c1.c0, px);
     Fp k1 = fp_mul_w(e, c1.c1, px);
     c1 = {k0, k1};
@@ -408,25 +415,28 @@ BLSW_HD bool fp6_is_eq_w(Emitter& e, const Fp6& self, const Fp6& other) {
     e.put_bool(r);
     return r;
 }
-// miller_loop([-g1, pk], [sig, H]) . final_exponentiation . is_one
-BLSW_HD bool chain_pairing(Emitter e_miller, Emitter e_fe, Emitter e_one, const Fp& pkx, const Fp& pky, const Fp* coeff_sig, const Fp* coeff_h) {
+// miller_loop([-g1, pk], [sig, H])
+template <class C>
+BLSW_HD Fp12 chain_miller(Emitter e, const Fp& pkx, const Fp& pky, const C& coeff_sig, const C& coeff_h) {
     Fp12 f = fp12_one();
-    int k = 0;
-    Emitter& e = e_miller;
+    uint32_t k = 0;
 #pragma unroll 1
     for (int i = 62; i >= 0; i--) {
         bool first = (i == 62);
         if (!first) f = fp12_sqr_w(e, f);
-        f = ell_const_p_w(e, f, coeff_sig + 4 * k, first);
-        f = ell_var_p_w(e, f, coeff_h + 4 * k, pkx, pky);
+        f = ell_const_p_w(e, f, coeff_sig, k, first);
+        f = ell_var_p_w(e, f, coeff_h, k, pkx, pky);
         k++;
         if ((BLSW_X_ABS >> i) & 1) {
-            f = ell_const_p_w(e, f, coeff_sig + 4 * k, false);
-            f = ell_var_p_w(e, f, coeff_h + 4 * k, pkx, pky);
+            f = ell_const_p_w(e, f, coeff_sig, k, false);
+            f = ell_var_p_w(e, f, coeff_h, k, pkx, pky);
             k++;
         }
     }
-    f = fp12_conj(f);
+    return fp12_conj(f);
+}
+// final_exponentiation . is_one
+BLSW_HD bool chain_final_exp_is_one(Emitter e_fe, Emitter e_one, const Fp12& f) {
     // final exponentiation
     Emitter& g = e_fe;
     Fp12 f1 = fp12_conj(f);

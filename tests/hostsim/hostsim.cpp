@@ -49,11 +49,12 @@ int hostsim_witness(const uint64_t* pk_xy, const uint8_t* msg, uint32_t msg_len,
     Proj<OpsFp2> q1 = chain_map_to_curve({base, L.off_map1}, u1);
     Proj<OpsFp2> h = chain_cofactor({base, L.off_add}, {base, L.off_cofactor}, q0, q1);
     std::vector<Fp> ch(68 * 4), cs(68 * 4);
-    chain_prepare_g2({base, L.off_prep_h}, h, ch.data());
+    chain_prepare_g2({base, L.off_prep_h}, h, CoeffLinear{ch.data()});
     bool sinf = fp2_is_zero(sx) && fp2_is_zero(sy);
     Proj<OpsFp2> sp = {sinf ? fp2_zero() : sx, sinf ? fp2_one() : sy, sinf ? fp2_zero() : fp2_one()};
-    chain_prepare_g2({base, L.off_prep_sig}, sp, cs.data());
-    bool res = chain_pairing({base, L.off_miller}, {base, L.off_final_exp}, {base, L.off_is_one}, g1.ax, g1.ay, cs.data(), ch.data());
+    chain_prepare_g2({base, L.off_prep_sig}, sp, CoeffLinear{cs.data()});
+    Fp12 fm = chain_miller({base, L.off_miller}, g1.ax, g1.ay, CoeffLinear{cs.data()}, CoeffLinear{ch.data()});
+    bool res = chain_final_exp_is_one({base, L.off_final_exp}, {base, L.off_is_one}, fm);
     (void)seg_ends;
     return res ? 1 : 0;
 }
