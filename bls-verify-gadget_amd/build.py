@@ -1,0 +1,34 @@
+"""Builds libblsw.so (HIP, gfx950) in-tree. hipcc cross-compiles without a GPU."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libblsw.so")
+SOURCES = ["kernels.hip"]
+HEADERS = ["fp.cuh", "gadgets.cuh", "constants.cuh", "curve.cuh", "tower.cuh", "sha.cuh", "chains.cuh", "layout.h"]
+
+
+def needs_build():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(HERE, "..", "include", "blsw.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return OUT
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-o", OUT] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        cmd.append("-Rpass-analysis=kernel-resource-usage")
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd, cwd=CSRC)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)

@@ -16,7 +16,7 @@ namespace blsw {
 BLSW_HD bool bit_of(const uint32_t* words, int i) { return (words[i >> 5] >> (i & 31)) & 1; }
 
 // [is_not_equal, multiplier] for diff = self - other whose inverse (or 0) the caller already has
-BLSW_HD bool fp_is_eq_pre_w(Emitter& e, const Fp& diff, const Fp& diff_inv) {
+BLSW_FN bool fp_is_eq_pre_w(Emitter& e, const Fp& diff, const Fp& diff_inv) {
     bool ne = !fp_is_zero(diff);
     e.put_bool(ne);
     e.put(ne ? diff_inv : fp_one());
@@ -27,7 +27,7 @@ BLSW_HD bool fp_is_eq_pre_w(Emitter& e, const Fp& diff, const Fp& diff_inv) {
 struct G1ChainOut {
     Fp ax, ay;  // prepare_g1(pk): affine coordinates (after the infinity select)
 };
-BLSW_HD G1ChainOut chain_g1_alloc(Emitter e_alloc, Emitter e_notzero, Emitter e_prep, const Fp& pkx, const Fp& pky) {
+BLSW_FN G1ChainOut chain_g1_alloc(Emitter e_alloc, Emitter e_notzero, Emitter e_prep, const Fp& pkx, const Fp& pky) {
     constexpr uint32_t H1[4] = BLSW_H1_WORDS;
     constexpr uint32_t H1INV[8] = BLSW_H1INV_WORDS;
     bool inf = fp_is_zero(pkx) && fp_is_zero(pky);
@@ -71,7 +71,7 @@ BLSW_HD G1ChainOut chain_g1_alloc(Emitter e_alloc, Emitter e_notzero, Emitter e_
 }
 
 // ------------------------------------------------------------------------------------------------ G2 allocation
-BLSW_HD void chain_g2_alloc(Emitter e, const Fp2& sx, const Fp2& sy) {
+BLSW_FN void chain_g2_alloc(Emitter e, const Fp2& sx, const Fp2& sy) {
     constexpr uint32_t RM1[8] = BLSW_RM1_WORDS;
     bool inf = fp2_is_zero(sx) && fp2_is_zero(sy);
     Proj<OpsFp2> ge;
@@ -102,7 +102,7 @@ BLSW_HD void chain_g2_alloc(Emitter e, const Fp2& sx, const Fp2& sy) {
 }
 
 // ------------------------------------------------------------------------------------------------ map_to_curve
-BLSW_HD Fp2 sswu_pow_c1_w(Emitter& e, const Fp2& v) {
+BLSW_FN Fp2 sswu_pow_c1_w(Emitter& e, const Fp2& v) {
     constexpr uint32_t C1[24] = BLSW_SSWU_C1_WORDS;
     // bits 759, 758 are 0 and bit 757 is the first 1: r stays the constant one, then becomes 1*v (no witness)
     Fp2 r = v;
@@ -114,7 +114,7 @@ BLSW_HD Fp2 sswu_pow_c1_w(Emitter& e, const Fp2& v) {
     return r;
 }
 // sgn0 (hasher.rs:520-530)
-BLSW_HD bool sswu_sgn0_w(Emitter& e, const Fp2& v) {
+BLSW_FN bool sswu_sgn0_w(Emitter& e, const Fp2& v) {
     bool sign_0 = fp_to_bits_le_w(e, v.c0);
     bool sign_1 = fp_to_bits_le_w(e, v.c1);
     bool zero_0 = fp_is_eq_w(e, fp_zero(), v.c0);
@@ -124,13 +124,13 @@ BLSW_HD bool sswu_sgn0_w(Emitter& e, const Fp2& v) {
     e.put_bool(s);
     return s;
 }
-BLSW_HD Fp2 poly_step_w(Emitter& e, Fp2& result, Fp2& curr_pow, const Fp2& coeff, const Fp2& point, bool pow_is_const_one) {
+BLSW_FN Fp2 poly_step_w(Emitter& e, Fp2& result, Fp2& curr_pow, const Fp2& coeff, const Fp2& point, bool pow_is_const_one) {
     // term = curr_pow * coeff (constant coefficient: no witness); curr_pow *= point (witness unless curr_pow == const 1)
     result = fp2_add(result, pow_is_const_one ? coeff : fp2_mul(curr_pow, coeff));
     curr_pow = pow_is_const_one ? point : fp2_mul_w(e, curr_pow, point);
     return result;
 }
-BLSW_HD Fp2 poly_eval4_w(Emitter& e, const Fp2& k0, const Fp2& k1, const Fp2& k2, const Fp2& k3, const Fp2& x) {
+BLSW_FN Fp2 poly_eval4_w(Emitter& e, const Fp2& k0, const Fp2& k1, const Fp2& k2, const Fp2& k3, const Fp2& x) {
     Fp2 result = fp2_zero(), cp = fp2_one();
     poly_step_w(e, result, cp, k0, x, true);
     poly_step_w(e, result, cp, k1, x, false);
@@ -138,14 +138,14 @@ BLSW_HD Fp2 poly_eval4_w(Emitter& e, const Fp2& k0, const Fp2& k1, const Fp2& k2
     poly_step_w(e, result, cp, k3, x, false);
     return result;
 }
-BLSW_HD Fp2 poly_eval3_w(Emitter& e, const Fp2& k0, const Fp2& k1, const Fp2& k2, const Fp2& x) {
+BLSW_FN Fp2 poly_eval3_w(Emitter& e, const Fp2& k0, const Fp2& k1, const Fp2& k2, const Fp2& x) {
     Fp2 result = fp2_zero(), cp = fp2_one();
     poly_step_w(e, result, cp, k0, x, true);
     poly_step_w(e, result, cp, k1, x, false);
     poly_step_w(e, result, cp, k2, x, false);
     return result;
 }
-BLSW_HD Proj<OpsFp2> chain_map_to_curve(Emitter e, const Fp2& u) {
+BLSW_FN Proj<OpsFp2> chain_map_to_curve(Emitter e, const Fp2& u) {
     const Fp2 Z = K_SSWU_Z(), A = K_SSWU_A(), B = K_SSWU_B(), C2 = K_SSWU_C2(), C3 = K_SSWU_C3(), C4 = K_SSWU_C4(), C5 = K_SSWU_C5();
     Fp2 tv1 = fp2_sqr_w(e, u);                       // 1
     Fp2 tv3 = fp2_mul(Z, tv1);                       // 2
@@ -252,7 +252,7 @@ struct Aff2Inf {
     Fp2 x, y;
     bool infinity;
 };
-BLSW_HD Aff2Inf g2_to_affine_w(Emitter& e, const Proj<OpsFp2>& p) {
+BLSW_FN Aff2Inf g2_to_affine_w(Emitter& e, const Proj<OpsFp2>& p) {
     bool infinity = fp2_is_zero_w(e, p.z);
     Fp2 z_inv = fp2_inv(p.z);
     e.put(z_inv.c0);
@@ -269,13 +269,13 @@ BLSW_HD Aff2Inf g2_to_affine_w(Emitter& e, const Proj<OpsFp2>& p) {
 
 // ------------------------------------------------------------------------------------------------ Q0 + Q1, clear_cofactor2
 // ZSTATE of a projective value: 0 = z is a variable, 2 = z is the constant one
-BLSW_HD Proj<OpsFp2> proj_add_zstate_w(Emitter& e, const Proj<OpsFp2>& a, int za, const Proj<OpsFp2>& b, int zb) {
+BLSW_FN Proj<OpsFp2> proj_add_zstate_w(Emitter& e, const Proj<OpsFp2>& a, int za, const Proj<OpsFp2>& b, int zb) {
     if (za == 2 && zb == 2) return proj_add_w<OpsFp2, 2>(e, a, b);
     if (zb == 2) return proj_add_w<OpsFp2, 1>(e, a, b);
     if (za == 2) return proj_add_w<OpsFp2, 1>(e, b, a);
     return proj_add_w<OpsFp2, 0>(e, a, b);
 }
-BLSW_HD Proj<OpsFp2> chain_cofactor(Emitter e_add, Emitter e, const Proj<OpsFp2>& q0, const Proj<OpsFp2>& q1) {
+BLSW_FN Proj<OpsFp2> chain_cofactor(Emitter e_add, Emitter e, const Proj<OpsFp2>& q0, const Proj<OpsFp2>& q1) {
     constexpr uint32_t HE[20] = BLSW_H_EFF_WORDS;
     Proj<OpsFp2> r = proj_add_w<OpsFp2, 0>(e_add, q0, q1);
     // scalar_mul_le(h_eff bits): to_affine, then 255-bit chunks of affine double-and-add
@@ -335,11 +335,11 @@ BLSW_HD Proj<OpsFp2> chain_cofactor(Emitter e_add, Emitter e, const Proj<OpsFp2>
 // coeffs: 68 pairs (c0, c1) handed to `out.st(4k + j, .)` in the order c0.c0, c0.c1, c1.c0, c1.c1
 struct CoeffLinear {  // plain array (host harness)
     Fp* p;
-    BLSW_HD void st(uint32_t idx, const Fp& v) const { p[idx] = v; }
-    BLSW_HD Fp ld(uint32_t idx) const { return p[idx]; }
+    BLSW_FN void st(uint32_t idx, const Fp& v) const { p[idx] = v; }
+    BLSW_FN Fp ld(uint32_t idx) const { return p[idx]; }
 };
 template <class C>
-BLSW_HD void chain_prepare_g2(Emitter e, const Proj<OpsFp2>& q_, const C& out) {
+BLSW_FN void chain_prepare_g2(Emitter e, const Proj<OpsFp2>& q_, const C& out) {
     Aff2Inf q = g2_to_affine_w(e, q_);
     const Fp two_inv = K_TWO_INV();
     Fp2 rx = q.x, ry = q.y;
@@ -389,7 +389,7 @@ BLSW_HD void chain_prepare_g2(Emitter e, const Proj<OpsFp2>& q_, const C& out) {
 // ------------------------------------------------------------------------------------------------ pairing
 // ell for the pair (-g1 constant, sig): c1 * p.x is a linear combination, d1 = (p.y, 0) constant
 template <class C>
-BLSW_HD Fp12 ell_const_p_w(Emitter& e, const Fp12& f, const C& coeff, uint32_t k, bool f_is_const) {
+BLSW_FN Fp12 ell_const_p_w(Emitter& e, const Fp12& f, const C& coeff, uint32_t k, bool f_is_const) {
     Fp2 c0 = {coeff.ld(4 * k + 0), coeff.ld(4 * k + 1)}, c1 = {coeff.ld(4 * k + 2), coeff.ld(4 * k + 3)};
     const Fp px = K_G1_GEN_X(), py = K_G1_GEN_NEG_Y();
     c1 = fp2_mul_fp(c1, px);
@@ -398,14 +398,14 @@ BLSW_HD Fp12 ell_const_p_w(Emitter& e, const Fp12& f, const C& coeff, uint32_t k
 }
 // ell for the pair (pk variable, H(m)): c1.c0*p.x and c1.c1*p.x are witnesses, d1 = (p.y, 0) with p.y variable
 template <class C>
-BLSW_HD Fp12 ell_var_p_w(Emitter& e, const Fp12& f, const C& coeff, uint32_t k, const Fp& px, const Fp& py) {
+BLSW_FN Fp12 ell_var_p_w(Emitter& e, const Fp12& f, const C& coeff, uint32_t k, const Fp& px, const Fp& py) {
     Fp2 c0 = {coeff.ld(4 * k + 0), coeff.ld(4 * k + 1)}, c1 = {coeff.ld(4 * k + 2), coeff.ld(4 * k + 3)};
     Fp k0 = fp_mul_w(e, c1.c0, px);
     Fp k1 = fp_mul_w(e, c1.c1, px);
     c1 = {k0, k1};
     return fp12_mul_by_014_w<true>(e, f, c0, c1, py);
 }
-BLSW_HD bool fp6_is_eq_w(Emitter& e, const Fp6& self, const Fp6& other) {
+BLSW_FN bool fp6_is_eq_w(Emitter& e, const Fp6& self, const Fp6& other) {
     bool b0 = fp2_is_eq_w(e, self.c0, other.c0);
     bool b1 = fp2_is_eq_w(e, self.c1, other.c1);
     bool b2 = fp2_is_eq_w(e, self.c2, other.c2);
@@ -417,7 +417,7 @@ BLSW_HD bool fp6_is_eq_w(Emitter& e, const Fp6& self, const Fp6& other) {
 }
 // miller_loop([-g1, pk], [sig, H])
 template <class C>
-BLSW_HD Fp12 chain_miller(Emitter e, const Fp& pkx, const Fp& pky, const C& coeff_sig, const C& coeff_h) {
+BLSW_FN Fp12 chain_miller(Emitter e, const Fp& pkx, const Fp& pky, const C& coeff_sig, const C& coeff_h) {
     Fp12 f = fp12_one();
     uint32_t k = 0;
 #pragma unroll 1
@@ -436,7 +436,7 @@ BLSW_HD Fp12 chain_miller(Emitter e, const Fp& pkx, const Fp& pky, const C& coef
     return fp12_conj(f);
 }
 // final_exponentiation . is_one
-BLSW_HD bool chain_final_exp_is_one(Emitter e_fe, Emitter e_one, const Fp12& f) {
+BLSW_FN bool chain_final_exp_is_one(Emitter e_fe, Emitter e_one, const Fp12& f) {
     // final exponentiation
     Emitter& g = e_fe;
     Fp12 f1 = fp12_conj(f);

@@ -19,7 +19,7 @@ struct OpsFp {
     static BLSW_HD F neg(const F& a) { return fp_neg(a); }
     static BLSW_HD F mul_w(Emitter& e, const F& a, const F& b) { return fp_mul_w(e, a, b); }
     static BLSW_HD F sqr_w(Emitter& e, const F& a) { return fp_mul_w(e, a, a); }
-    static BLSW_HD F mul3b(const F& a) {  // * 12
+    static BLSW_FN F mul3b(const F& a) {  // * 12
         F a4 = fp_dbl(fp_dbl(a));
         return fp_add(fp_dbl(a4), a4);
     }
@@ -35,7 +35,7 @@ struct OpsFp2 {
     static BLSW_HD F neg(const F& a) { return fp2_neg(a); }
     static BLSW_HD F mul_w(Emitter& e, const F& a, const F& b) { return fp2_mul_w(e, a, b); }
     static BLSW_HD F sqr_w(Emitter& e, const F& a) { return fp2_sqr_w(e, a); }
-    static BLSW_HD F mul3b(const F& a) {  // * 12(1+u)
+    static BLSW_FN F mul3b(const F& a) {  // * 12(1+u)
         F x = fp2_mul_xi(a);
         F a4 = fp2_dbl(fp2_dbl(x));
         return fp2_add(fp2_dbl(a4), a4);
@@ -52,7 +52,7 @@ struct Proj {
 
 // ProjectiveVar::double_in_place on variables: 3 squarings + 8 products, in this order
 template <class O>
-BLSW_HD Proj<O> proj_double_w(Emitter& e, const Proj<O>& p) {
+BLSW_FN Proj<O> proj_double_w(Emitter& e, const Proj<O>& p) {
     typedef typename O::F F;
     F xx = O::sqr_w(e, p.x);
     F yy = O::sqr_w(e, p.y);
@@ -78,7 +78,7 @@ BLSW_HD Proj<O> proj_double_w(Emitter& e, const Proj<O>& p) {
 // 1 = z2 is the constant one (zz = z1 is a linear combination: 11 products);
 // 2 = both z are the constant one (zz constant: 11 products).
 template <class O, int ZMODE>
-BLSW_HD Proj<O> proj_add_w(Emitter& e, const Proj<O>& a, const Proj<O>& b) {
+BLSW_FN Proj<O> proj_add_w(Emitter& e, const Proj<O>& a, const Proj<O>& b) {
     typedef typename O::F F;
     F xx = O::mul_w(e, a.x, b.x);
     F yy = O::mul_w(e, a.y, b.y);
@@ -114,7 +114,7 @@ BLSW_HD Proj<O> proj_add_w(Emitter& e, const Proj<O>& a, const Proj<O>& b) {
 // result = [k] ge with `result = zero; for b in BE bits: double; if b: += ge` (the first set bit costs nothing:
 // zero is a constant, so the first add returns ge itself)
 template <class O>
-BLSW_HD Proj<O> proj_mul_bits_be_w(Emitter& e, const Proj<O>& ge, const uint32_t* words, int nbits) {
+BLSW_FN Proj<O> proj_mul_bits_be_w(Emitter& e, const Proj<O>& ge, const uint32_t* words, int nbits) {
     Proj<O> result = ge;
 #pragma unroll 1
     for (int i = nbits - 2; i >= 0; i--) {
@@ -128,7 +128,7 @@ BLSW_HD Proj<O> proj_mul_bits_be_w(Emitter& e, const Proj<O>& ge, const uint32_t
 struct Aff2 {
     Fp2 x, y;
 };
-BLSW_HD Aff2 nz_double_w(Emitter& e, const Aff2& p) {
+BLSW_FN Aff2 nz_double_w(Emitter& e, const Aff2& p) {
     Fp2 x1_sqr = fp2_sqr_w(e, p.x);
     Fp2 num = fp2_add(fp2_dbl(x1_sqr), x1_sqr);
     Fp2 den = fp2_dbl(p.y);
@@ -139,7 +139,7 @@ BLSW_HD Aff2 nz_double_w(Emitter& e, const Aff2& p) {
     Fp2 y3 = fp2_sub(t, p.y);
     return {x3, y3};
 }
-BLSW_HD Aff2 nz_add_unchecked_w(Emitter& e, const Aff2& p, const Aff2& q) {
+BLSW_FN Aff2 nz_add_unchecked_w(Emitter& e, const Aff2& p, const Aff2& q) {
     Fp2 num = fp2_sub(q.y, p.y);
     Fp2 den = fp2_sub(q.x, p.x);
     Fp2 lambda = fp2_div_w(e, num, den);
@@ -154,7 +154,7 @@ BLSW_HD Aff2 nz_add_unchecked_w(Emitter& e, const Aff2& p, const Aff2& q) {
 struct Jac1 {
     Fp x, y, z;
 };
-BLSW_HD Jac1 jac1_dbl(const Jac1& p) {
+BLSW_FN Jac1 jac1_dbl(const Jac1& p) {
     Fp A = fp_sqr(p.x), B = fp_sqr(p.y), C = fp_sqr(B);
     Fp t = fp_add(p.x, B);
     Fp D = fp_dbl(fp_sub(fp_sub(fp_sqr(t), A), C));
@@ -167,7 +167,7 @@ BLSW_HD Jac1 jac1_dbl(const Jac1& p) {
     return {x3, y3, z3};
 }
 // mixed addition p + (qx, qy); p must not be the identity and must differ from +-q (true for 1 < k < r)
-BLSW_HD Jac1 jac1_add_mixed(const Jac1& p, const Fp& qx, const Fp& qy) {
+BLSW_FN Jac1 jac1_add_mixed(const Jac1& p, const Fp& qx, const Fp& qy) {
     Fp z1z1 = fp_sqr(p.z);
     Fp u2 = fp_mul(qx, z1z1);
     Fp s2 = fp_mul(fp_mul(qy, p.z), z1z1);

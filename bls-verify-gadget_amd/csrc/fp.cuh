@@ -10,9 +10,11 @@
 #include <hip/hip_runtime.h>
 #define BLSW_HD __host__ __device__ __forceinline__
 #define BLSW_HD_NOINLINE __host__ __device__ __noinline__
+#define BLSW_FN __host__ __device__ __noinline__
 #else
 #define BLSW_HD inline
 #define BLSW_HD_NOINLINE
+#define BLSW_FN inline
 #endif
 
 namespace blsw {
@@ -204,25 +206,25 @@ BLSW_HD_NOINLINE Fp fp_inv(const Fp& a) {
 BLSW_HD Fp2 fp2_zero() { return {fp_zero(), fp_zero()}; }
 BLSW_HD Fp2 fp2_one() { return {fp_one(), fp_zero()}; }
 BLSW_HD bool fp2_is_zero(const Fp2& a) { return fp_is_zero(a.c0) && fp_is_zero(a.c1); }
-BLSW_HD Fp2 fp2_add(const Fp2& a, const Fp2& b) { return {fp_add(a.c0, b.c0), fp_add(a.c1, b.c1)}; }
-BLSW_HD Fp2 fp2_sub(const Fp2& a, const Fp2& b) { return {fp_sub(a.c0, b.c0), fp_sub(a.c1, b.c1)}; }
-BLSW_HD Fp2 fp2_neg(const Fp2& a) { return {fp_neg(a.c0), fp_neg(a.c1)}; }
-BLSW_HD Fp2 fp2_dbl(const Fp2& a) { return {fp_dbl(a.c0), fp_dbl(a.c1)}; }
+BLSW_FN Fp2 fp2_add(const Fp2& a, const Fp2& b) { return {fp_add(a.c0, b.c0), fp_add(a.c1, b.c1)}; }
+BLSW_FN Fp2 fp2_sub(const Fp2& a, const Fp2& b) { return {fp_sub(a.c0, b.c0), fp_sub(a.c1, b.c1)}; }
+BLSW_FN Fp2 fp2_neg(const Fp2& a) { return {fp_neg(a.c0), fp_neg(a.c1)}; }
+BLSW_FN Fp2 fp2_dbl(const Fp2& a) { return {fp_dbl(a.c0), fp_dbl(a.c1)}; }
 BLSW_HD Fp2 fp2_conj(const Fp2& a) { return {a.c0, fp_neg(a.c1)}; }
-BLSW_HD Fp2 fp2_mul_xi(const Fp2& a) { return {fp_sub(a.c0, a.c1), fp_add(a.c0, a.c1)}; }  // * (1+u)
+BLSW_FN Fp2 fp2_mul_xi(const Fp2& a) { return {fp_sub(a.c0, a.c1), fp_add(a.c0, a.c1)}; }  // * (1+u)
 // value-only products (used where the circuit has a constant operand: linear combination, no witness)
-BLSW_HD Fp2 fp2_mul(const Fp2& a, const Fp2& b) {
+BLSW_FN Fp2 fp2_mul(const Fp2& a, const Fp2& b) {
     Fp v0 = fp_mul(a.c0, b.c0), v1 = fp_mul(a.c1, b.c1);
     Fp s = fp_mul(fp_add(a.c0, a.c1), fp_add(b.c0, b.c1));
     return {fp_sub(v0, v1), fp_sub(fp_sub(s, v0), v1)};
 }
-BLSW_HD Fp2 fp2_sqr(const Fp2& a) {
+BLSW_FN Fp2 fp2_sqr(const Fp2& a) {
     Fp v = fp_mul(a.c0, a.c1);
     Fp t = fp_mul(fp_sub(a.c0, a.c1), fp_add(a.c0, a.c1));
     return {t, fp_dbl(v)};
 }
-BLSW_HD Fp2 fp2_mul_fp(const Fp2& a, const Fp& b) { return {fp_mul(a.c0, b), fp_mul(a.c1, b)}; }
-BLSW_HD Fp2 fp2_inv(const Fp2& a) {
+BLSW_FN Fp2 fp2_mul_fp(const Fp2& a, const Fp& b) { return {fp_mul(a.c0, b), fp_mul(a.c1, b)}; }
+BLSW_FN Fp2 fp2_inv(const Fp2& a) {
     Fp n = fp_add(fp_sqr(a.c0), fp_sqr(a.c1));
     Fp ni = fp_inv(n);
     return {fp_mul(a.c0, ni), fp_neg(fp_mul(a.c1, ni))};

@@ -38,14 +38,14 @@ struct Emitter {
 };
 
 // ---- FpVar
-BLSW_HD Fp fp_mul_w(Emitter& e, const Fp& a, const Fp& b) {
+BLSW_FN Fp fp_mul_w(Emitter& e, const Fp& a, const Fp& b) {
     Fp r = fp_mul(a, b);
     e.put(r);
     return r;
 }
 // AllocatedFp::is_neq(self, other): witnesses = [is_not_equal (boolean), multiplier]; returns is_eq.
 // Orientation matters: (Var v).is_eq(Constant c) is evaluated as c.is_eq(v), i.e. diff = c - v.
-BLSW_HD bool fp_is_eq_w(Emitter& e, const Fp& self, const Fp& other) {
+BLSW_FN bool fp_is_eq_w(Emitter& e, const Fp& self, const Fp& other) {
     Fp diff = fp_sub(self, other);
     bool ne = !fp_is_zero(diff);
     e.put_bool(ne);
@@ -53,7 +53,7 @@ BLSW_HD bool fp_is_eq_w(Emitter& e, const Fp& self, const Fp& other) {
     e.put(ne ? m : fp_one());
     return !ne;
 }
-BLSW_HD Fp fp_select_w(Emitter& e, bool cond, const Fp& t, const Fp& f) {
+BLSW_FN Fp fp_select_w(Emitter& e, bool cond, const Fp& t, const Fp& f) {
     Fp r;
 #pragma unroll
     for (int i = 0; i < 12; i++) r.l[i] = cond ? t.l[i] : f.l[i];
@@ -62,19 +62,19 @@ BLSW_HD Fp fp_select_w(Emitter& e, bool cond, const Fp& t, const Fp& f) {
 }
 
 // ---- Fp2Var (QuadExtVar over FpVar)
-BLSW_HD Fp2 fp2_mul_w(Emitter& e, const Fp2& a, const Fp2& b) {
+BLSW_FN Fp2 fp2_mul_w(Emitter& e, const Fp2& a, const Fp2& b) {
     Fp v0 = fp_mul_w(e, a.c0, b.c0);
     Fp v1 = fp_mul_w(e, a.c1, b.c1);
     Fp s = fp_mul_w(e, fp_add(a.c0, a.c1), fp_add(b.c0, b.c1));
     return {fp_sub(v0, v1), fp_sub(fp_sub(s, v0), v1)};
 }
-BLSW_HD Fp2 fp2_sqr_w(Emitter& e, const Fp2& a) {
+BLSW_FN Fp2 fp2_sqr_w(Emitter& e, const Fp2& a) {
     Fp v2 = fp_mul_w(e, a.c0, a.c1);
     Fp t = fp_mul_w(e, fp_sub(a.c0, a.c1), fp_add(a.c0, a.c1));
     return {t, fp_dbl(v2)};
 }
 // QuadExtVar::inverse: witnesses inv.c0, inv.c1, then mul_equals' v1 = a.c1 * inv.c1
-BLSW_HD Fp2 fp2_inv_w(Emitter& e, const Fp2& a) {
+BLSW_FN Fp2 fp2_inv_w(Emitter& e, const Fp2& a) {
     Fp2 inv = fp2_inv(a);
     e.put(inv.c0);
     e.put(inv.c1);
@@ -82,14 +82,14 @@ BLSW_HD Fp2 fp2_inv_w(Emitter& e, const Fp2& a) {
     return inv;
 }
 // FieldVar::mul_by_inverse_unchecked: witnesses r = num/den (c0, c1), then v1 = r.c1 * den.c1
-BLSW_HD Fp2 fp2_div_w(Emitter& e, const Fp2& num, const Fp2& den) {
+BLSW_FN Fp2 fp2_div_w(Emitter& e, const Fp2& num, const Fp2& den) {
     Fp2 r = fp2_mul(num, fp2_inv(den));
     e.put(r.c0);
     e.put(r.c1);
     fp_mul_w(e, r.c1, den.c1);
     return r;
 }
-BLSW_HD bool fp2_is_eq_w(Emitter& e, const Fp2& self, const Fp2& other) {
+BLSW_FN bool fp2_is_eq_w(Emitter& e, const Fp2& self, const Fp2& other) {
     bool b0 = fp_is_eq_w(e, self.c0, other.c0);
     bool b1 = fp_is_eq_w(e, self.c1, other.c1);
     bool r = b0 && b1;  // Not(ne0) AND Not(ne1) -> nor witness
@@ -97,8 +97,8 @@ BLSW_HD bool fp2_is_eq_w(Emitter& e, const Fp2& self, const Fp2& other) {
     return r;
 }
 // v.is_eq(Constant zero) / v.is_zero(): evaluated as zero.is_eq(v)
-BLSW_HD bool fp2_is_zero_w(Emitter& e, const Fp2& v) { return fp2_is_eq_w(e, fp2_zero(), v); }
-BLSW_HD Fp2 fp2_select_w(Emitter& e, bool cond, const Fp2& t, const Fp2& f) {
+BLSW_FN bool fp2_is_zero_w(Emitter& e, const Fp2& v) { return fp2_is_eq_w(e, fp2_zero(), v); }
+BLSW_FN Fp2 fp2_select_w(Emitter& e, bool cond, const Fp2& t, const Fp2& f) {
     Fp c0 = fp_select_w(e, cond, t.c0, f.c0);
     Fp c1 = fp_select_w(e, cond, t.c1, f.c1);
     return {c0, c1};
@@ -106,7 +106,7 @@ BLSW_HD Fp2 fp2_select_w(Emitter& e, bool cond, const Fp2& t, const Fp2& f) {
 
 // ---- FpVar::to_bits_le on a variable: 381 boolean witnesses (LSB first) followed by
 // Boolean::enforce_in_field_le's AND chain against p-1. Returns bit 0.
-BLSW_HD bool fp_to_bits_le_w(Emitter& e, const Fp& a) {
+BLSW_FN bool fp_to_bits_le_w(Emitter& e, const Fp& a) {
     constexpr uint32_t P[12] = BLSW_P_LIMBS;
     Fp c = fp_to_canonical(a);
 #pragma unroll 1

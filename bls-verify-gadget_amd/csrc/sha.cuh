@@ -21,7 +21,7 @@ BLSW_HD W32 w_rotr(const W32& a, int n) { return {rotr32(a.v, n), rotr32(a.cm, n
 BLSW_HD W32 w_shr(const W32& a, int n) { return {a.v >> n, (a.cm >> n) | ~(0xffffffffu >> n), a.nm >> n}; }
 BLSW_HD W32 w_not(const W32& a) { return {~a.v, a.cm, ~a.nm & ~a.cm}; }
 
-BLSW_HD uint32_t pext32(uint32_t v, uint32_t m) {
+BLSW_FN uint32_t pext32(uint32_t v, uint32_t m) {
     if (m == 0xffffffffu) return v;
     if ((m & (m + 1)) == 0) return v & m;  // contiguous low mask
     uint32_t r = 0, k = 0;
@@ -78,7 +78,7 @@ struct BitSink {
     }
 };
 
-BLSW_HD W32 w_xor(BitSink& s, const W32& a, const W32& b) {
+BLSW_FN W32 w_xor(BitSink& s, const W32& a, const W32& b) {
     uint32_t wm = ~a.cm & ~b.cm;
     if (wm) s.push(pext32((a.v ^ a.nm) ^ (b.v ^ b.nm), wm), popc32(wm));
     W32 r;
@@ -87,7 +87,7 @@ BLSW_HD W32 w_xor(BitSink& s, const W32& a, const W32& b) {
     r.nm = (a.nm ^ b.nm ^ (a.cm & a.v) ^ (b.cm & b.v)) & ~r.cm;
     return r;
 }
-BLSW_HD W32 w_and(BitSink& s, const W32& a, const W32& b) {
+BLSW_FN W32 w_and(BitSink& s, const W32& a, const W32& b) {
     uint32_t wm = ~a.cm & ~b.cm;
     if (wm) s.push(pext32(a.v & b.v, wm), popc32(wm));
     W32 r;
@@ -98,7 +98,7 @@ BLSW_HD W32 w_and(BitSink& s, const W32& a, const W32& b) {
     return r;
 }
 // UInt32::addmany over k operands
-BLSW_HD W32 w_addmany(BitSink& s, const W32* ops, int k) {
+BLSW_FN W32 w_addmany(BitSink& s, const W32* ops, int k) {
     uint64_t sum = 0;
     uint32_t allc = 0xffffffffu;
     for (int i = 0; i < k; i++) {
@@ -127,7 +127,7 @@ BLSW_HD W32 w_addmany(BitSink& s, const W32* ops, int k) {
     }
 
 // Sha256Gadget::update_state
-BLSW_HD void sha_block_w(BitSink& s, W32 st[8], const W32 data[16]) {
+BLSW_FN void sha_block_w(BitSink& s, W32 st[8], const W32 data[16]) {
     constexpr uint32_t K[64] = BLSW_SHA_K;
     W32 w[64];
     for (int i = 0; i < 16; i++) w[i] = data[i];
@@ -181,7 +181,7 @@ BLSW_HD void sha_block_w(BitSink& s, W32 st[8], const W32 data[16]) {
 #define BLSW_DST_LEN 43
 
 // byte k of msg_prime = Z_pad(64) | msg | I2OSP(256,2) (witness) | 0 | DST | len(DST), followed by SHA padding
-BLSW_HD void b0_byte(const uint8_t* msg, uint32_t msg_len, bool msg_const, uint32_t k, uint32_t total, uint32_t& val, bool& konst) {
+BLSW_FN void b0_byte(const uint8_t* msg, uint32_t msg_len, bool msg_const, uint32_t k, uint32_t total, uint32_t& val, bool& konst) {
     const char dst[] = BLSW_DST;
     konst = true;
     val = 0;
@@ -224,7 +224,7 @@ BLSW_HD void b0_byte(const uint8_t* msg, uint32_t msg_len, bool msg_const, uint3
 // Runs the whole expand_message_xmd (len_in_bytes = 256) gadget for one message.
 // Emits the 16 lib_str booleans first (they are allocated before the first digest), then every SHA witness.
 // out_words: the 8 digests b1..b8 as 64 big-endian words (uniform_bytes).
-BLSW_HD void expand_message_w(BitSink& s, const uint8_t* msg, uint32_t msg_len, bool msg_const, uint32_t uniform_words[64]) {
+BLSW_FN void expand_message_w(BitSink& s, const uint8_t* msg, uint32_t msg_len, bool msg_const, uint32_t uniform_words[64]) {
     constexpr uint32_t H0[8] = BLSW_SHA_H0;
     const char dst[] = BLSW_DST;
     // lib_str_var: two witness bytes, little-endian bit order each: 0x01, 0x00
@@ -303,7 +303,7 @@ BLSW_HD void expand_message_w(BitSink& s, const uint8_t* msg, uint32_t msg_len, 
 
 // hash_to_field (hasher.rs:58-107): element j (0..3) = OS2IP(uniform_bytes[64j .. 64j+64)) mod p as
 // head(47 high bytes) * 256^17 + tail(17 low bytes); linear combinations only (no witnesses).
-BLSW_HD Fp hash_to_field_elem(const uint32_t* W /*16 big-endian words*/) {
+BLSW_FN Fp hash_to_field_elem(const uint32_t* W /*16 big-endian words*/) {
     constexpr uint32_t R2[12] = BLSW_R2_LIMBS;
     uint32_t L[16];
     for (int i = 0; i < 16; i++) L[i] = W[15 - i];

@@ -1,0 +1,45 @@
+"""ctypes loader for tests/hostsim/libhostsim.so: the device headers compiled for the host (TEST HARNESS ONLY)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+u64p = ctypes.POINTER(ctypes.c_uint64)
+
+_FIELDS = (
+    "msg_len n_instance_vars n_witness sha_bits off_msg off_pk_alloc off_sig_alloc off_pk_not_zero off_expand off_map0 off_map1 "
+    "off_add off_cofactor off_prep_h off_prep_pk off_prep_sig off_miller off_final_exp off_is_one"
+).split()
+
+
+class Lay(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint32) for n in _FIELDS]
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "hostsim")])
+        _lib = ctypes.CDLL(os.path.join(HERE, "hostsim", "libhostsim.so"))
+    return _lib
+
+
+def layout(msg_len):
+    L = Lay()
+    load().hostsim_layout(msg_len, ctypes.byref(L))
+    return {n: getattr(L, n) for n in _FIELDS}
+
+
+def witness(pk_xy, msg, sig_xy):
+    pk_xy = np.ascontiguousarray(pk_xy, dtype=np.uint64)
+    sig_xy = np.ascontiguousarray(sig_xy, dtype=np.uint64)
+    lay = layout(len(msg))
+    out = np.zeros((lay["n_witness"], 6), dtype=np.uint64)
+    buf = (ctypes.c_uint8 * max(1, len(msg))).from_buffer_copy(bytes(msg) if len(msg) else b"\0")
+    r = load().hostsim_witness(pk_xy.ctypes.data_as(u64p), buf, len(msg), sig_xy.ctypes.data_as(u64p), out.ctypes.data_as(u64p), None)
+    return r, out
