@@ -52,14 +52,19 @@ def lib():
         L = ctypes.CDLL(LIB_PATH)
         L.blsw_layout.argtypes = [ctypes.c_uint32, ctypes.POINTER(blsw_layout_t)]
         L.blsw_workspace_bytes.argtypes = [ctypes.c_uint64, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64)]
-        L.blsw_witness_batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64,
+        L.blsw_ctx_create.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+        L.blsw_ctx_destroy.argtypes = [ctypes.c_void_p]
+        L.blsw_ctx_last_expand_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
+        L.blsw_microbench.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_double)]
+        L.blsw_witness_batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64,
                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
         L.blsw_hash_to_g2_batch.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
         _lib = L
     return _lib
 
 
-EXPORTED_SYMBOLS = ["blsw_version", "blsw_layout", "blsw_workspace_bytes", "blsw_witness_batch", "blsw_hash_to_g2_batch"]
+EXPORTED_SYMBOLS = ["blsw_version", "blsw_layout", "blsw_workspace_bytes", "blsw_ctx_create", "blsw_ctx_destroy", "blsw_ctx_last_expand_ms",
+                    "blsw_witness_batch", "blsw_hash_to_g2_batch", "blsw_microbench"]
 
 
 def layout(msg_len=32):
@@ -130,6 +135,26 @@ class BlsSignatureVerifyGadget:
         self.workspace = torch.empty(workspace_bytes(self.n, msg_len), dtype=torch.uint8, device=self.device)
         self.result = torch.empty(self.n, dtype=torch.int32, device=self.device)
         self.witness = torch.empty((self.n, self.n_witness, 6), dtype=torch.int64, device=self.device) if want_witness else None
+        self._ctx = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            rc = lib().blsw_ctx_create(ctypes.byref(self._ctx))
+        if rc:
+            raise BlswError("blsw_ctx_create failed: %d" % rc)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_ctx", None):
+                lib().blsw_ctx_destroy(self._ctx)
+                self._ctx = None
+        except Exception:
+            pass
+
+    def last_expand_ms(self):
+        ms = ctypes.c_float(0)
+        rc = lib().blsw_ctx_last_expand_ms(self._ctx, ctypes.byref(ms))
+        if rc:
+            raise BlswError("blsw_ctx_last_expand_ms failed: %d" % rc)
+        return ms.value
 
     def verify(self, parameters, public_key, message, signature, witness=None, stream=None):
         """message: [n, msg_len] uint8 tensor. Returns the int32 result tensor (gadget Boolean per instance); the witness
@@ -142,11 +167,21 @@ class BlsSignatureVerifyGadget:
         assert pk.is_contiguous() and sig.is_contiguous() and message.is_contiguous()
         w = witness if witness is not None else self.witness
         s = stream if stream is not None else torch.cuda.current_stream(self.device)
-        rc = lib().blsw_witness_batch(pk.data_ptr(), sig.data_ptr(), message.data_ptr(), self.msg_len, self.n, w.data_ptr() if w is not None else None,
+        rc = lib().blsw_witness_batch(self._ctx, pk.data_ptr(), sig.data_ptr(), message.data_ptr(), self.msg_len, self.n, w.data_ptr() if w is not None else None,
                                       self.n_witness, self.result.data_ptr(), self.workspace.data_ptr(), self.workspace.numel(), s.cuda_stream)
         if rc:
             raise BlswError("blsw_witness_batch failed: %d" % rc)
         return self.result
+
+
+def microbench(which, iters=4096, blocks=4096):
+    """Measured device rates for the VALU roofline: which=0 v_mad_u64_u32/s, which=1 Fp products/s."""
+    _require_cuda()
+    v = ctypes.c_double(0)
+    rc = lib().blsw_microbench(which, iters, blocks, ctypes.byref(v))
+    if rc:
+        raise BlswError("blsw_microbench failed: %d" % rc)
+    return v.value
 
 
 def hash_to_g2_batch(message, out=None):

@@ -77,17 +77,39 @@ BLSW_HD bool fp_eq(const Fp& a, const Fp& b) {
     for (int i = 0; i < 12; i++) o |= a.l[i] ^ b.l[i];
     return o == 0;
 }
+// add / subtract with carry. clang lowers __builtin_addc/__builtin_subc to v_add_co_u32 / v_addc_co_u32 chains.
+#if defined(__clang__)
+BLSW_HD uint32_t addc32(uint32_t a, uint32_t b, uint32_t& carry) {
+    unsigned co;
+    uint32_t r = __builtin_addc(a, b, carry, &co);
+    carry = co;
+    return r;
+}
+BLSW_HD uint32_t subb32(uint32_t a, uint32_t b, uint32_t& borrow) {
+    unsigned bo;
+    uint32_t r = __builtin_subc(a, b, borrow, &bo);
+    borrow = bo;
+    return r;
+}
+#else
+BLSW_HD uint32_t addc32(uint32_t a, uint32_t b, uint32_t& carry) {
+    uint64_t x = (uint64_t)a + b + carry;
+    carry = (uint32_t)(x >> 32);
+    return (uint32_t)x;
+}
+BLSW_HD uint32_t subb32(uint32_t a, uint32_t b, uint32_t& borrow) {
+    uint64_t x = (uint64_t)a - b - borrow;
+    borrow = (uint32_t)(x >> 32) & 1u;
+    return (uint32_t)x;
+}
+#endif
 // r = a - p if a >= p else a   (a < 2p, given with its 13th carry word)
 BLSW_HD Fp fp_cond_sub_p(const Fp& a, uint32_t top) {
     constexpr uint32_t P[12] = BLSW_P_LIMBS;
     Fp d;
-    uint64_t borrow = 0;
+    uint32_t borrow = 0;
 #pragma unroll
-    for (int i = 0; i < 12; i++) {
-        uint64_t x = (uint64_t)a.l[i] - P[i] - borrow;
-        d.l[i] = (uint32_t)x;
-        borrow = (x >> 32) & 1;
-    }
+    for (int i = 0; i < 12; i++) d.l[i] = subb32(a.l[i], P[i], borrow);
     bool ge = (top != 0) || (borrow == 0);
     Fp r;
 #pragma unroll
@@ -96,67 +118,54 @@ BLSW_HD Fp fp_cond_sub_p(const Fp& a, uint32_t top) {
 }
 BLSW_HD Fp fp_add(const Fp& a, const Fp& b) {
     Fp s;
-    uint64_t c = 0;
+    uint32_t c = 0;
 #pragma unroll
-    for (int i = 0; i < 12; i++) {
-        uint64_t x = (uint64_t)a.l[i] + b.l[i] + c;
-        s.l[i] = (uint32_t)x;
-        c = x >> 32;
-    }
-    return fp_cond_sub_p(s, (uint32_t)c);
+    for (int i = 0; i < 12; i++) s.l[i] = addc32(a.l[i], b.l[i], c);
+    return fp_cond_sub_p(s, c);
 }
 BLSW_HD Fp fp_sub(const Fp& a, const Fp& b) {
     constexpr uint32_t P[12] = BLSW_P_LIMBS;
     Fp d;
-    uint64_t borrow = 0;
+    uint32_t borrow = 0;
 #pragma unroll
-    for (int i = 0; i < 12; i++) {
-        uint64_t x = (uint64_t)a.l[i] - b.l[i] - borrow;
-        d.l[i] = (uint32_t)x;
-        borrow = (x >> 32) & 1;
-    }
-    uint32_t mask = borrow ? 0xffffffffu : 0u;
-    uint64_t c = 0;
+    for (int i = 0; i < 12; i++) d.l[i] = subb32(a.l[i], b.l[i], borrow);
+    uint32_t mask = 0u - borrow;
+    uint32_t c = 0;
     Fp r;
 #pragma unroll
-    for (int i = 0; i < 12; i++) {
-        uint64_t x = (uint64_t)d.l[i] + (P[i] & mask) + c;
-        r.l[i] = (uint32_t)x;
-        c = x >> 32;
-    }
+    for (int i = 0; i < 12; i++) r.l[i] = addc32(d.l[i], P[i] & mask, c);
     return r;
 }
 BLSW_HD Fp fp_neg(const Fp& a) { return fp_sub(fp_zero(), a); }
 BLSW_HD Fp fp_dbl(const Fp& a) { return fp_add(a, a); }
 
-// Montgomery product a*b*R^-1 mod p, CIOS over 32-bit limbs: 144 + 144 + 12 v_mad_u64_u32-class
-// multiply-adds (the "300 MAD per Fp-mul" of SURVEY §8d). Kept out of line: one body per code object.
-BLSW_HD_NOINLINE Fp fp_mul(const Fp& a, const Fp& b) {
+// Montgomery product a*b*R^-1 mod p, CIOS over 32-bit limbs: 144 + 144 v_mad_u64_u32 + 12 v_mul_lo_u32
+// (the "300 MAD per Fp-mul" of SURVEY §8d). Per row the 12 products are independent (no carry in the mad
+// chain); the high halves are folded in by one add-with-carry pass. Kept out of line: one body per code object.
+BLSW_HD_NOINLINE Fp fp_mul(const Fp a, const Fp b) {
     constexpr uint32_t P[12] = BLSW_P_LIMBS;
-    uint32_t t[12];
+    uint32_t t[13];
 #pragma unroll
-    for (int i = 0; i < 12; i++) t[i] = 0;
+    for (int i = 0; i < 13; i++) t[i] = 0;
 #pragma unroll
     for (int i = 0; i < 12; i++) {
-        uint64_t c = 0;
-        uint32_t bi = b.l[i];
+        const uint32_t bi = b.l[i];
+        uint64_t x[12];
 #pragma unroll
-        for (int j = 0; j < 12; j++) {
-            uint64_t x = (uint64_t)a.l[j] * bi + t[j] + c;
-            t[j] = (uint32_t)x;
-            c = x >> 32;
-        }
-        uint32_t t12 = (uint32_t)c;
-        uint32_t m = t[0] * BLSW_INV32;
-        uint64_t x = (uint64_t)m * P[0] + t[0];
-        c = x >> 32;
+        for (int j = 0; j < 12; j++) x[j] = (uint64_t)a.l[j] * bi + t[j];
+        uint32_t c = 0;
+        t[0] = (uint32_t)x[0];
 #pragma unroll
-        for (int j = 1; j < 12; j++) {
-            x = (uint64_t)m * P[j] + t[j] + c;
-            t[j - 1] = (uint32_t)x;
-            c = x >> 32;
-        }
-        t[11] = t12 + (uint32_t)c;  // t < 2p < 2^383: no carry out
+        for (int j = 1; j < 12; j++) t[j] = addc32((uint32_t)x[j], (uint32_t)(x[j - 1] >> 32), c);
+        t[12] = addc32(t[12], (uint32_t)(x[11] >> 32), c);
+        const uint32_t m = t[0] * BLSW_INV32;
+#pragma unroll
+        for (int j = 0; j < 12; j++) x[j] = (uint64_t)m * P[j] + t[j];
+        c = 0;
+#pragma unroll
+        for (int j = 1; j < 12; j++) t[j - 1] = addc32((uint32_t)x[j], (uint32_t)(x[j - 1] >> 32), c);
+        t[11] = addc32(t[12], (uint32_t)(x[11] >> 32), c);
+        t[12] = c;  // 0: t < 2p < 2^383
     }
     Fp r;
 #pragma unroll
@@ -188,8 +197,9 @@ BLSW_HD Fp fp_to_canonical(const Fp& a) {
 }
 
 // Inversion, returns 0 for 0 (arkworks `inverse().unwrap_or(zero)` hint semantics).
-// Round-1 implementation: Fermat a^(p-2) with a fixed (uniform) exponent: 380 squarings + 226 products.
-BLSW_HD_NOINLINE Fp fp_inv(const Fp& a) {
+// Fermat a^(p-2) with a fixed (uniform) exponent: 380 squarings + 226 products. Kept as the independent
+// cross-check of fp_inv (tests) — not used on the hot path.
+BLSW_HD_NOINLINE Fp fp_inv_fermat(const Fp& a) {
     constexpr uint32_t P[12] = BLSW_P_LIMBS;
     Fp r = a;  // top bit (bit 380) of p-2 is set
 #pragma unroll 1
@@ -198,6 +208,151 @@ BLSW_HD_NOINLINE Fp fp_inv(const Fp& a) {
         uint32_t w = P[i >> 5];
         if (i < 32) w -= 2;  // p - 2: only the lowest limb changes (0xffffaaab - 2, no borrow)
         if ((w >> (i & 31)) & 1) r = fp_mul(r, a);
+    }
+    return r;
+}
+
+// ---- Bernstein-Yang "safegcd" inversion (half-delta divsteps), 13 signed 30-bit limbs, batches of 30 divsteps.
+// Per batch: 30 cheap steps on the low words build a 2x2 transition matrix, which is then applied to the full
+// (f, g) and, modulo p, to (d, e): 10 x 13 v_mad_i64_i32 instead of 30 full-width shift/add passes.
+// e starts at R^2 mod p, so for a Montgomery input aR the output is a^-1 R directly. All lanes run the same
+// instruction stream; the loop ends when every lane's g is 0 (<= 30 batches for 381-bit inputs).
+#define BLSW_P30                                                                                                                              \
+    {                                                                                                                                         \
+        0x3fffaaab, 0x27fbffff, 0x153ffffb, 0x2affffac, 0x30f6241e, 0x034a83da, 0x112bf673, 0x12e13ce1, 0x2cd76477, 0x1ed90d2e, 0x29a4b1ba, \
+            0x3a8e5ff9, 0x001a0111                                                                                                            \
+    }
+#define BLSW_R2_30                                                                                                                            \
+    {                                                                                                                                         \
+        0x1c341746, 0x137c7cd0, 0x1d104f1f, 0x1db9a982, 0x15b6d50a, 0x151db132, 0x183c08de, 0x222a64e7, 0x152d67eb, 0x3a16d466, 0x3aa9a793, \
+            0x3964b2b8, 0x0011988f                                                                                                            \
+    }
+#define BLSW_PINV30 0x30003u
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BLSW_WAVE_ANY(x) (__any((x)) != 0)
+#else
+#define BLSW_WAVE_ANY(x) (x)
+#endif
+BLSW_HD_NOINLINE Fp fp_inv(const Fp& a) {
+    constexpr int32_t P30[13] = BLSW_P30;
+    constexpr int32_t R2_30[13] = BLSW_R2_30;
+    const int32_t M30 = 0x3fffffff;
+    int32_t f[13], g[13], d[13], e[13];
+    // g = a as 13 x 30-bit limbs
+#pragma unroll
+    for (int k = 0; k < 13; k++) {
+        const int bp = 30 * k, w = bp >> 5, sh = bp & 31;
+        uint32_t v = (w < 12) ? (a.l[w] >> sh) : 0u;
+        if (sh > 2 && w + 1 < 12) v |= a.l[w + 1] << (32 - sh);
+        g[k] = (int32_t)(v & (uint32_t)M30);
+        f[k] = P30[k];
+        d[k] = 0;
+        e[k] = R2_30[k];
+    }
+    int32_t zeta = -1;
+#pragma unroll 1
+    for (int it = 0; it < 37; it++) {
+        uint32_t gnz = 0;
+#pragma unroll
+        for (int k = 0; k < 13; k++) gnz |= (uint32_t)g[k];
+        if (!BLSW_WAVE_ANY(gnz != 0)) break;
+        // ---- 30 divsteps on the low words
+        uint32_t u = 1, v = 0, q = 0, r = 1;
+        uint32_t f0 = (uint32_t)f[0] | ((uint32_t)f[1] << 30), g0 = (uint32_t)g[0] | ((uint32_t)g[1] << 30);
+#pragma unroll 6
+        for (int i = 0; i < 30; i++) {
+            uint32_t c1 = (uint32_t)(zeta >> 31);
+            uint32_t c2 = 0u - (g0 & 1u);
+            uint32_t x = (f0 ^ c1) - c1, y = (u ^ c1) - c1, z = (v ^ c1) - c1;
+            g0 += x & c2;
+            q += y & c2;
+            r += z & c2;
+            c1 &= c2;
+            zeta = (int32_t)(((uint32_t)zeta ^ c1) - 1u);
+            f0 += g0 & c1;
+            u += q & c1;
+            v += r & c1;
+            g0 >>= 1;
+            u <<= 1;
+            v <<= 1;
+        }
+        const int32_t tu = (int32_t)u, tv = (int32_t)v, tq = (int32_t)q, tr = (int32_t)r;
+        // ---- (d, e) <- t * (d, e) / 2^30 mod p
+        {
+            int32_t sd = d[12] >> 31, se = e[12] >> 31;
+            int32_t md = (tu & sd) + (tv & se), me = (tq & sd) + (tr & se);
+            int64_t cd = (int64_t)tu * d[0] + (int64_t)tv * e[0];
+            int64_t ce = (int64_t)tq * d[0] + (int64_t)tr * e[0];
+            md -= (int32_t)((BLSW_PINV30 * (uint32_t)cd + (uint32_t)md) & (uint32_t)M30);
+            me -= (int32_t)((BLSW_PINV30 * (uint32_t)ce + (uint32_t)me) & (uint32_t)M30);
+            cd += (int64_t)P30[0] * md;
+            ce += (int64_t)P30[0] * me;
+            cd >>= 30;
+            ce >>= 30;
+#pragma unroll
+            for (int k = 1; k < 13; k++) {
+                int32_t dk = d[k], ek = e[k];
+                cd += (int64_t)tu * dk + (int64_t)tv * ek + (int64_t)P30[k] * md;
+                ce += (int64_t)tq * dk + (int64_t)tr * ek + (int64_t)P30[k] * me;
+                d[k - 1] = (int32_t)cd & M30;
+                e[k - 1] = (int32_t)ce & M30;
+                cd >>= 30;
+                ce >>= 30;
+            }
+            d[12] = (int32_t)cd;
+            e[12] = (int32_t)ce;
+        }
+        // ---- (f, g) <- t * (f, g) / 2^30
+        {
+            int64_t cf = (int64_t)tu * f[0] + (int64_t)tv * g[0];
+            int64_t cg = (int64_t)tq * f[0] + (int64_t)tr * g[0];
+            cf >>= 30;
+            cg >>= 30;
+#pragma unroll
+            for (int k = 1; k < 13; k++) {
+                int32_t fk = f[k], gk = g[k];
+                cf += (int64_t)tu * fk + (int64_t)tv * gk;
+                cg += (int64_t)tq * fk + (int64_t)tr * gk;
+                f[k - 1] = (int32_t)cf & M30;
+                g[k - 1] = (int32_t)cg & M30;
+                cf >>= 30;
+                cg >>= 30;
+            }
+            f[12] = (int32_t)cf;
+            g[12] = (int32_t)cg;
+        }
+    }
+    // ---- normalize d: into (-p, p), negate if f < 0, then into [0, p)
+    {
+        int32_t cond_add = d[12] >> 31;
+#pragma unroll
+        for (int k = 0; k < 13; k++) d[k] += P30[k] & cond_add;
+        int32_t cond_neg = f[12] >> 31;
+#pragma unroll
+        for (int k = 0; k < 13; k++) d[k] = (d[k] ^ cond_neg) - cond_neg;
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            d[k + 1] += d[k] >> 30;
+            d[k] &= M30;
+        }
+        cond_add = d[12] >> 31;
+#pragma unroll
+        for (int k = 0; k < 13; k++) d[k] += P30[k] & cond_add;
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            d[k + 1] += d[k] >> 30;
+            d[k] &= M30;
+        }
+    }
+    // back to 12 x 32-bit limbs
+    Fp r;
+#pragma unroll
+    for (int w = 0; w < 12; w++) {
+        const int bp = 32 * w, k = bp / 30, sh = bp - 30 * k;  // bit bp lives in 30-bit limb k at offset sh
+        uint32_t v = (uint32_t)d[k] >> sh;
+        v |= (uint32_t)d[k + 1] << (30 - sh);
+        if (30 - sh + 30 < 32 && k + 2 < 13) v |= (uint32_t)d[k + 2] << (60 - sh);
+        r.l[w] = v;
     }
     return r;
 }

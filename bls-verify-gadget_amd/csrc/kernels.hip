@@ -66,7 +66,7 @@ __device__ __forceinline__ uint32_t* wit_base(uint64_t* d_witness, uint64_t stri
 
 // ---------------------------------------------------------------- kernels (one instance per lane)
 __global__ __launch_bounds__(64) void k_sha(const uint8_t* __restrict__ msgs, uint32_t msg_len, uint64_t n, blsw_layout_t L, Workspace ws,
-                                            uint64_t* d_witness, uint64_t stride, int want_bits) {
+                                            uint64_t* d_witness, uint64_t stride, int want_bits, int write_u) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint8_t* msg = msgs + i * msg_len;
@@ -80,6 +80,16 @@ __global__ __launch_bounds__(64) void k_sha(const uint8_t* __restrict__ msgs, ui
     s.init(want_bits ? ws.bits + i : nullptr, n);
     uint32_t uw[64];
     expand_message_w(s, msg, msg_len, false, uw);
+    if (write_u)
+        for (int j = 0; j < 4; j++) st_fp(ws.u + (uint64_t)j * n + i, hash_to_field_elem(uw + 16 * j));
+}
+
+// value-only expand_message + hash_to_field: hands u0, u1 to k_map without waiting for the witness-bit pass
+__global__ __launch_bounds__(64) void k_sha_values(const uint8_t* __restrict__ msgs, uint32_t msg_len, uint64_t n, Workspace ws) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t uw[64];
+    expand_message_values(msgs + i * msg_len, msg_len, uw);
     for (int j = 0; j < 4; j++) st_fp(ws.u + (uint64_t)j * n + i, hash_to_field_elem(uw + 16 * j));
 }
 
@@ -224,6 +234,34 @@ __global__ __launch_bounds__(64) void k_h_to_affine(uint64_t n, Workspace ws, ui
     st_fp(o + 3, y.c1);
 }
 
+// ---- micro-benchmarks (roofline denominators): measured on the device, not assumed
+__global__ __launch_bounds__(256) void k_bench_mad(uint32_t iters, uint32_t* out) {
+    uint32_t x = threadIdx.x * 2654435761u + blockIdx.x, y = x ^ 0x9e3779b9u;
+    uint64_t a0 = x, a1 = y, a2 = x + 1, a3 = y + 1, a4 = x + 2, a5 = y + 2, a6 = x + 3, a7 = y + 3;
+    for (uint32_t i = 0; i < iters; i++) {  // 8 independent v_mad_u64_u32 chains per lane
+        a0 = (uint64_t)(uint32_t)a0 * x + a0;
+        a1 = (uint64_t)(uint32_t)a1 * y + a1;
+        a2 = (uint64_t)(uint32_t)a2 * x + a2;
+        a3 = (uint64_t)(uint32_t)a3 * y + a3;
+        a4 = (uint64_t)(uint32_t)a4 * x + a4;
+        a5 = (uint64_t)(uint32_t)a5 * y + a5;
+        a6 = (uint64_t)(uint32_t)a6 * x + a6;
+        a7 = (uint64_t)(uint32_t)a7 * y + a7;
+    }
+    uint64_t r = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
+    if (r == 0x123456789abcdefull) out[0] = (uint32_t)r;  // keep the chains live
+}
+__global__ __launch_bounds__(64) void k_bench_fpmul(uint32_t iters, uint32_t* out) {
+    Fp a = fp_one(), b = fp_one();
+    a.l[0] ^= threadIdx.x + 1;
+    b.l[1] ^= blockIdx.x + 1;
+    for (uint32_t i = 0; i < iters; i++) {
+        a = fp_mul(a, b);
+        b = fp_mul(b, a);
+    }
+    if (a.l[0] == 0x12345678u && b.l[3] == 0x9abcdef0u) out[0] = a.l[1];
+}
+
 inline int hip_ok(hipError_t e, const char* what) {
     if (e != hipSuccess) {
         fprintf(stderr, "[blsw] %s: %s\n", what, hipGetErrorString(e));
@@ -234,9 +272,55 @@ inline int hip_ok(hipError_t e, const char* what) {
 
 }  // namespace
 
+// Execution context: auxiliary streams and events so that the independent chains of one batch overlap.
+//   main : sha_values -> map -> cofactor -> prepare(H) ............ -> pairing -> join
+//   aux0 : g1_alloc, g2_alloc                                        (needs only pk / sig)
+//   aux1 : prepare(sig)                                              (needs only sig)
+//   aux2 : sha witness bits -> sha_expand (the HBM-bound stream of ~31 MB / instance)
+struct blsw_ctx {
+    hipStream_t aux[3];
+    hipEvent_t ev_start, ev_aux[3];
+    hipEvent_t ev_exp0, ev_exp1;  // around k_sha_expand, for the live roofline measurement
+    int have_expand_timing;
+};
+
 extern "C" {
 
-int blsw_version(void) { return 1; }
+int blsw_version(void) { return 2; }
+
+int blsw_ctx_create(blsw_ctx_t** out) {
+    if (!out) return BLSW_ERR_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return BLSW_ERR_NO_DEVICE;
+    blsw_ctx* c = new blsw_ctx();
+    for (int i = 0; i < 3; i++) {
+        if (hip_ok(hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking), "stream create")) return BLSW_ERR_HIP;
+        if (hip_ok(hipEventCreateWithFlags(&c->ev_aux[i], hipEventDisableTiming), "event create")) return BLSW_ERR_HIP;
+    }
+    if (hip_ok(hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming), "event create")) return BLSW_ERR_HIP;
+    if (hip_ok(hipEventCreate(&c->ev_exp0), "event create") || hip_ok(hipEventCreate(&c->ev_exp1), "event create")) return BLSW_ERR_HIP;
+    c->have_expand_timing = 0;
+    *out = c;
+    return BLSW_OK;
+}
+int blsw_ctx_destroy(blsw_ctx_t* c) {
+    if (!c) return BLSW_ERR_ARG;
+    for (int i = 0; i < 3; i++) {
+        hipStreamDestroy(c->aux[i]);
+        hipEventDestroy(c->ev_aux[i]);
+    }
+    hipEventDestroy(c->ev_start);
+    hipEventDestroy(c->ev_exp0);
+    hipEventDestroy(c->ev_exp1);
+    delete c;
+    return BLSW_OK;
+}
+// duration of the last k_sha_expand launch issued through this context (blocks until it has finished)
+int blsw_ctx_last_expand_ms(blsw_ctx_t* c, float* ms) {
+    if (!c || !ms || !c->have_expand_timing) return BLSW_ERR_ARG;
+    if (hip_ok(hipEventSynchronize(c->ev_exp1), "event sync")) return BLSW_ERR_HIP;
+    return hip_ok(hipEventElapsedTime(ms, c->ev_exp0, c->ev_exp1), "event elapsed");
+}
 
 int blsw_layout(uint32_t msg_len, blsw_layout_t* out) {
     if (!out || msg_len > 65535) return BLSW_ERR_ARG;
@@ -253,9 +337,9 @@ int blsw_workspace_bytes(uint64_t n, uint32_t msg_len, uint64_t* bytes) {
     return BLSW_OK;
 }
 
-int blsw_witness_batch(const uint64_t* d_pk_xy, const uint64_t* d_sig_xy, const uint8_t* d_msg, uint32_t msg_len, uint64_t n, uint64_t* d_witness,
-                       uint64_t witness_stride, int32_t* d_result, void* d_workspace, uint64_t workspace_bytes, void* stream_) {
-    if (!d_pk_xy || !d_sig_xy || (!d_msg && msg_len) || n == 0 || !d_workspace) return BLSW_ERR_ARG;
+int blsw_witness_batch(blsw_ctx_t* c, const uint64_t* d_pk_xy, const uint64_t* d_sig_xy, const uint8_t* d_msg, uint32_t msg_len, uint64_t n,
+                       uint64_t* d_witness, uint64_t witness_stride, int32_t* d_result, void* d_workspace, uint64_t workspace_bytes, void* stream_) {
+    if (!c || !d_pk_xy || !d_sig_xy || (!d_msg && msg_len) || n == 0 || !d_workspace) return BLSW_ERR_ARG;
     blsw_layout_t L;
     make_layout(msg_len, &L);
     if (d_witness && witness_stride < L.n_witness) return BLSW_ERR_ARG;
@@ -263,17 +347,35 @@ int blsw_witness_batch(const uint64_t* d_pk_xy, const uint64_t* d_sig_xy, const 
     if (ws.total_bytes > workspace_bytes) return BLSW_ERR_WORKSPACE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream_);
     const unsigned g1 = (unsigned)((n + 63) / 64), g2 = (unsigned)((2 * n + 63) / 64);
-    hipLaunchKernelGGL(k_sha, dim3(g1), dim3(64), 0, st, d_msg, msg_len, n, L, ws, d_witness, witness_stride, d_witness ? 1 : 0);
+    // fork
+    hipEventRecord(c->ev_start, st);
+    for (int i = 0; i < 3; i++) hipStreamWaitEvent(c->aux[i], c->ev_start, 0);
+    // aux0: group allocations
+    hipLaunchKernelGGL(k_g1, dim3(g1), dim3(64), 0, c->aux[0], d_pk_xy, n, L, ws, d_witness, witness_stride);
+    hipLaunchKernelGGL(k_g2_alloc, dim3(g1), dim3(64), 0, c->aux[0], d_sig_xy, n, L, d_witness, witness_stride);
+    hipEventRecord(c->ev_aux[0], c->aux[0]);
+    // aux1: prepare_g2(sig)
+    hipLaunchKernelGGL(k_prepare, dim3(g1), dim3(64), 0, c->aux[1], d_sig_xy, n, L, ws, d_witness, witness_stride, 1, 1);
+    hipEventRecord(c->ev_aux[1], c->aux[1]);
+    // aux2: SHA-256 witness bits and their expansion (only when witnesses are requested)
     if (d_witness) {
+        hipLaunchKernelGGL(k_sha, dim3(g1), dim3(64), 0, c->aux[2], d_msg, msg_len, n, L, ws, d_witness, witness_stride, 1, 0);
         dim3 grid((L.sha_bits * 3 + 4095) / 4096, (unsigned)n);
-        hipLaunchKernelGGL(k_sha_expand, grid, dim3(256), 0, st, ws.bits, n, L.sha_bits, L.off_expand, d_witness, witness_stride);
+        hipEventRecord(c->ev_exp0, c->aux[2]);
+        hipLaunchKernelGGL(k_sha_expand, grid, dim3(256), 0, c->aux[2], ws.bits, n, L.sha_bits, L.off_expand, d_witness, witness_stride);
+        hipEventRecord(c->ev_exp1, c->aux[2]);
+        c->have_expand_timing = 1;
     }
-    hipLaunchKernelGGL(k_g1, dim3(g1), dim3(64), 0, st, d_pk_xy, n, L, ws, d_witness, witness_stride);
-    hipLaunchKernelGGL(k_g2_alloc, dim3(g1), dim3(64), 0, st, d_sig_xy, n, L, d_witness, witness_stride);
+    hipEventRecord(c->ev_aux[2], c->aux[2]);
+    // main: the hash-to-G2 critical path
+    hipLaunchKernelGGL(k_sha_values, dim3(g1), dim3(64), 0, st, d_msg, msg_len, n, ws);
     hipLaunchKernelGGL(k_map, dim3(g2), dim3(64), 0, st, n, L, ws, d_witness, witness_stride);
     hipLaunchKernelGGL(k_cofactor, dim3(g1), dim3(64), 0, st, n, L, ws, d_witness, witness_stride);
-    hipLaunchKernelGGL(k_prepare, dim3(g2), dim3(64), 0, st, d_sig_xy, n, L, ws, d_witness, witness_stride, 0, 2);
+    hipLaunchKernelGGL(k_prepare, dim3(g1), dim3(64), 0, st, d_sig_xy, n, L, ws, d_witness, witness_stride, 0, 1);
+    hipStreamWaitEvent(st, c->ev_aux[0], 0);
+    hipStreamWaitEvent(st, c->ev_aux[1], 0);
     hipLaunchKernelGGL(k_pairing, dim3(g1), dim3(64), 0, st, n, L, ws, d_witness, witness_stride, d_result);
+    hipStreamWaitEvent(st, c->ev_aux[2], 0);  // join
     return hip_ok(hipGetLastError(), "launch");
 }
 
@@ -286,10 +388,38 @@ int blsw_hash_to_g2_batch(const uint8_t* d_msg, uint32_t msg_len, uint64_t n, ui
     if (ws.total_bytes > workspace_bytes) return BLSW_ERR_WORKSPACE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream_);
     const unsigned g1 = (unsigned)((n + 63) / 64), g2 = (unsigned)((2 * n + 63) / 64);
-    hipLaunchKernelGGL(k_sha, dim3(g1), dim3(64), 0, st, d_msg, msg_len, n, L, ws, (uint64_t*)nullptr, (uint64_t)0, 0);
+    hipLaunchKernelGGL(k_sha_values, dim3(g1), dim3(64), 0, st, d_msg, msg_len, n, ws);
     hipLaunchKernelGGL(k_map, dim3(g2), dim3(64), 0, st, n, L, ws, (uint64_t*)nullptr, (uint64_t)0);
     hipLaunchKernelGGL(k_cofactor, dim3(g1), dim3(64), 0, st, n, L, ws, (uint64_t*)nullptr, (uint64_t)0);
     hipLaunchKernelGGL(k_h_to_affine, dim3(g1), dim3(64), 0, st, n, ws, d_out_affine);
     return hip_ok(hipGetLastError(), "launch");
+}
+
+// which = 0: v_mad_u64_u32 issue rate (result in multiply-adds/s); which = 1: fp_mul rate (Fp products/s). Synchronous.
+int blsw_microbench(int which, uint32_t iters, uint32_t blocks, double* ops_per_s) {
+    if (!ops_per_s || iters == 0 || blocks == 0) return BLSW_ERR_ARG;
+    uint32_t* d = nullptr;
+    if (hip_ok(hipMalloc(&d, 4), "malloc")) return BLSW_ERR_HIP;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    const int threads = which == 0 ? 256 : 64;
+    for (int rep = 0; rep < 2; rep++) {  // first pass warms up
+        hipEventRecord(e0, 0);
+        if (which == 0)
+            hipLaunchKernelGGL(k_bench_mad, dim3(blocks), dim3(threads), 0, 0, iters, d);
+        else
+            hipLaunchKernelGGL(k_bench_fpmul, dim3(blocks), dim3(threads), 0, 0, iters, d);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+    }
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    double per_lane = which == 0 ? 8.0 * iters : 2.0 * iters;
+    *ops_per_s = per_lane * blocks * threads / (ms * 1e-3);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    hipFree(d);
+    return hip_ok(hipGetLastError(), "microbench");
 }
 }

@@ -301,6 +301,95 @@ BLSW_FN void expand_message_w(BitSink& s, const uint8_t* msg, uint32_t msg_len, 
     s.flush();
 }
 
+// ---- value-only path: plain SHA-256 / expand_message_xmd (no witness bits). Used to hand u0, u1 to the
+// map_to_curve chain immediately, while the witness-bit pass of the same message runs on another stream.
+BLSW_FN void sha256_compress_plain(uint32_t st[8], const uint32_t w_in[16]) {
+    constexpr uint32_t K[64] = BLSW_SHA_K;
+    uint32_t w[64];
+    for (int i = 0; i < 16; i++) w[i] = w_in[i];
+#pragma unroll 1
+    for (int i = 16; i < 64; i++) {
+        uint32_t s0 = rotr32(w[i - 15], 7) ^ rotr32(w[i - 15], 18) ^ (w[i - 15] >> 3);
+        uint32_t s1 = rotr32(w[i - 2], 17) ^ rotr32(w[i - 2], 19) ^ (w[i - 2] >> 10);
+        w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+    }
+    uint32_t a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
+#pragma unroll 1
+    for (int i = 0; i < 64; i++) {
+        uint32_t ch = (e & f) ^ (~e & g);
+        uint32_t ma = (a & b) ^ (a & c) ^ (b & c);
+        uint32_t s0 = rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22);
+        uint32_t s1 = rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25);
+        uint32_t t0 = h + s1 + ch + K[i] + w[i];
+        uint32_t t1 = s0 + ma;
+        h = g;
+        g = f;
+        f = e;
+        e = d + t0;
+        d = c;
+        c = b;
+        b = a;
+        a = t0 + t1;
+    }
+    st[0] += a;
+    st[1] += b;
+    st[2] += c;
+    st[3] += d;
+    st[4] += e;
+    st[5] += f;
+    st[6] += g;
+    st[7] += h;
+}
+BLSW_FN void expand_message_values(const uint8_t* msg, uint32_t msg_len, uint32_t uniform_words[64]) {
+    constexpr uint32_t H0[8] = BLSW_SHA_H0;
+    const char dst[] = BLSW_DST;
+    uint32_t st[8];
+    for (int i = 0; i < 8; i++) st[i] = H0[i];
+    uint32_t total = 64 + msg_len + 3 + BLSW_DST_LEN + 1;
+    uint32_t nblocks = (total + 9 + 63) / 64;
+#pragma unroll 1
+    for (uint32_t blk = 0; blk < nblocks; blk++) {
+        uint32_t data[16];
+        for (int wi = 0; wi < 16; wi++) {
+            uint32_t v = 0;
+            for (int b = 0; b < 4; b++) {
+                uint32_t bv;
+                bool bc;
+                b0_byte(msg, msg_len, false, blk * 64 + wi * 4 + b, total, bv, bc);
+                v |= bv << (8 * (3 - b));
+            }
+            data[wi] = v;
+        }
+        sha256_compress_plain(st, data);
+    }
+    uint32_t b0[8], last[8];
+    for (int i = 0; i < 8; i++) b0[i] = st[i];
+    uint8_t tailb[96];
+    for (int k = 0; k < 96; k++) tailb[k] = 0;
+    for (int k = 0; k < BLSW_DST_LEN; k++) tailb[1 + k] = (uint8_t)dst[k];
+    tailb[1 + BLSW_DST_LEN] = BLSW_DST_LEN;
+    tailb[2 + BLSW_DST_LEN] = 0x80;
+    tailb[94] = (uint8_t)((77 * 8) >> 8);
+    tailb[95] = (uint8_t)((77 * 8) & 0xff);
+#pragma unroll 1
+    for (uint32_t i = 1; i <= 8; i++) {
+        uint32_t data[16];
+        for (int k = 0; k < 8; k++) data[k] = (i == 1) ? b0[k] : (b0[k] ^ last[k]);
+        tailb[0] = (uint8_t)i;
+        for (int k = 0; k < 8; k++)
+            data[8 + k] = ((uint32_t)tailb[4 * k] << 24) | ((uint32_t)tailb[4 * k + 1] << 16) | ((uint32_t)tailb[4 * k + 2] << 8) | tailb[4 * k + 3];
+        for (int k = 0; k < 8; k++) st[k] = H0[k];
+        sha256_compress_plain(st, data);
+        for (int k = 0; k < 16; k++)
+            data[k] = ((uint32_t)tailb[32 + 4 * k] << 24) | ((uint32_t)tailb[33 + 4 * k] << 16) | ((uint32_t)tailb[34 + 4 * k] << 8) | tailb[35 + 4 * k];
+        sha256_compress_plain(st, data);
+        for (int k = 0; k < 8; k++) {
+            last[k] = st[k];
+            uniform_words[(i - 1) * 8 + k] = st[k];
+        }
+    }
+}
+
 // hash_to_field (hasher.rs:58-107): element j (0..3) = OS2IP(uniform_bytes[64j .. 64j+64)) mod p as
 // head(47 high bytes) * 256^17 + tail(17 low bytes); linear combinations only (no witnesses).
 BLSW_FN Fp hash_to_field_elem(const uint32_t* W /*16 big-endian words*/) {

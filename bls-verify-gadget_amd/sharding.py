@@ -1,0 +1,38 @@
+"""Instance sharding across ranks (one process per GPU). Instances are fully independent:
+contiguous blocks per rank, no data-path collective. Only the per-instance result booleans (and, on request,
+fixed-size witness chunks) are exchanged, with torch.distributed (backend "nccl" = RCCL on ROCm, "gloo" on CPU)."""
+
+
+def shard_range(n_total, rank, world):
+    """Contiguous block [lo, hi) of instances owned by `rank`; sizes differ by at most one."""
+    base, rem = divmod(n_total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def all_gather_results(local_results, n_total, group=None):
+    """Gathers the int32 result shards of all ranks into one [n_total] tensor (ragged shards are padded)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    sizes = [shard_range(n_total, r, world) for r in range(world)]
+    m = max(hi - lo for lo, hi in sizes)
+    pad = torch.zeros(m, dtype=local_results.dtype, device=local_results.device)
+    pad[: local_results.numel()] = local_results
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    return torch.cat([parts[r][: hi - lo] for r, (lo, hi) in enumerate(sizes)])
+
+
+def all_gather_witness_chunk(local_chunk, group=None):
+    """RCCL all-gather of one equal-sized witness micro-batch chunk ([m, k, 6] int64 per rank -> [world*m, k, 6]).
+    The full gathered witness (n x 34 MB) does not fit one GPU at config-3 scale, so callers gather micro-batches
+    and hand each to its consumer before the next."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    out = torch.empty((world * local_chunk.shape[0],) + tuple(local_chunk.shape[1:]), dtype=local_chunk.dtype, device=local_chunk.device)
+    dist.all_gather_into_tensor(out, local_chunk.contiguous(), group=group)
+    return out

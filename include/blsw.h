@@ -50,6 +50,15 @@ int blsw_layout(uint32_t msg_len, blsw_layout_t* out);
 /* bytes of device workspace blsw_witness_batch needs for n instances */
 int blsw_workspace_bytes(uint64_t n, uint32_t msg_len, uint64_t* bytes);
 
+/* Execution context: auxiliary HIP streams/events of the current device, so that the independent chains of one batch
+ * (G1/G2 allocation, prepare_g2(sig), SHA witness expansion, hash-to-G2 critical path) overlap. One context per
+ * concurrently in-flight batch. */
+typedef struct blsw_ctx blsw_ctx_t;
+int blsw_ctx_create(blsw_ctx_t** out);
+int blsw_ctx_destroy(blsw_ctx_t* ctx);
+/* duration (ms) of the last bit->Fp expansion kernel launched through ctx (HIP events on the stream it ran on) */
+int blsw_ctx_last_expand_ms(blsw_ctx_t* ctx, float* ms);
+
 /* Fills the witness vectors of n independent (pk, msg, sig) instances.
  *   d_pk_xy   [n][12] u64  affine G1 (x, y) Montgomery; (0,0) = point at infinity      (PublicKeyVar, constraints.rs:214-232)
  *   d_sig_xy  [n][24] u64  affine G2 (x.c0, x.c1, y.c0, y.c1); all zero = infinity     (SignatureVar, constraints.rs:234-249)
@@ -57,14 +66,17 @@ int blsw_workspace_bytes(uint64_t n, uint32_t msg_len, uint64_t* bytes);
  *   d_witness [n][witness_stride] field elements (48 B each), witness_stride >= layout.n_witness; may be NULL (results only)
  *   d_result  [n] int32: value of the gadget's output Boolean (constraints.rs:127)
  * Asynchronous on `stream` (hipStream_t, may be NULL). */
-int blsw_witness_batch(const uint64_t* d_pk_xy, const uint64_t* d_sig_xy, const uint8_t* d_msg, uint32_t msg_len, uint64_t n, uint64_t* d_witness,
+int blsw_witness_batch(blsw_ctx_t* ctx, const uint64_t* d_pk_xy, const uint64_t* d_sig_xy, const uint8_t* d_msg, uint32_t msg_len, uint64_t n, uint64_t* d_witness,
                        uint64_t witness_stride, int32_t* d_result, void* d_workspace, uint64_t workspace_bytes, void* stream);
 
 /* hash_to_g2 only (src/hasher.rs:727-740 / src/bls.rs:477-493): d_out_affine [n][24] u64 (x.c0, x.c1, y.c0, y.c1) Montgomery */
 int blsw_hash_to_g2_batch(const uint8_t* d_msg, uint32_t msg_len, uint64_t n, uint64_t* d_out_affine, void* d_workspace, uint64_t workspace_bytes,
                           void* stream);
 
-/* Stage timing hooks for bench.py: runs only the named stage (0 = all). See DESIGN.md. */
+/* Device micro-benchmarks that give the VALU roofline its MEASURED denominator:
+ * which = 0: v_mad_u64_u32 rate (32x32+64 multiply-adds per second, all CUs); which = 1: Fp Montgomery products per second. */
+int blsw_microbench(int which, uint32_t iters, uint32_t blocks, double* ops_per_s);
+
 int blsw_version(void);
 
 #ifdef __cplusplus

@@ -67,4 +67,8 @@ void hostsim_fp_inv(const uint64_t* a, uint64_t* r) {
     Fp z = fp_inv(load_fp(a));
     memcpy(r, z.l, 48);
 }
+void hostsim_fp_inv_fermat(const uint64_t* a, uint64_t* r) {
+    Fp z = fp_inv_fermat(load_fp(a));
+    memcpy(r, z.l, 48);
+}
 }

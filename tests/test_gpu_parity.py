@@ -78,7 +78,7 @@ def test_verify_fixtures(pkg, oracle):
         if st1 or st2 or inf1 or inf2 or len(unhex(i["message"])) != 32:
             continue
         rows.append((pk, np.frombuffer(unhex(i["message"]), dtype=np.uint8), sig, case["output"]))
-    assert len(rows) >= 27
+    assert len(rows) >= 19  # 9 valid + 9 wrong-pubkey + sk=1 case; tampered signatures do not decode
     pk = np.stack([r[0] for r in rows])
     msg = np.stack([r[1] for r in rows])
     sig = np.stack([r[2] for r in rows])

@@ -1,0 +1,69 @@
+"""N>1 path on CPU: world_size-2 gloo processes shard a batch by instance, each rank produces its shard's results
+(here with the CPU oracle as the stand-in compute; the GPU engine plugs in at the same place) and the shards are
+gathered. Covers ragged shards."""
+import importlib
+import os
+import socket
+
+import numpy as np
+import pytest
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_total, q):
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests import oracle_lib, synth
+
+    sharding = importlib.import_module("bls-verify-gadget_amd.sharding")
+    o = oracle_lib.load()
+    pk, msg, sig, expect = synth.make_batch(o, n_total, tamper_every=2)
+    lo, hi = sharding.shard_range(n_total, rank, world)
+    res, _ = o.witness_batch(pk[lo:hi], msg[lo:hi], sig[lo:hi], threads=1, want_digests=False)
+    local = torch.from_numpy(res.astype(np.int32))
+    full = sharding.all_gather_results(local, n_total)
+    chunk = torch.full((2, 3, 6), rank, dtype=torch.int64)
+    gathered = sharding.all_gather_witness_chunk(chunk)
+    if rank == 0:
+        q.put((full.numpy().astype(bool).tolist(), expect.tolist(), gathered[:, 0, 0].tolist()))
+    dist.destroy_process_group()
+
+
+def test_shard_ranges():
+    sharding = importlib.import_module("bls-verify-gadget_amd.sharding")
+    for n in (0, 1, 5, 8, 65536):
+        for w in (1, 2, 3, 8):
+            r = [sharding.shard_range(n, k, w) for k in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(r[k][1] == r[k + 1][0] for k in range(w - 1))
+            assert max(h - l for l, h in r) - min(h - l for l, h in r) <= 1
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_gather():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    n_total = 5  # ragged: 3 + 2
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got, expect, gathered = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got == expect
+    assert gathered == [0, 0, 1, 1]
