@@ -6,9 +6,10 @@ One "step" = one pass of the hot path (blsw_witness_batch: every witness of the 
 instances (BASELINE.json configs[1]). Inputs are resident in HBM before the timed region; every step writes a
 complete [1024][n_witness] witness tensor (34 MB per instance) into HBM.
 
-Steps are issued into a ring of `--inflight` execution slots (each with its own HIP streams, workspace and output
-tensor), so independent batches overlap on the device exactly as a prover feeding on finished batches would see
-them; EXACTLY K steps are timed between barrier + synchronize on both sides.
+Steps are SUBMITTED to the engine, which fuses up to `--coalesce` pending batches into one group of launches (a single
+batch of 1024 instances is 16 wavefronts per chain kernel on a 1024-SIMD chip) and then writes every step's witness
+tensor, in submission order, into a ring of `--outputs` output tensors. EXACTLY K steps (K full witness tensors) are
+timed between barrier + synchronize on both sides.
 
 Multi-GPU (launched by torch.distributed.run, one rank per GPU): instances are independent, each rank processes its
 own 1 024-instance shard per step (weak scaling, no data-path collective); only the result vectors are gathered.
@@ -48,10 +49,11 @@ def synth_inputs(n, seed=0x5EED):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=1024, help="instances per GPU per step (configs[1]: 1024)")
-    ap.add_argument("--inflight", type=int, default=6, help="batches in flight per GPU (each owns a 34 MB x batch output tensor)")
+    ap.add_argument("--coalesce", type=int, default=32, help="max submitted batches fused into one launch group")
+    ap.add_argument("--outputs", type=int, default=2, help="ring of output witness tensors (34 MB x batch each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=32)
     args = ap.parse_args()
@@ -78,21 +80,25 @@ def main():
     d_sig = torch.from_numpy(sig.view(np.int64)).to(dev)
     d_msg = torch.from_numpy(msg).to(dev)
     lay = pkg.layout(32)
-    per_slot = n * lay["n_witness"] * 48 + pkg.workspace_bytes(n, 32)
+    # engine: up to `--coalesce` submitted batches are fused into one launch group (fills the SIMDs); witness tensors
+    # are written per step, in order, into a ring of `--outputs` output tensors (a consumer would drain them in order)
+    out_bytes = n * lay["n_witness"] * 48
     free_b, _ = torch.cuda.mem_get_info(dev)
-    inflight = max(1, min(args.inflight, int(free_b * 0.92 // per_slot), args.steps + args.warmup))
-    slots = [pkg.BlsSignatureVerifyGadget(n, 32, device=dev, want_witness=True) for _ in range(inflight)]
-    streams = [torch.cuda.Stream(device=dev) for _ in range(inflight)]
-    params, pkv, sigv = pkg.ParametersVar(), pkg.PublicKeyVar.new_witness(d_pk), pkg.SignatureVar.new_witness(d_sig)
+    n_out = max(1, min(args.outputs, args.steps + args.warmup))
+    coalesce = max(1, min(args.coalesce, args.steps))
+    while coalesce > 1 and pkg.engine_workspace_bytes(n, 32, coalesce) + n_out * out_bytes > 0.92 * free_b:
+        coalesce -= 1
+    eng = pkg.WitnessEngine(n, 32, max_steps=coalesce, device=dev)
+    outs = [eng.new_witness_tensor() for _ in range(n_out)]
+    results = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(n_out)]
     torch.cuda.synchronize()
 
     def step(k):
-        s = k % inflight
-        with torch.cuda.stream(streams[s]):
-            slots[s].verify(params, pkv, d_msg, sigv, stream=streams[s])
+        eng.submit(d_pk, d_sig, d_msg, witness=outs[k % n_out], result=results[k % n_out])
 
     for k in range(args.warmup):
         step(k)
+    eng.flush()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -100,6 +106,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(args.warmup + k)
+    eng.flush()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -108,14 +115,14 @@ def main():
 
     # live measurement of the dominant-by-bytes kernel (k_sha_expand): HIP events recorded around it on the stream it
     # ran on, inside the timed region (last launch of every slot)
-    exp_ms = [s.last_expand_ms() for s in slots]
-    res = torch.stack([s.result for s in slots])
+    exp_ms = [eng.last_expand_ms()]
+    res = torch.stack(results)
     ok = bool((res.cpu().numpy().astype(bool) == expect[None, :]).all())
     if dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        sharding.all_gather_results(slots[0].result, n * world)  # result shards only (multi-GPU)
+        sharding.all_gather_results(results[0], n * world)  # result shards only (multi-GPU)
 
     if rank != 0:
         return
@@ -142,7 +149,7 @@ def main():
         "dtype": "u32 (12 x 32-bit limb Montgomery integers mod the 381-bit BLS12-381 prime; SHA-256 words)",
         "data": "synthetic",
         "config": {"workload": "configs[1]: batch of 1024 independent BLS-verify instances per GPU per step, 32-byte messages, full witness vectors written",
-                   "instances_per_gpu_per_step": n, "batches_in_flight": inflight, "n_witness": lay["n_witness"], "results_ok": ok},
+                   "instances_per_gpu_per_step": n, "batches_fused_per_launch_group": coalesce, "output_ring": n_out, "n_witness": lay["n_witness"], "results_ok": ok},
         "roofline": {"bound": "hbm", "kernel": "k_sha_expand", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                      "traffic": None, "algorithmic_bytes_per_launch": expand_bytes, "avg_launch_ms": exp_avg_ms},
         "roofline_whole_path": {"bound": "hbm", "algorithmic_bytes_per_instance": bytes_per_instance,

@@ -50,21 +50,23 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise BlswError("libblsw.so is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (no CPU fallback exists)")
         L = ctypes.CDLL(LIB_PATH)
-        L.blsw_layout.argtypes = [ctypes.c_uint32, ctypes.POINTER(blsw_layout_t)]
-        L.blsw_workspace_bytes.argtypes = [ctypes.c_uint64, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64)]
-        L.blsw_ctx_create.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
-        L.blsw_ctx_destroy.argtypes = [ctypes.c_void_p]
-        L.blsw_ctx_last_expand_ms.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
-        L.blsw_microbench.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_double)]
-        L.blsw_witness_batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64,
-                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
-        L.blsw_hash_to_g2_batch.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
+        vp, u32, u64 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64
+        L.blsw_layout.argtypes = [u32, ctypes.POINTER(blsw_layout_t)]
+        L.blsw_engine_workspace_bytes.argtypes = [u64, u32, u32, ctypes.POINTER(u64)]
+        L.blsw_engine_create.argtypes = [ctypes.POINTER(vp), u64, u32, u32, vp, u64]
+        L.blsw_engine_destroy.argtypes = [vp]
+        L.blsw_engine_submit.argtypes = [vp, vp, vp, vp, vp, u64, vp, vp]
+        L.blsw_engine_flush.argtypes = [vp, vp]
+        L.blsw_engine_last_expand_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+        L.blsw_hash_to_g2_workspace_bytes.argtypes = [u64, u32, ctypes.POINTER(u64)]
+        L.blsw_hash_to_g2_batch.argtypes = [vp, u32, u64, vp, vp, u64, vp]
+        L.blsw_microbench.argtypes = [ctypes.c_int, u32, u32, ctypes.POINTER(ctypes.c_double)]
         _lib = L
     return _lib
 
 
-EXPORTED_SYMBOLS = ["blsw_version", "blsw_layout", "blsw_workspace_bytes", "blsw_ctx_create", "blsw_ctx_destroy", "blsw_ctx_last_expand_ms",
-                    "blsw_witness_batch", "blsw_hash_to_g2_batch", "blsw_microbench"]
+EXPORTED_SYMBOLS = ["blsw_version", "blsw_layout", "blsw_engine_workspace_bytes", "blsw_engine_create", "blsw_engine_destroy", "blsw_engine_submit",
+                    "blsw_engine_flush", "blsw_engine_last_expand_ms", "blsw_hash_to_g2_workspace_bytes", "blsw_hash_to_g2_batch", "blsw_microbench"]
 
 
 def layout(msg_len=32):
@@ -76,11 +78,11 @@ def layout(msg_len=32):
     return {n: getattr(L, n) for n in _LAYOUT_FIELDS}
 
 
-def workspace_bytes(n, msg_len=32):
+def engine_workspace_bytes(n, msg_len=32, max_steps=1):
     b = ctypes.c_uint64(0)
-    rc = lib().blsw_workspace_bytes(n, msg_len, ctypes.byref(b))
+    rc = lib().blsw_engine_workspace_bytes(n, msg_len, max_steps, ctypes.byref(b))
     if rc:
-        raise BlswError("blsw_workspace_bytes failed: %d" % rc)
+        raise BlswError("blsw_engine_workspace_bytes failed: %d" % rc)
     return b.value
 
 
@@ -90,6 +92,68 @@ def _require_cuda():
     if not torch.cuda.is_available():
         raise BlswError("no HIP device visible: the witness path runs only on the GPU (there is no CPU fallback)")
     return torch
+
+
+class WitnessEngine:
+    """Thin wrapper of blsw_engine_*: submit batches, flush, read results. max_steps batches are fused per launch group."""
+
+    def __init__(self, n, msg_len=32, max_steps=1, device=None):
+        torch = _require_cuda()
+        self.torch = torch
+        self.n, self.msg_len, self.max_steps = int(n), int(msg_len), int(max_steps)
+        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        self.layout = layout(msg_len)
+        self.n_witness = self.layout["n_witness"]
+        self.workspace = torch.empty(engine_workspace_bytes(self.n, msg_len, self.max_steps), dtype=torch.uint8, device=self.device)
+        self._e = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            rc = lib().blsw_engine_create(ctypes.byref(self._e), self.n, self.msg_len, self.max_steps, self.workspace.data_ptr(), self.workspace.numel())
+        if rc:
+            raise BlswError("blsw_engine_create failed: %d" % rc)
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "_e", None):
+            lib().blsw_engine_destroy(self._e)
+            self._e = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def new_witness_tensor(self):
+        return self.torch.empty((self.n, self.n_witness, 6), dtype=self.torch.int64, device=self.device)
+
+    def submit(self, pk_xy, sig_xy, msg, witness=None, result=None, stream=None):
+        torch = self.torch
+        assert pk_xy.is_cuda and sig_xy.is_cuda and msg.is_cuda
+        assert pk_xy.shape == (self.n, 12) and sig_xy.shape == (self.n, 24) and msg.shape == (self.n, self.msg_len)
+        assert pk_xy.is_contiguous() and sig_xy.is_contiguous() and msg.is_contiguous()
+        if witness is not None:
+            assert witness.is_contiguous() and witness.shape[0] == self.n and witness.shape[1] >= self.n_witness
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        rc = lib().blsw_engine_submit(self._e, pk_xy.data_ptr(), sig_xy.data_ptr(), msg.data_ptr() if self.msg_len else None,
+                                      witness.data_ptr() if witness is not None else None, witness.shape[1] if witness is not None else 0,
+                                      result.data_ptr() if result is not None else None, s.cuda_stream)
+        if rc:
+            raise BlswError("blsw_engine_submit failed: %d" % rc)
+        self._keep.append((pk_xy, sig_xy, msg, witness, result))
+
+    def flush(self, stream=None):
+        s = stream if stream is not None else self.torch.cuda.current_stream(self.device)
+        rc = lib().blsw_engine_flush(self._e, s.cuda_stream)
+        if rc:
+            raise BlswError("blsw_engine_flush failed: %d" % rc)
+        self._keep = self._keep[-4 * self.max_steps:]
+
+    def last_expand_ms(self):
+        ms = ctypes.c_float(0)
+        rc = lib().blsw_engine_last_expand_ms(self._e, ctypes.byref(ms))
+        if rc:
+            raise BlswError("blsw_engine_last_expand_ms failed: %d" % rc)
+        return ms.value
 
 
 class ParametersVar:
@@ -122,55 +186,25 @@ class SignatureVar:
 
 
 class BlsSignatureVerifyGadget:
-    """Batched counterpart of constraints.rs:79-128. One call = n independent circuits."""
+    """Batched counterpart of constraints.rs:79-128. One call = n independent circuits (direct mode engine, one batch)."""
 
-    def __init__(self, n, msg_len=32, device=None, want_witness=True):
-        torch = _require_cuda()
+    def __init__(self, n, msg_len=32, device=None, want_witness=True, max_steps=1):
+        self.engine = WitnessEngine(n, msg_len, max_steps=max_steps, device=device)
+        torch = self.engine.torch
         self.torch = torch
-        self.n = int(n)
-        self.msg_len = int(msg_len)
-        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
-        self.layout = layout(msg_len)
-        self.n_witness = self.layout["n_witness"]
-        self.workspace = torch.empty(workspace_bytes(self.n, msg_len), dtype=torch.uint8, device=self.device)
+        self.n, self.msg_len, self.device = self.engine.n, self.engine.msg_len, self.engine.device
+        self.layout = self.engine.layout
+        self.n_witness = self.engine.n_witness
         self.result = torch.empty(self.n, dtype=torch.int32, device=self.device)
-        self.witness = torch.empty((self.n, self.n_witness, 6), dtype=torch.int64, device=self.device) if want_witness else None
-        self._ctx = ctypes.c_void_p()
-        with torch.cuda.device(self.device):
-            rc = lib().blsw_ctx_create(ctypes.byref(self._ctx))
-        if rc:
-            raise BlswError("blsw_ctx_create failed: %d" % rc)
-
-    def __del__(self):
-        try:
-            if getattr(self, "_ctx", None):
-                lib().blsw_ctx_destroy(self._ctx)
-                self._ctx = None
-        except Exception:
-            pass
-
-    def last_expand_ms(self):
-        ms = ctypes.c_float(0)
-        rc = lib().blsw_ctx_last_expand_ms(self._ctx, ctypes.byref(ms))
-        if rc:
-            raise BlswError("blsw_ctx_last_expand_ms failed: %d" % rc)
-        return ms.value
+        self.witness = self.engine.new_witness_tensor() if want_witness else None
 
     def verify(self, parameters, public_key, message, signature, witness=None, stream=None):
         """message: [n, msg_len] uint8 tensor. Returns the int32 result tensor (gadget Boolean per instance); the witness
         vectors are in self.witness (or the tensor passed as `witness`)."""
-        torch = self.torch
         assert isinstance(parameters, ParametersVar)
-        pk, sig = public_key.xy, signature.xy
-        assert pk.is_cuda and sig.is_cuda and message.is_cuda
-        assert pk.shape == (self.n, 12) and sig.shape == (self.n, 24) and message.shape == (self.n, self.msg_len)
-        assert pk.is_contiguous() and sig.is_contiguous() and message.is_contiguous()
         w = witness if witness is not None else self.witness
-        s = stream if stream is not None else torch.cuda.current_stream(self.device)
-        rc = lib().blsw_witness_batch(self._ctx, pk.data_ptr(), sig.data_ptr(), message.data_ptr(), self.msg_len, self.n, w.data_ptr() if w is not None else None,
-                                      self.n_witness, self.result.data_ptr(), self.workspace.data_ptr(), self.workspace.numel(), s.cuda_stream)
-        if rc:
-            raise BlswError("blsw_witness_batch failed: %d" % rc)
+        self.engine.submit(public_key.xy, signature.xy, message, witness=w, result=self.result, stream=stream)
+        self.engine.flush(stream=stream)
         return self.result
 
 
@@ -188,7 +222,9 @@ def hash_to_g2_batch(message, out=None):
     """Batched hash_to_g2_with_cons values (hasher.rs:727-740): message [n, msg_len] uint8 cuda tensor -> [n, 24] int64 affine."""
     torch = _require_cuda()
     n, msg_len = message.shape
-    ws = torch.empty(workspace_bytes(n, msg_len), dtype=torch.uint8, device=message.device)
+    wb = ctypes.c_uint64(0)
+    lib().blsw_hash_to_g2_workspace_bytes(n, msg_len, ctypes.byref(wb))
+    ws = torch.empty(wb.value, dtype=torch.uint8, device=message.device)
     if out is None:
         out = torch.empty((n, 24), dtype=torch.int64, device=message.device)
     rc = lib().blsw_hash_to_g2_batch(message.data_ptr(), msg_len, n, out.data_ptr(), ws.data_ptr(), ws.numel(), torch.cuda.current_stream(message.device).cuda_stream)

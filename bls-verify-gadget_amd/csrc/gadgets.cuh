@@ -10,20 +10,22 @@
 namespace blsw {
 
 struct Emitter {
-    uint32_t* base;  // this instance's witness vector (12 u32 per element), 16-byte aligned
-    uint32_t pos;    // element index of the next witness
+    uint32_t* base;        // where element 0 of this instance lives (16-byte aligned); nullptr = value-only mode
+    uint32_t pos;          // element index of the next witness
+    uint64_t stride = 12;  // distance, in u32, between consecutive elements: 12 = dense vector (instance-major);
+                           // 12 * N = element-major staging shared by N instances (coalesced across lanes)
     BLSW_HD void put(const Fp& v) {
         if (base == nullptr) {  // value-only mode (hash_to_g2 batch): no store, cursor still advances
             pos++;
             return;
         }
 #if defined(__HIP_DEVICE_COMPILE__)
-        uint4* d = reinterpret_cast<uint4*>(base + (size_t)pos * 12);
+        uint4* d = reinterpret_cast<uint4*>(base + (size_t)pos * stride);
         d[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
         d[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
         d[2] = make_uint4(v.l[8], v.l[9], v.l[10], v.l[11]);
 #else
-        uint32_t* d = base + (size_t)pos * 12;
+        uint32_t* d = base + (size_t)pos * stride;
         for (int i = 0; i < 12; i++) d[i] = v.l[i];
 #endif
         pos++;

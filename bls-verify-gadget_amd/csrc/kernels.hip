@@ -12,20 +12,21 @@ using namespace blsw;
 namespace {
 
 // ---------------------------------------------------------------- workspace
-// All per-instance scratch is stored element-major: element e of instance i lives at index e*n + i, so that the
+// All per-instance scratch is stored element-major: element e of instance I lives at index e*N + I, so that the
 // 64 lanes of a wave touch one contiguous 3 KiB window per element (48 B per lane).
 struct Workspace {
-    uint32_t* bits;  // [sha_words][n] u32 : SHA witness bitstream, word-major
-    Fp* u;           // [4][n]   hash_to_field output u0.c0,u0.c1,u1.c0,u1.c1
-    Fp* q;           // [12][n]  Q0 (x.c0,x.c1,y.c0,y.c1,z.c0,z.c1), Q1
-    Fp* h;           // [6][n]   H(m) projective
-    Fp* pkaff;       // [2][n]   prepare_g1(pk)
-    Fp* coeff;       // [2][272][n]  line coefficients: 0 = H(m), 1 = sig
+    uint32_t* bits;  // [sha_words][N] u32 : SHA witness bitstream, word-major
+    Fp* u;           // [4][N]   hash_to_field output u0.c0,u0.c1,u1.c0,u1.c1
+    Fp* q;           // [12][N]  Q0 (x.c0,x.c1,y.c0,y.c1,z.c0,z.c1), Q1
+    Fp* h;           // [6][N]   H(m) projective
+    Fp* pkaff;       // [2][N]   prepare_g1(pk)
+    Fp* coeff;       // [2][272][N]  line coefficients: 0 = H(m), 1 = sig
+    Fp* staging;     // [staging_rows][N] field witnesses, element-major (engine mode), or nullptr (direct mode)
     uint64_t sha_words;
     uint64_t total_bytes;
 };
 inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
-Workspace carve(void* base, uint64_t n, const blsw_layout_t& L) {
+Workspace carve(void* base, uint64_t N, const blsw_layout_t& L, bool with_staging) {
     Workspace w;
     w.sha_words = (L.sha_bits + 31) / 32 + 1;
     uint64_t off = 0;
@@ -34,14 +35,42 @@ Workspace carve(void* base, uint64_t n, const blsw_layout_t& L) {
         off = align_up(off + bytes, 256);
         return reinterpret_cast<char*>(base) + o;
     };
-    w.bits = reinterpret_cast<uint32_t*>(take(w.sha_words * n * 4));
-    w.u = reinterpret_cast<Fp*>(take(4 * n * sizeof(Fp)));
-    w.q = reinterpret_cast<Fp*>(take(12 * n * sizeof(Fp)));
-    w.h = reinterpret_cast<Fp*>(take(6 * n * sizeof(Fp)));
-    w.pkaff = reinterpret_cast<Fp*>(take(2 * n * sizeof(Fp)));
-    w.coeff = reinterpret_cast<Fp*>(take(2ull * 272 * n * sizeof(Fp)));
+    w.bits = reinterpret_cast<uint32_t*>(take(w.sha_words * N * 4));
+    w.u = reinterpret_cast<Fp*>(take(4 * N * sizeof(Fp)));
+    w.q = reinterpret_cast<Fp*>(take(12 * N * sizeof(Fp)));
+    w.h = reinterpret_cast<Fp*>(take(6 * N * sizeof(Fp)));
+    w.pkaff = reinterpret_cast<Fp*>(take(2 * N * sizeof(Fp)));
+    w.coeff = reinterpret_cast<Fp*>(take(2ull * 272 * N * sizeof(Fp)));
+    w.staging = with_staging ? reinterpret_cast<Fp*>(take((uint64_t)(L.n_witness - L.sha_bits) * N * sizeof(Fp))) : nullptr;
     w.total_bytes = off;
     return w;
+}
+
+// one submitted batch ("step"): where its inputs are and where its witness tensor / results go
+struct StepDesc {
+    const uint64_t* pk;
+    const uint64_t* sig;
+    const uint8_t* msg;
+    uint64_t* out;        // [n][out_stride] field elements, or nullptr (results only)
+    uint64_t out_stride;  // in field elements
+    int32_t* result;
+};
+// a group of `steps` batches of n instances each, processed by one set of launches (N = steps * n lanes per chain)
+struct Group {
+    uint64_t N;
+    uint32_t n;
+    uint32_t msg_len;
+    const StepDesc* desc;  // device array [steps]
+    blsw_layout_t L;       // offsets in the witness vector
+    blsw_layout_t LS;      // offsets in the staging rows (the vector with the SHA segment cut out)
+    Workspace ws;
+};
+inline blsw_layout_t staging_layout(const blsw_layout_t& L) {
+    blsw_layout_t S = L;
+    uint32_t* f = &S.off_msg;
+    const uint32_t* g = &L.off_msg;
+    for (int k = 0; k < 15; k++) f[k] = g[k] > L.off_expand ? g[k] - L.sha_bits : g[k];
+    return S;
 }
 
 __device__ __forceinline__ Fp ld_fp(const Fp* p) {
@@ -60,55 +89,84 @@ __device__ __forceinline__ void st_fp(Fp* p, const Fp& v) {
     d[2] = make_uint4(v.l[8], v.l[9], v.l[10], v.l[11]);
 }
 __device__ __forceinline__ Fp2 ld_fp2(const Fp* p, uint64_t n) { return {ld_fp(p), ld_fp(p + n)}; }
-__device__ __forceinline__ uint32_t* wit_base(uint64_t* d_witness, uint64_t stride, uint64_t i) {
-    return d_witness ? reinterpret_cast<uint32_t*>(d_witness + i * stride * 6) : nullptr;
+
+// lane -> (step, instance-in-step)
+struct LaneId {
+    uint64_t I;
+    uint32_t s, i;
+};
+__device__ __forceinline__ LaneId lane_id(const Group& g, uint64_t I) {
+    LaneId r;
+    r.I = I;
+    r.s = (uint32_t)(I / g.n);
+    r.i = (uint32_t)(I - (uint64_t)r.s * g.n);
+    return r;
 }
+// witness cursor for a segment: staging row (engine mode), the instance's dense vector (direct mode), or value-only
+__device__ __forceinline__ Emitter emitter(const Group& g, const LaneId& id, uint32_t off_full, uint32_t off_staging) {
+    Emitter e;
+    if (g.ws.staging) {
+        e.base = reinterpret_cast<uint32_t*>(g.ws.staging + id.I);
+        e.pos = off_staging;
+        e.stride = g.N * 12;
+        return e;
+    }
+    const StepDesc& d = g.desc[id.s];
+    e.base = d.out ? reinterpret_cast<uint32_t*>(d.out + (uint64_t)id.i * d.out_stride * 6) : nullptr;
+    e.pos = off_full;
+    e.stride = 12;
+    return e;
+}
+#define EMIT(g, id, field) emitter(g, id, (g).L.field, (g).LS.field)
 
 // ---------------------------------------------------------------- kernels (one instance per lane)
-__global__ __launch_bounds__(64) void k_sha(const uint8_t* __restrict__ msgs, uint32_t msg_len, uint64_t n, blsw_layout_t L, Workspace ws,
-                                            uint64_t* d_witness, uint64_t stride, int want_bits, int write_u) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint8_t* msg = msgs + i * msg_len;
+// SHA-256 witness bits of expand_message (+ the message bits themselves)
+__global__ __launch_bounds__(64) void k_sha(Group g, int want_bits, int write_u) {
+    uint64_t I = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (I >= g.N) return;
+    LaneId id = lane_id(g, I);
+    const uint8_t* msg = g.desc[id.s].msg + (uint64_t)id.i * g.msg_len;
     // UInt8::new_witness_vec(msg): 8 booleans per byte, little-endian
-    Emitter em = {wit_base(d_witness, stride, i), L.off_msg};
-    for (uint32_t k = 0; k < msg_len; k++) {
+    Emitter em = EMIT(g, id, off_msg);
+    for (uint32_t k = 0; k < g.msg_len; k++) {
         uint32_t b = msg[k];
         for (int j = 0; j < 8; j++) em.put_bool((b >> j) & 1);
     }
     BitSink s;
-    s.init(want_bits ? ws.bits + i : nullptr, n);
+    s.init(want_bits ? g.ws.bits + I : nullptr, g.N);
     uint32_t uw[64];
-    expand_message_w(s, msg, msg_len, false, uw);
+    expand_message_w(s, msg, g.msg_len, false, uw);
     if (write_u)
-        for (int j = 0; j < 4; j++) st_fp(ws.u + (uint64_t)j * n + i, hash_to_field_elem(uw + 16 * j));
+        for (int j = 0; j < 4; j++) st_fp(g.ws.u + (uint64_t)j * g.N + I, hash_to_field_elem(uw + 16 * j));
 }
 
 // value-only expand_message + hash_to_field: hands u0, u1 to k_map without waiting for the witness-bit pass
-__global__ __launch_bounds__(64) void k_sha_values(const uint8_t* __restrict__ msgs, uint32_t msg_len, uint64_t n, Workspace ws) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+__global__ __launch_bounds__(64) void k_sha_values(Group g) {
+    uint64_t I = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (I >= g.N) return;
+    LaneId id = lane_id(g, I);
     uint32_t uw[64];
-    expand_message_values(msgs + i * msg_len, msg_len, uw);
-    for (int j = 0; j < 4; j++) st_fp(ws.u + (uint64_t)j * n + i, hash_to_field_elem(uw + 16 * j));
+    expand_message_values(g.desc[id.s].msg + (uint64_t)id.i * g.msg_len, g.msg_len, uw);
+    for (int j = 0; j < 4; j++) st_fp(g.ws.u + (uint64_t)j * g.N + I, hash_to_field_elem(uw + 16 * j));
 }
 
 // bitstream -> Fp elements: element e of the expand segment = bit ? R mod p : 0. One 16-byte chunk per thread
 // per step, consecutive threads write consecutive 16 B: every store instruction covers 1 KiB contiguous per wave.
-__global__ __launch_bounds__(256) void k_sha_expand(const uint32_t* __restrict__ bits, uint64_t n, uint32_t sha_bits, uint32_t off_expand,
-                                                    uint64_t* __restrict__ d_witness, uint64_t stride) {
+// Direct mode: blockIdx.y = instance of the (single) step.
+__global__ __launch_bounds__(256) void k_sha_expand(const uint32_t* __restrict__ bits, uint64_t N, uint64_t first, uint32_t sha_bits,
+                                                    uint32_t off_expand, uint64_t* __restrict__ d_witness, uint64_t stride) {
     constexpr uint32_t R1[12] = BLSW_R1_LIMBS;
     const uint64_t inst = blockIdx.y;
     const uint32_t nchunks = sha_bits * 3;
     uint4* out = reinterpret_cast<uint4*>(d_witness + (inst * stride + off_expand) * 6);
-    const uint32_t* b = bits + inst;
+    const uint32_t* b = bits + first + inst;
     uint32_t q0 = blockIdx.x * (256 * 16) + threadIdx.x;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         uint32_t q = q0 + k * 256;
         if (q < nchunks) {
             uint32_t e = q / 3, c = q - e * 3;
-            uint32_t w = b[(uint64_t)(e >> 5) * n];
+            uint32_t w = b[(uint64_t)(e >> 5) * N];
             uint32_t m = 0u - ((w >> (e & 31)) & 1u);
             uint4 v;
             v.x = (c == 0 ? R1[0] : (c == 1 ? R1[4] : R1[8])) & m;
@@ -119,41 +177,63 @@ __global__ __launch_bounds__(256) void k_sha_expand(const uint32_t* __restrict__
         }
     }
 }
-
-__global__ __launch_bounds__(64) void k_g1(const uint64_t* __restrict__ pk_xy, uint64_t n, blsw_layout_t L, Workspace ws, uint64_t* d_witness,
-                                           uint64_t stride) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const Fp* p = reinterpret_cast<const Fp*>(pk_xy + i * 12);
-    uint32_t* base = wit_base(d_witness, stride, i);
-    G1ChainOut o = chain_g1_alloc({base, L.off_pk_alloc}, {base, L.off_pk_not_zero}, {base, L.off_prep_pk}, ld_fp(p), ld_fp(p + 1));
-    st_fp(ws.pkaff + i, o.ax);
-    st_fp(ws.pkaff + n + i, o.ay);
+// Engine mode: the field witnesses of one step, staged element-major, are moved into place around the SHA segment.
+// 16-byte chunk q of instance i covers elements [0, off_expand) and [off_expand + sha_bits, n_witness).
+__global__ __launch_bounds__(256) void k_place_field(const Fp* __restrict__ staging, uint64_t N, uint64_t first, uint32_t off_expand, uint32_t sha_bits,
+                                                     uint32_t staging_rows, uint64_t* __restrict__ d_witness, uint64_t stride) {
+    const uint64_t inst = blockIdx.y;
+    const uint32_t nchunks = staging_rows * 3;
+    const uint4* src = reinterpret_cast<const uint4*>(staging + first + inst);
+    uint4* out = reinterpret_cast<uint4*>(d_witness + inst * stride * 6);
+    uint32_t q0 = blockIdx.x * (256 * 8) + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        uint32_t q = q0 + k * 256;
+        if (q < nchunks) {
+            uint32_t e = q / 3, c = q - e * 3;
+            uint4 v = src[(uint64_t)e * N * 3 + c];
+            uint32_t dst_e = e < off_expand ? e : e + sha_bits;
+            out[(uint64_t)dst_e * 3 + c] = v;
+        }
+    }
 }
 
-__global__ __launch_bounds__(64) void k_g2_alloc(const uint64_t* __restrict__ sig_xy, uint64_t n, blsw_layout_t L, uint64_t* d_witness, uint64_t stride) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const Fp* p = reinterpret_cast<const Fp*>(sig_xy + i * 24);
+__global__ __launch_bounds__(64) void k_g1(Group g) {
+    uint64_t I = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (I >= g.N) return;
+    LaneId id = lane_id(g, I);
+    const Fp* p = reinterpret_cast<const Fp*>(g.desc[id.s].pk + (uint64_t)id.i * 12);
+    G1ChainOut o = chain_g1_alloc(EMIT(g, id, off_pk_alloc), EMIT(g, id, off_pk_not_zero), EMIT(g, id, off_prep_pk), ld_fp(p), ld_fp(p + 1));
+    st_fp(g.ws.pkaff + I, o.ax);
+    st_fp(g.ws.pkaff + g.N + I, o.ay);
+}
+
+__global__ __launch_bounds__(64) void k_g2_alloc(Group g) {
+    uint64_t I = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (I >= g.N) return;
+    LaneId id = lane_id(g, I);
+    const Fp* p = reinterpret_cast<const Fp*>(g.desc[id.s].sig + (uint64_t)id.i * 24);
     Fp2 sx = {ld_fp(p), ld_fp(p + 1)}, sy = {ld_fp(p + 2), ld_fp(p + 3)};
-    chain_g2_alloc({wit_base(d_witness, stride, i), L.off_sig_alloc}, sx, sy);
+    chain_g2_alloc(EMIT(g, id, off_sig_alloc), sx, sy);
 }
 
-// lanes [0, n): u0 -> Q0 ; lanes [n, 2n): u1 -> Q1
-__global__ __launch_bounds__(64) void k_map(uint64_t n, blsw_layout_t L, Workspace ws, uint64_t* d_witness, uint64_t stride) {
+// lanes [0, N): u0 -> Q0 ; lanes [N, 2N): u1 -> Q1
+__global__ __launch_bounds__(64) void k_map(Group g) {
     uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= 2 * n) return;
-    uint32_t which = t >= n;
-    uint64_t i = which ? t - n : t;
-    Fp2 u = ld_fp2(ws.u + (uint64_t)(2 * which) * n + i, n);
-    Proj<OpsFp2> q = chain_map_to_curve({wit_base(d_witness, stride, i), which ? L.off_map1 : L.off_map0}, u);
-    Fp* o = ws.q + (uint64_t)(6 * which) * n + i;
+    if (t >= 2 * g.N) return;
+    uint32_t which = t >= g.N;
+    uint64_t I = which ? t - g.N : t;
+    LaneId id = lane_id(g, I);
+    const uint64_t N = g.N;
+    Fp2 u = ld_fp2(g.ws.u + (uint64_t)(2 * which) * N + I, N);
+    Proj<OpsFp2> q = chain_map_to_curve(which ? EMIT(g, id, off_map1) : EMIT(g, id, off_map0), u);
+    Fp* o = g.ws.q + (uint64_t)(6 * which) * N + I;
     st_fp(o, q.x.c0);
-    st_fp(o + n, q.x.c1);
-    st_fp(o + 2 * n, q.y.c0);
-    st_fp(o + 3 * n, q.y.c1);
-    st_fp(o + 4 * n, q.z.c0);
-    st_fp(o + 5 * n, q.z.c1);
+    st_fp(o + N, q.x.c1);
+    st_fp(o + 2 * N, q.y.c0);
+    st_fp(o + 3 * N, q.y.c1);
+    st_fp(o + 4 * N, q.z.c0);
+    st_fp(o + 5 * N, q.z.c1);
 }
 
 __device__ __forceinline__ Proj<OpsFp2> ld_proj2(const Fp* p, uint64_t n) {
@@ -163,61 +243,63 @@ __device__ __forceinline__ Proj<OpsFp2> ld_proj2(const Fp* p, uint64_t n) {
     r.z = ld_fp2(p + 4 * n, n);
     return r;
 }
-__global__ __launch_bounds__(64) void k_cofactor(uint64_t n, blsw_layout_t L, Workspace ws, uint64_t* d_witness, uint64_t stride) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    Proj<OpsFp2> q0 = ld_proj2(ws.q + i, n), q1 = ld_proj2(ws.q + 6 * n + i, n);
-    uint32_t* base = wit_base(d_witness, stride, i);
-    Proj<OpsFp2> h = chain_cofactor({base, L.off_add}, {base, L.off_cofactor}, q0, q1);
-    Fp* o = ws.h + i;
+__global__ __launch_bounds__(64) void k_cofactor(Group g) {
+    uint64_t I = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (I >= g.N) return;
+    LaneId id = lane_id(g, I);
+    const uint64_t N = g.N;
+    Proj<OpsFp2> q0 = ld_proj2(g.ws.q + I, N), q1 = ld_proj2(g.ws.q + 6 * N + I, N);
+    Proj<OpsFp2> h = chain_cofactor(EMIT(g, id, off_add), EMIT(g, id, off_cofactor), q0, q1);
+    Fp* o = g.ws.h + I;
     st_fp(o, h.x.c0);
-    st_fp(o + n, h.x.c1);
-    st_fp(o + 2 * n, h.y.c0);
-    st_fp(o + 3 * n, h.y.c1);
-    st_fp(o + 4 * n, h.z.c0);
-    st_fp(o + 5 * n, h.z.c1);
+    st_fp(o + N, h.x.c1);
+    st_fp(o + 2 * N, h.y.c0);
+    st_fp(o + 3 * N, h.y.c1);
+    st_fp(o + 4 * N, h.z.c0);
+    st_fp(o + 5 * N, h.z.c1);
 }
 
-// line coefficients, element-major: coefficient idx of instance i at p[idx * n]
+// line coefficients, element-major: coefficient idx of instance I at p[idx * N]
 struct CoeffStrided {
     Fp* p;
     uint64_t n;
     __device__ __forceinline__ void st(uint32_t idx, const Fp& v) const { st_fp(p + (uint64_t)idx * n, v); }
     __device__ __forceinline__ Fp ld(uint32_t idx) const { return ld_fp(p + (uint64_t)idx * n); }
 };
-// which = 0: prepare_g2(H(m)) ; which = 1: prepare_g2(sig). Lanes [0, n) take `which_first`, [n, 2n) the next one.
-__global__ __launch_bounds__(64) void k_prepare(const uint64_t* __restrict__ sig_xy, uint64_t n, blsw_layout_t L, Workspace ws, uint64_t* d_witness,
-                                                uint64_t stride, int which_first, int which_count) {
-    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (uint64_t)which_count * n) return;
-    uint32_t which = which_first + (uint32_t)(t / n);
-    uint64_t i = t % n;
+// which = 0: prepare_g2(H(m)) ; which = 1: prepare_g2(sig)
+__global__ __launch_bounds__(64) void k_prepare(Group g, int which) {
+    uint64_t I = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (I >= g.N) return;
+    LaneId id = lane_id(g, I);
+    const uint64_t N = g.N;
     Proj<OpsFp2> q;
     if (which == 0) {
-        q = ld_proj2(ws.h + i, n);
+        q = ld_proj2(g.ws.h + I, N);
     } else {
-        const Fp* p = reinterpret_cast<const Fp*>(sig_xy + i * 24);
+        const Fp* p = reinterpret_cast<const Fp*>(g.desc[id.s].sig + (uint64_t)id.i * 24);
         Fp2 sx = {ld_fp(p), ld_fp(p + 1)}, sy = {ld_fp(p + 2), ld_fp(p + 3)};
         bool inf = fp2_is_zero(sx) && fp2_is_zero(sy);
         q.x = inf ? fp2_zero() : sx;
         q.y = inf ? fp2_one() : sy;
         q.z = inf ? fp2_zero() : fp2_one();
     }
-    CoeffStrided out = {ws.coeff + (uint64_t)which * 272 * n + i, n};
-    chain_prepare_g2({wit_base(d_witness, stride, i), which == 0 ? L.off_prep_h : L.off_prep_sig}, q, out);
+    CoeffStrided out = {g.ws.coeff + (uint64_t)which * 272 * N + I, N};
+    chain_prepare_g2(which == 0 ? EMIT(g, id, off_prep_h) : EMIT(g, id, off_prep_sig), q, out);
 }
 
 // Miller loop + final exponentiation + is_one
-__global__ __launch_bounds__(64) void k_pairing(uint64_t n, blsw_layout_t L, Workspace ws, uint64_t* d_witness, uint64_t stride, int32_t* d_result) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t* base = wit_base(d_witness, stride, i);
-    Fp pkx = ld_fp(ws.pkaff + i), pky = ld_fp(ws.pkaff + n + i);
-    CoeffStrided ch = {ws.coeff + i, n};
-    CoeffStrided cs = {ws.coeff + 272ull * n + i, n};
-    Fp12 f = chain_miller({base, L.off_miller}, pkx, pky, cs, ch);
-    bool res = chain_final_exp_is_one({base, L.off_final_exp}, {base, L.off_is_one}, f);
-    if (d_result) d_result[i] = res ? 1 : 0;
+__global__ __launch_bounds__(64) void k_pairing(Group g) {
+    uint64_t I = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (I >= g.N) return;
+    LaneId id = lane_id(g, I);
+    const uint64_t N = g.N;
+    Fp pkx = ld_fp(g.ws.pkaff + I), pky = ld_fp(g.ws.pkaff + N + I);
+    CoeffStrided ch = {g.ws.coeff + I, N};
+    CoeffStrided cs = {g.ws.coeff + 272ull * N + I, N};
+    Fp12 f = chain_miller(EMIT(g, id, off_miller), pkx, pky, cs, ch);
+    bool res = chain_final_exp_is_one(EMIT(g, id, off_final_exp), EMIT(g, id, off_is_one), f);
+    int32_t* r = g.desc[id.s].result;
+    if (r) r[id.i] = res ? 1 : 0;
 }
 
 // H(m) projective -> affine (hash_to_g2 batch output)
@@ -272,55 +354,109 @@ inline int hip_ok(hipError_t e, const char* what) {
 
 }  // namespace
 
-// Execution context: auxiliary streams and events so that the independent chains of one batch overlap.
-//   main : sha_values -> map -> cofactor -> prepare(H) ............ -> pairing -> join
+// Execution engine. Batches ("steps") are SUBMITTED with their input/output pointers and processed in GROUPS of up
+// to max_steps batches by one set of launches (N = steps * n lanes per chain kernel), which is what fills the chip:
+// one batch of 1024 instances is only 16 waves per chain. Per group:
+//   main : sha_values -> map -> cofactor -> prepare(H) ............ -> pairing
 //   aux0 : g1_alloc, g2_alloc                                        (needs only pk / sig)
 //   aux1 : prepare(sig)                                              (needs only sig)
-//   aux2 : sha witness bits -> sha_expand (the HBM-bound stream of ~31 MB / instance)
-struct blsw_ctx {
-    hipStream_t aux[3];
-    hipEvent_t ev_start, ev_aux[3];
-    hipEvent_t ev_exp0, ev_exp1;  // around k_sha_expand, for the live roofline measurement
-    int have_expand_timing;
+//   aux2 : sha witness bits
+// Field witnesses go to an element-major staging area (coalesced stores); then, per step and in submission order,
+// the `place` stream writes the step's complete witness tensor: k_sha_expand (bit -> Fp, ~31 MB per instance, the
+// HBM-bound kernel) and k_place_field (staging -> its place around the SHA segment). Two group buffers ping-pong,
+// so the next group's chains overlap the previous group's placement.
+struct GroupBuf {
+    void* base;
+    Workspace ws;
+    StepDesc* h_desc;  // pinned host
+    StepDesc* d_desc;
+    hipStream_t st[4];  // main, aux0..2
+    hipEvent_t ev_start, ev_aux[3], ev_chains, ev_done;
+    bool used;
 };
+struct blsw_engine {
+    uint64_t n;
+    uint32_t msg_len, max_steps;
+    blsw_layout_t L, LS;
+    GroupBuf buf[2];
+    int cur;
+    uint32_t pending;
+    hipStream_t place;
+    hipEvent_t ev_exp0, ev_exp1, ev_in;
+    int have_expand_timing;
+    bool staged;  // false: direct mode (max_steps == 1, no staging; witnesses written in place by the chains)
+};
+
+static int launch_group(blsw_engine* e, hipStream_t user_stream) {
+    GroupBuf& b = e->buf[e->cur];
+    const uint32_t steps = e->pending;
+    if (steps == 0) return BLSW_OK;
+    Group g;
+    g.N = (uint64_t)steps * e->n;
+    g.n = (uint32_t)e->n;
+    g.msg_len = e->msg_len;
+    g.desc = b.d_desc;
+    g.L = e->L;
+    g.LS = e->LS;
+    g.ws = carve(b.base, g.N, e->L, e->staged);
+    const unsigned g1 = (unsigned)((g.N + 63) / 64), g2 = (unsigned)((2 * g.N + 63) / 64);
+    hipStream_t st = b.st[0];
+    // inputs are ready once the submitting stream reaches this point
+    hipEventRecord(e->ev_in, user_stream);
+    hipStreamWaitEvent(st, e->ev_in, 0);
+    hipMemcpyAsync(b.d_desc, b.h_desc, sizeof(StepDesc) * steps, hipMemcpyHostToDevice, st);
+    hipEventRecord(b.ev_start, st);
+    for (int i = 0; i < 3; i++) hipStreamWaitEvent(b.st[1 + i], b.ev_start, 0);
+    bool any_out = false;
+    for (uint32_t s = 0; s < steps; s++) any_out = any_out || b.h_desc[s].out != nullptr;
+    // aux0: group allocations
+    hipLaunchKernelGGL(k_g1, dim3(g1), dim3(64), 0, b.st[1], g);
+    hipLaunchKernelGGL(k_g2_alloc, dim3(g1), dim3(64), 0, b.st[1], g);
+    hipEventRecord(b.ev_aux[0], b.st[1]);
+    // aux1: prepare_g2(sig)
+    hipLaunchKernelGGL(k_prepare, dim3(g1), dim3(64), 0, b.st[2], g, 1);
+    hipEventRecord(b.ev_aux[1], b.st[2]);
+    // aux2: SHA-256 witness bits
+    if (any_out) hipLaunchKernelGGL(k_sha, dim3(g1), dim3(64), 0, b.st[3], g, 1, 0);
+    hipEventRecord(b.ev_aux[2], b.st[3]);
+    // main: the hash-to-G2 critical path, then the pairing
+    hipLaunchKernelGGL(k_sha_values, dim3(g1), dim3(64), 0, st, g);
+    hipLaunchKernelGGL(k_map, dim3(g2), dim3(64), 0, st, g);
+    hipLaunchKernelGGL(k_cofactor, dim3(g1), dim3(64), 0, st, g);
+    hipLaunchKernelGGL(k_prepare, dim3(g1), dim3(64), 0, st, g, 0);
+    hipStreamWaitEvent(st, b.ev_aux[0], 0);
+    hipStreamWaitEvent(st, b.ev_aux[1], 0);
+    hipLaunchKernelGGL(k_pairing, dim3(g1), dim3(64), 0, st, g);
+    hipStreamWaitEvent(st, b.ev_aux[2], 0);
+    hipEventRecord(b.ev_chains, st);
+    // placement, per step, in submission order
+    hipStreamWaitEvent(e->place, b.ev_chains, 0);
+    for (uint32_t s = 0; s < steps && any_out; s++) {
+        const StepDesc& d = b.h_desc[s];
+        if (!d.out) continue;
+        dim3 grid((e->L.sha_bits * 3 + 4095) / 4096, (unsigned)e->n);
+        hipEventRecord(e->ev_exp0, e->place);
+        hipLaunchKernelGGL(k_sha_expand, grid, dim3(256), 0, e->place, g.ws.bits, g.N, (uint64_t)s * e->n, e->L.sha_bits, e->L.off_expand, d.out,
+                           d.out_stride);
+        hipEventRecord(e->ev_exp1, e->place);
+        e->have_expand_timing = 1;
+        if (e->staged) {
+            const uint32_t rows = e->L.n_witness - e->L.sha_bits;
+            dim3 grid2((rows * 3 + 2047) / 2048, (unsigned)e->n);
+            hipLaunchKernelGGL(k_place_field, grid2, dim3(256), 0, e->place, g.ws.staging, g.N, (uint64_t)s * e->n, e->L.off_expand, e->L.sha_bits, rows,
+                               d.out, d.out_stride);
+        }
+    }
+    hipEventRecord(b.ev_done, e->place);
+    b.used = true;
+    e->pending = 0;
+    e->cur ^= 1;
+    return hip_ok(hipGetLastError(), "launch");
+}
 
 extern "C" {
 
-int blsw_version(void) { return 2; }
-
-int blsw_ctx_create(blsw_ctx_t** out) {
-    if (!out) return BLSW_ERR_ARG;
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return BLSW_ERR_NO_DEVICE;
-    blsw_ctx* c = new blsw_ctx();
-    for (int i = 0; i < 3; i++) {
-        if (hip_ok(hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking), "stream create")) return BLSW_ERR_HIP;
-        if (hip_ok(hipEventCreateWithFlags(&c->ev_aux[i], hipEventDisableTiming), "event create")) return BLSW_ERR_HIP;
-    }
-    if (hip_ok(hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming), "event create")) return BLSW_ERR_HIP;
-    if (hip_ok(hipEventCreate(&c->ev_exp0), "event create") || hip_ok(hipEventCreate(&c->ev_exp1), "event create")) return BLSW_ERR_HIP;
-    c->have_expand_timing = 0;
-    *out = c;
-    return BLSW_OK;
-}
-int blsw_ctx_destroy(blsw_ctx_t* c) {
-    if (!c) return BLSW_ERR_ARG;
-    for (int i = 0; i < 3; i++) {
-        hipStreamDestroy(c->aux[i]);
-        hipEventDestroy(c->ev_aux[i]);
-    }
-    hipEventDestroy(c->ev_start);
-    hipEventDestroy(c->ev_exp0);
-    hipEventDestroy(c->ev_exp1);
-    delete c;
-    return BLSW_OK;
-}
-// duration of the last k_sha_expand launch issued through this context (blocks until it has finished)
-int blsw_ctx_last_expand_ms(blsw_ctx_t* c, float* ms) {
-    if (!c || !ms || !c->have_expand_timing) return BLSW_ERR_ARG;
-    if (hip_ok(hipEventSynchronize(c->ev_exp1), "event sync")) return BLSW_ERR_HIP;
-    return hip_ok(hipEventElapsedTime(ms, c->ev_exp0, c->ev_exp1), "event elapsed");
-}
+int blsw_version(void) { return 3; }
 
 int blsw_layout(uint32_t msg_len, blsw_layout_t* out) {
     if (!out || msg_len > 65535) return BLSW_ERR_ARG;
@@ -328,71 +464,145 @@ int blsw_layout(uint32_t msg_len, blsw_layout_t* out) {
     return BLSW_OK;
 }
 
-int blsw_workspace_bytes(uint64_t n, uint32_t msg_len, uint64_t* bytes) {
-    if (!bytes || n == 0) return BLSW_ERR_ARG;
+int blsw_engine_workspace_bytes(uint64_t n, uint32_t msg_len, uint32_t max_steps, uint64_t* bytes) {
+    if (!bytes || n == 0 || max_steps == 0) return BLSW_ERR_ARG;
     blsw_layout_t L;
     make_layout(msg_len, &L);
-    Workspace w = carve(nullptr, n, L);
-    *bytes = w.total_bytes;
+    Workspace w = carve(nullptr, n * max_steps, L, max_steps > 1);
+    *bytes = 2 * align_up(w.total_bytes, 4096);
     return BLSW_OK;
 }
 
-int blsw_witness_batch(blsw_ctx_t* c, const uint64_t* d_pk_xy, const uint64_t* d_sig_xy, const uint8_t* d_msg, uint32_t msg_len, uint64_t n,
-                       uint64_t* d_witness, uint64_t witness_stride, int32_t* d_result, void* d_workspace, uint64_t workspace_bytes, void* stream_) {
-    if (!c || !d_pk_xy || !d_sig_xy || (!d_msg && msg_len) || n == 0 || !d_workspace) return BLSW_ERR_ARG;
-    blsw_layout_t L;
-    make_layout(msg_len, &L);
-    if (d_witness && witness_stride < L.n_witness) return BLSW_ERR_ARG;
-    Workspace ws = carve(d_workspace, n, L);
-    if (ws.total_bytes > workspace_bytes) return BLSW_ERR_WORKSPACE;
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream_);
-    const unsigned g1 = (unsigned)((n + 63) / 64), g2 = (unsigned)((2 * n + 63) / 64);
-    // fork
-    hipEventRecord(c->ev_start, st);
-    for (int i = 0; i < 3; i++) hipStreamWaitEvent(c->aux[i], c->ev_start, 0);
-    // aux0: group allocations
-    hipLaunchKernelGGL(k_g1, dim3(g1), dim3(64), 0, c->aux[0], d_pk_xy, n, L, ws, d_witness, witness_stride);
-    hipLaunchKernelGGL(k_g2_alloc, dim3(g1), dim3(64), 0, c->aux[0], d_sig_xy, n, L, d_witness, witness_stride);
-    hipEventRecord(c->ev_aux[0], c->aux[0]);
-    // aux1: prepare_g2(sig)
-    hipLaunchKernelGGL(k_prepare, dim3(g1), dim3(64), 0, c->aux[1], d_sig_xy, n, L, ws, d_witness, witness_stride, 1, 1);
-    hipEventRecord(c->ev_aux[1], c->aux[1]);
-    // aux2: SHA-256 witness bits and their expansion (only when witnesses are requested)
-    if (d_witness) {
-        hipLaunchKernelGGL(k_sha, dim3(g1), dim3(64), 0, c->aux[2], d_msg, msg_len, n, L, ws, d_witness, witness_stride, 1, 0);
-        dim3 grid((L.sha_bits * 3 + 4095) / 4096, (unsigned)n);
-        hipEventRecord(c->ev_exp0, c->aux[2]);
-        hipLaunchKernelGGL(k_sha_expand, grid, dim3(256), 0, c->aux[2], ws.bits, n, L.sha_bits, L.off_expand, d_witness, witness_stride);
-        hipEventRecord(c->ev_exp1, c->aux[2]);
-        c->have_expand_timing = 1;
+int blsw_engine_create(blsw_engine_t** out, uint64_t n, uint32_t msg_len, uint32_t max_steps, void* d_workspace, uint64_t workspace_bytes) {
+    if (!out || n == 0 || max_steps == 0 || !d_workspace) return BLSW_ERR_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return BLSW_ERR_NO_DEVICE;
+    uint64_t need = 0;
+    blsw_engine_workspace_bytes(n, msg_len, max_steps, &need);
+    if (workspace_bytes < need) return BLSW_ERR_WORKSPACE;
+    blsw_engine* e = new blsw_engine();
+    e->n = n;
+    e->msg_len = msg_len;
+    e->max_steps = max_steps;
+    e->staged = max_steps > 1;
+    make_layout(msg_len, &e->L);
+    e->LS = staging_layout(e->L);
+    e->cur = 0;
+    e->pending = 0;
+    e->have_expand_timing = 0;
+    for (int k = 0; k < 2; k++) {
+        GroupBuf& b = e->buf[k];
+        b.base = reinterpret_cast<char*>(d_workspace) + (uint64_t)k * (need / 2);
+        b.used = false;
+        if (hip_ok(hipHostMalloc(reinterpret_cast<void**>(&b.h_desc), sizeof(StepDesc) * max_steps, hipHostMallocDefault), "host alloc")) return BLSW_ERR_HIP;
+        if (hip_ok(hipMalloc(reinterpret_cast<void**>(&b.d_desc), sizeof(StepDesc) * max_steps), "desc alloc")) return BLSW_ERR_HIP;
+        for (int i = 0; i < 4; i++)
+            if (hip_ok(hipStreamCreateWithFlags(&b.st[i], hipStreamNonBlocking), "stream create")) return BLSW_ERR_HIP;
+        for (int i = 0; i < 3; i++) hipEventCreateWithFlags(&b.ev_aux[i], hipEventDisableTiming);
+        hipEventCreateWithFlags(&b.ev_start, hipEventDisableTiming);
+        hipEventCreateWithFlags(&b.ev_chains, hipEventDisableTiming);
+        hipEventCreateWithFlags(&b.ev_done, hipEventDisableTiming);
     }
-    hipEventRecord(c->ev_aux[2], c->aux[2]);
-    // main: the hash-to-G2 critical path
-    hipLaunchKernelGGL(k_sha_values, dim3(g1), dim3(64), 0, st, d_msg, msg_len, n, ws);
-    hipLaunchKernelGGL(k_map, dim3(g2), dim3(64), 0, st, n, L, ws, d_witness, witness_stride);
-    hipLaunchKernelGGL(k_cofactor, dim3(g1), dim3(64), 0, st, n, L, ws, d_witness, witness_stride);
-    hipLaunchKernelGGL(k_prepare, dim3(g1), dim3(64), 0, st, d_sig_xy, n, L, ws, d_witness, witness_stride, 0, 1);
-    hipStreamWaitEvent(st, c->ev_aux[0], 0);
-    hipStreamWaitEvent(st, c->ev_aux[1], 0);
-    hipLaunchKernelGGL(k_pairing, dim3(g1), dim3(64), 0, st, n, L, ws, d_witness, witness_stride, d_result);
-    hipStreamWaitEvent(st, c->ev_aux[2], 0);  // join
-    return hip_ok(hipGetLastError(), "launch");
+    if (hip_ok(hipStreamCreateWithFlags(&e->place, hipStreamNonBlocking), "stream create")) return BLSW_ERR_HIP;
+    hipEventCreate(&e->ev_exp0);
+    hipEventCreate(&e->ev_exp1);
+    hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming);
+    *out = e;
+    return hip_ok(hipGetLastError(), "engine create");
+}
+
+int blsw_engine_destroy(blsw_engine_t* e) {
+    if (!e) return BLSW_ERR_ARG;
+    hipDeviceSynchronize();
+    for (int k = 0; k < 2; k++) {
+        GroupBuf& b = e->buf[k];
+        hipHostFree(b.h_desc);
+        hipFree(b.d_desc);
+        for (int i = 0; i < 4; i++) hipStreamDestroy(b.st[i]);
+        for (int i = 0; i < 3; i++) hipEventDestroy(b.ev_aux[i]);
+        hipEventDestroy(b.ev_start);
+        hipEventDestroy(b.ev_chains);
+        hipEventDestroy(b.ev_done);
+    }
+    hipStreamDestroy(e->place);
+    hipEventDestroy(e->ev_exp0);
+    hipEventDestroy(e->ev_exp1);
+    hipEventDestroy(e->ev_in);
+    delete e;
+    return BLSW_OK;
+}
+
+int blsw_engine_submit(blsw_engine_t* e, const uint64_t* d_pk_xy, const uint64_t* d_sig_xy, const uint8_t* d_msg, uint64_t* d_witness,
+                       uint64_t witness_stride, int32_t* d_result, void* stream_) {
+    if (!e || !d_pk_xy || !d_sig_xy || (!d_msg && e->msg_len)) return BLSW_ERR_ARG;
+    if (d_witness && witness_stride < e->L.n_witness) return BLSW_ERR_ARG;
+    GroupBuf& b = e->buf[e->cur];
+    if (e->pending == 0 && b.used) {
+        // the buffer's previous group must have been fully placed before its staging is overwritten
+        if (hip_ok(hipEventSynchronize(b.ev_done), "event sync")) return BLSW_ERR_HIP;
+        b.used = false;
+    }
+    StepDesc& d = b.h_desc[e->pending];
+    d.pk = d_pk_xy;
+    d.sig = d_sig_xy;
+    d.msg = d_msg;
+    d.out = d_witness;
+    d.out_stride = witness_stride;
+    d.result = d_result;
+    e->pending++;
+    if (e->pending == e->max_steps) return launch_group(e, reinterpret_cast<hipStream_t>(stream_));
+    return BLSW_OK;
+}
+
+// launches whatever is pending and makes `stream` wait for every group issued so far
+int blsw_engine_flush(blsw_engine_t* e, void* stream_) {
+    if (!e) return BLSW_ERR_ARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream_);
+    int rc = launch_group(e, st);
+    if (rc) return rc;
+    for (int k = 0; k < 2; k++)
+        if (e->buf[k].used) hipStreamWaitEvent(st, e->buf[k].ev_done, 0);
+    return hip_ok(hipGetLastError(), "flush");
+}
+
+// duration (ms) of the last bit->Fp expansion launch (HIP events on the stream it ran on); blocks until it finished
+int blsw_engine_last_expand_ms(blsw_engine_t* e, float* ms) {
+    if (!e || !ms || !e->have_expand_timing) return BLSW_ERR_ARG;
+    if (hip_ok(hipEventSynchronize(e->ev_exp1), "event sync")) return BLSW_ERR_HIP;
+    return hip_ok(hipEventElapsedTime(ms, e->ev_exp0, e->ev_exp1), "event elapsed");
 }
 
 int blsw_hash_to_g2_batch(const uint8_t* d_msg, uint32_t msg_len, uint64_t n, uint64_t* d_out_affine, void* d_workspace, uint64_t workspace_bytes,
                           void* stream_) {
     if ((!d_msg && msg_len) || n == 0 || !d_workspace || !d_out_affine) return BLSW_ERR_ARG;
+    Group g;
+    make_layout(msg_len, &g.L);
+    g.LS = staging_layout(g.L);
+    // the step descriptor lives at the head of the workspace
+    StepDesc* d_desc = reinterpret_cast<StepDesc*>(d_workspace);
+    g.ws = carve(reinterpret_cast<char*>(d_workspace) + 256, n, g.L, false);
+    if (g.ws.total_bytes + 256 > workspace_bytes) return BLSW_ERR_WORKSPACE;
+    g.N = n;
+    g.n = (uint32_t)n;
+    g.msg_len = msg_len;
+    g.desc = d_desc;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream_);
+    StepDesc h = {nullptr, nullptr, d_msg, nullptr, 0, nullptr};
+    hipMemcpyAsync(d_desc, &h, sizeof(h), hipMemcpyHostToDevice, st);
+    hipStreamSynchronize(st);  // `h` is a stack object
+    const unsigned g1 = (unsigned)((n + 63) / 64), g2 = (unsigned)((2 * n + 63) / 64);
+    hipLaunchKernelGGL(k_sha_values, dim3(g1), dim3(64), 0, st, g);
+    hipLaunchKernelGGL(k_map, dim3(g2), dim3(64), 0, st, g);
+    hipLaunchKernelGGL(k_cofactor, dim3(g1), dim3(64), 0, st, g);
+    hipLaunchKernelGGL(k_h_to_affine, dim3(g1), dim3(64), 0, st, n, g.ws, d_out_affine);
+    return hip_ok(hipGetLastError(), "launch");
+}
+int blsw_hash_to_g2_workspace_bytes(uint64_t n, uint32_t msg_len, uint64_t* bytes) {
+    if (!bytes || n == 0) return BLSW_ERR_ARG;
     blsw_layout_t L;
     make_layout(msg_len, &L);
-    Workspace ws = carve(d_workspace, n, L);
-    if (ws.total_bytes > workspace_bytes) return BLSW_ERR_WORKSPACE;
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream_);
-    const unsigned g1 = (unsigned)((n + 63) / 64), g2 = (unsigned)((2 * n + 63) / 64);
-    hipLaunchKernelGGL(k_sha_values, dim3(g1), dim3(64), 0, st, d_msg, msg_len, n, ws);
-    hipLaunchKernelGGL(k_map, dim3(g2), dim3(64), 0, st, n, L, ws, (uint64_t*)nullptr, (uint64_t)0);
-    hipLaunchKernelGGL(k_cofactor, dim3(g1), dim3(64), 0, st, n, L, ws, (uint64_t*)nullptr, (uint64_t)0);
-    hipLaunchKernelGGL(k_h_to_affine, dim3(g1), dim3(64), 0, st, n, ws, d_out_affine);
-    return hip_ok(hipGetLastError(), "launch");
+    *bytes = carve(nullptr, n, L, false).total_bytes + 256;
+    return BLSW_OK;
 }
 
 // which = 0: v_mad_u64_u32 issue rate (result in multiply-adds/s); which = 1: fp_mul rate (Fp products/s). Synchronous.

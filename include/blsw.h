@@ -47,29 +47,35 @@ typedef struct {
 /* layout(circuit shape) — replaces reading cs.num_witness_variables() after synthesis (constraints.rs:369-373). Host only. */
 int blsw_layout(uint32_t msg_len, blsw_layout_t* out);
 
-/* bytes of device workspace blsw_witness_batch needs for n instances */
-int blsw_workspace_bytes(uint64_t n, uint32_t msg_len, uint64_t* bytes);
+/* Execution engine. Batches of n instances are SUBMITTED with their input / output pointers and processed in groups
+ * of up to max_steps batches by one set of kernel launches (one batch of 1024 instances is only 16 wavefronts per
+ * chain; a group of 32 batches fills the 1024 SIMDs of an MI355X). max_steps == 1 is the direct mode: the chains
+ * write every witness in place. With max_steps > 1 field witnesses are staged element-major (coalesced stores) and
+ * each batch's witness tensor is then written, in submission order, by the streaming placement kernels.
+ * The caller owns the device workspace (blsw_engine_workspace_bytes). One engine per device; not thread-safe. */
+typedef struct blsw_engine blsw_engine_t;
+int blsw_engine_workspace_bytes(uint64_t n, uint32_t msg_len, uint32_t max_steps, uint64_t* bytes);
+int blsw_engine_create(blsw_engine_t** out, uint64_t n, uint32_t msg_len, uint32_t max_steps, void* d_workspace, uint64_t workspace_bytes);
+int blsw_engine_destroy(blsw_engine_t* e);
 
-/* Execution context: auxiliary HIP streams/events of the current device, so that the independent chains of one batch
- * (G1/G2 allocation, prepare_g2(sig), SHA witness expansion, hash-to-G2 critical path) overlap. One context per
- * concurrently in-flight batch. */
-typedef struct blsw_ctx blsw_ctx_t;
-int blsw_ctx_create(blsw_ctx_t** out);
-int blsw_ctx_destroy(blsw_ctx_t* ctx);
-/* duration (ms) of the last bit->Fp expansion kernel launched through ctx (HIP events on the stream it ran on) */
-int blsw_ctx_last_expand_ms(blsw_ctx_t* ctx, float* ms);
-
-/* Fills the witness vectors of n independent (pk, msg, sig) instances.
+/* Submits one batch of n independent (pk, msg, sig) instances: the witness vectors of the circuit of
+ * src/constraints.rs:335-366 are written to d_witness and the gadget's output Boolean (constraints.rs:127) to d_result.
  *   d_pk_xy   [n][12] u64  affine G1 (x, y) Montgomery; (0,0) = point at infinity      (PublicKeyVar, constraints.rs:214-232)
  *   d_sig_xy  [n][24] u64  affine G2 (x.c0, x.c1, y.c0, y.c1); all zero = infinity     (SignatureVar, constraints.rs:234-249)
  *   d_msg     [n][msg_len] bytes                                                        (UInt8::new_witness_vec, constraints.rs:341)
  *   d_witness [n][witness_stride] field elements (48 B each), witness_stride >= layout.n_witness; may be NULL (results only)
- *   d_result  [n] int32: value of the gadget's output Boolean (constraints.rs:127)
- * Asynchronous on `stream` (hipStream_t, may be NULL). */
-int blsw_witness_batch(blsw_ctx_t* ctx, const uint64_t* d_pk_xy, const uint64_t* d_sig_xy, const uint8_t* d_msg, uint32_t msg_len, uint64_t n, uint64_t* d_witness,
-                       uint64_t witness_stride, int32_t* d_result, void* d_workspace, uint64_t workspace_bytes, void* stream);
+ *   d_result  [n] int32, may be NULL
+ * Device work is issued when max_steps batches are pending or at blsw_engine_flush; `stream` (hipStream_t, may be NULL)
+ * is the stream on which the inputs become valid. Buffers must stay alive until the flush has completed. */
+int blsw_engine_submit(blsw_engine_t* e, const uint64_t* d_pk_xy, const uint64_t* d_sig_xy, const uint8_t* d_msg, uint64_t* d_witness,
+                       uint64_t witness_stride, int32_t* d_result, void* stream);
+/* Issues everything pending and makes `stream` wait for all batches submitted so far (asynchronous for the host). */
+int blsw_engine_flush(blsw_engine_t* e, void* stream);
+/* duration (ms) of the last bit->Fp expansion kernel (HIP events on the stream it ran on); blocks until it has finished */
+int blsw_engine_last_expand_ms(blsw_engine_t* e, float* ms);
 
 /* hash_to_g2 only (src/hasher.rs:727-740 / src/bls.rs:477-493): d_out_affine [n][24] u64 (x.c0, x.c1, y.c0, y.c1) Montgomery */
+int blsw_hash_to_g2_workspace_bytes(uint64_t n, uint32_t msg_len, uint64_t* bytes);
 int blsw_hash_to_g2_batch(const uint8_t* d_msg, uint32_t msg_len, uint64_t n, uint64_t* d_out_affine, void* d_workspace, uint64_t workspace_bytes,
                           void* stream);
 

@@ -108,6 +108,35 @@ def test_other_message_lengths(pkg, oracle, msg_len):
     _compare(oracle, pk, msg.reshape(2, msg_len), sig, got, w, range(2))
 
 
+def test_engine_grouped_batches(pkg, oracle):
+    # engine mode: 5 different batches of 8 instances, fused 3 per launch group (3 + 2: both ping-pong buffers, staging,
+    # per-step placement), each with its own witness tensor
+    import torch
+
+    n, steps = 8, 5
+    pk, msg, sig, expect = synth.make_batch(oracle, n * steps, tamper_every=3)
+    dev = torch.device("cuda:0")
+    eng = pkg.WitnessEngine(n, 32, max_steps=3, device=dev)
+    outs, ress, ins = [], [], []
+    for k in range(steps):
+        sl = slice(k * n, (k + 1) * n)
+        d = (torch.from_numpy(pk[sl].view(np.int64)).to(dev), torch.from_numpy(sig[sl].view(np.int64)).to(dev), torch.from_numpy(msg[sl]).to(dev))
+        w, r = eng.new_witness_tensor(), torch.empty(n, dtype=torch.int32, device=dev)
+        eng.submit(d[0], d[1], d[2], witness=w, result=r)
+        outs.append(w)
+        ress.append(r)
+        ins.append(d)
+    eng.flush()
+    torch.cuda.synchronize()
+    for k in range(steps):
+        sl = slice(k * n, (k + 1) * n)
+        got = ress[k].cpu().numpy().astype(bool)
+        assert np.array_equal(got, expect[sl])
+        w = outs[k].cpu().numpy().view(np.uint64)
+        _compare(oracle, pk[sl], msg[sl], sig[sl], got, w, range(0, n, 3))
+    eng.close()
+
+
 def test_hash_to_g2_batch(pkg, oracle):
     import torch
 
