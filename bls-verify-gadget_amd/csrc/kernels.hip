@@ -122,6 +122,7 @@ __device__ __forceinline__ Emitter emitter(const Group& g, const LaneId& id, uin
 // ---------------------------------------------------------------- kernels (one instance per lane)
 // SHA-256 witness bits of expand_message (+ the message bits themselves)
 __global__ __launch_bounds__(64) void k_sha(Group g, int want_bits, int write_u) {
+    __builtin_amdgcn_s_setprio(3);  // latency-critical chain: win VALU issue arbitration against the streaming placement waves
     uint64_t I = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (I >= g.N) return;
     LaneId id = lane_id(g, I);
@@ -142,6 +143,7 @@ __global__ __launch_bounds__(64) void k_sha(Group g, int want_bits, int write_u)
 
 // value-only expand_message + hash_to_field: hands u0, u1 to k_map without waiting for the witness-bit pass
 __global__ __launch_bounds__(64) void k_sha_values(Group g) {
+    __builtin_amdgcn_s_setprio(3);  // latency-critical chain: win VALU issue arbitration against the streaming placement waves
     uint64_t I = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (I >= g.N) return;
     LaneId id = lane_id(g, I);
@@ -199,6 +201,7 @@ __global__ __launch_bounds__(256) void k_place_field(const Fp* __restrict__ stag
 }
 
 __global__ __launch_bounds__(64) void k_g1(Group g) {
+    __builtin_amdgcn_s_setprio(3);  // latency-critical chain: win VALU issue arbitration against the streaming placement waves
     uint64_t I = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (I >= g.N) return;
     LaneId id = lane_id(g, I);
@@ -209,6 +212,7 @@ __global__ __launch_bounds__(64) void k_g1(Group g) {
 }
 
 __global__ __launch_bounds__(64) void k_g2_alloc(Group g) {
+    __builtin_amdgcn_s_setprio(3);  // latency-critical chain: win VALU issue arbitration against the streaming placement waves
     uint64_t I = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (I >= g.N) return;
     LaneId id = lane_id(g, I);
@@ -219,6 +223,7 @@ __global__ __launch_bounds__(64) void k_g2_alloc(Group g) {
 
 // lanes [0, N): u0 -> Q0 ; lanes [N, 2N): u1 -> Q1
 __global__ __launch_bounds__(64) void k_map(Group g) {
+    __builtin_amdgcn_s_setprio(3);  // latency-critical chain: win VALU issue arbitration against the streaming placement waves
     uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= 2 * g.N) return;
     uint32_t which = t >= g.N;
@@ -244,6 +249,7 @@ __device__ __forceinline__ Proj<OpsFp2> ld_proj2(const Fp* p, uint64_t n) {
     return r;
 }
 __global__ __launch_bounds__(64) void k_cofactor(Group g) {
+    __builtin_amdgcn_s_setprio(3);  // latency-critical chain: win VALU issue arbitration against the streaming placement waves
     uint64_t I = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (I >= g.N) return;
     LaneId id = lane_id(g, I);
@@ -268,6 +274,7 @@ struct CoeffStrided {
 };
 // which = 0: prepare_g2(H(m)) ; which = 1: prepare_g2(sig)
 __global__ __launch_bounds__(64) void k_prepare(Group g, int which) {
+    __builtin_amdgcn_s_setprio(3);  // latency-critical chain: win VALU issue arbitration against the streaming placement waves
     uint64_t I = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (I >= g.N) return;
     LaneId id = lane_id(g, I);
@@ -289,6 +296,7 @@ __global__ __launch_bounds__(64) void k_prepare(Group g, int which) {
 
 // Miller loop + final exponentiation + is_one
 __global__ __launch_bounds__(64) void k_pairing(Group g) {
+    __builtin_amdgcn_s_setprio(3);  // latency-critical chain: win VALU issue arbitration against the streaming placement waves
     uint64_t I = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (I >= g.N) return;
     LaneId id = lane_id(g, I);
@@ -378,7 +386,8 @@ struct blsw_engine {
     uint64_t n;
     uint32_t msg_len, max_steps;
     blsw_layout_t L, LS;
-    GroupBuf buf[2];
+    GroupBuf buf[4];
+    int nbuf;
     int cur;
     uint32_t pending;
     hipStream_t place;
@@ -450,7 +459,7 @@ static int launch_group(blsw_engine* e, hipStream_t user_stream) {
     hipEventRecord(b.ev_done, e->place);
     b.used = true;
     e->pending = 0;
-    e->cur ^= 1;
+    e->cur = (e->cur + 1) % e->nbuf;
     return hip_ok(hipGetLastError(), "launch");
 }
 
@@ -464,12 +473,13 @@ int blsw_layout(uint32_t msg_len, blsw_layout_t* out) {
     return BLSW_OK;
 }
 
+static int engine_nbuf(uint32_t max_steps) { return max_steps > 1 ? 3 : 1; }
 int blsw_engine_workspace_bytes(uint64_t n, uint32_t msg_len, uint32_t max_steps, uint64_t* bytes) {
     if (!bytes || n == 0 || max_steps == 0) return BLSW_ERR_ARG;
     blsw_layout_t L;
     make_layout(msg_len, &L);
     Workspace w = carve(nullptr, n * max_steps, L, max_steps > 1);
-    *bytes = 2 * align_up(w.total_bytes, 4096);
+    *bytes = (uint64_t)engine_nbuf(max_steps) * align_up(w.total_bytes, 4096);
     return BLSW_OK;
 }
 
@@ -490,20 +500,23 @@ int blsw_engine_create(blsw_engine_t** out, uint64_t n, uint32_t msg_len, uint32
     e->cur = 0;
     e->pending = 0;
     e->have_expand_timing = 0;
-    for (int k = 0; k < 2; k++) {
+    e->nbuf = engine_nbuf(max_steps);
+    int prio_lo = 0, prio_hi = 0;
+    hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);  // (least, greatest): numerically lower = higher priority
+    for (int k = 0; k < e->nbuf; k++) {
         GroupBuf& b = e->buf[k];
-        b.base = reinterpret_cast<char*>(d_workspace) + (uint64_t)k * (need / 2);
+        b.base = reinterpret_cast<char*>(d_workspace) + (uint64_t)k * (need / e->nbuf);
         b.used = false;
         if (hip_ok(hipHostMalloc(reinterpret_cast<void**>(&b.h_desc), sizeof(StepDesc) * max_steps, hipHostMallocDefault), "host alloc")) return BLSW_ERR_HIP;
         if (hip_ok(hipMalloc(reinterpret_cast<void**>(&b.d_desc), sizeof(StepDesc) * max_steps), "desc alloc")) return BLSW_ERR_HIP;
         for (int i = 0; i < 4; i++)
-            if (hip_ok(hipStreamCreateWithFlags(&b.st[i], hipStreamNonBlocking), "stream create")) return BLSW_ERR_HIP;
+            if (hip_ok(hipStreamCreateWithPriority(&b.st[i], hipStreamNonBlocking, prio_hi), "stream create")) return BLSW_ERR_HIP;
         for (int i = 0; i < 3; i++) hipEventCreateWithFlags(&b.ev_aux[i], hipEventDisableTiming);
         hipEventCreateWithFlags(&b.ev_start, hipEventDisableTiming);
         hipEventCreateWithFlags(&b.ev_chains, hipEventDisableTiming);
         hipEventCreateWithFlags(&b.ev_done, hipEventDisableTiming);
     }
-    if (hip_ok(hipStreamCreateWithFlags(&e->place, hipStreamNonBlocking), "stream create")) return BLSW_ERR_HIP;
+    if (hip_ok(hipStreamCreateWithPriority(&e->place, hipStreamNonBlocking, prio_lo), "stream create")) return BLSW_ERR_HIP;
     hipEventCreate(&e->ev_exp0);
     hipEventCreate(&e->ev_exp1);
     hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming);
@@ -514,7 +527,7 @@ int blsw_engine_create(blsw_engine_t** out, uint64_t n, uint32_t msg_len, uint32
 int blsw_engine_destroy(blsw_engine_t* e) {
     if (!e) return BLSW_ERR_ARG;
     hipDeviceSynchronize();
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < e->nbuf; k++) {
         GroupBuf& b = e->buf[k];
         hipHostFree(b.h_desc);
         hipFree(b.d_desc);
@@ -560,7 +573,7 @@ int blsw_engine_flush(blsw_engine_t* e, void* stream_) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream_);
     int rc = launch_group(e, st);
     if (rc) return rc;
-    for (int k = 0; k < 2; k++)
+    for (int k = 0; k < e->nbuf; k++)
         if (e->buf[k].used) hipStreamWaitEvent(st, e->buf[k].ev_done, 0);
     return hip_ok(hipGetLastError(), "flush");
 }
