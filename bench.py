@@ -26,7 +26,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # HIP multiplexes streams onto 4 hardware queues by default; the engine runs ~9 streams (2 group buffers x 4 + placement)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# ROCr sizes a queue's scratch (the chain kernels' stacks, up to 10.5 KB per lane) for full-device occupancy: 5.7 GB for
+# k_pairing, above the 3 GB default above which scratch is re-allocated for every dispatch
+os.environ.setdefault("HSA_SCRATCH_SINGLE_LIMIT_ASYNC", str(8 << 30))
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured float4 copy)
 # algorithmic field work per instance, from the oracle's op counter on the reference gadget case
@@ -55,6 +58,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--batch", type=int, default=1024, help="instances per GPU per step (configs[1]: 1024)")
     ap.add_argument("--coalesce", type=int, default=20, help="max submitted batches fused into one launch group")
+    ap.add_argument("--buffers", type=int, default=3, help="launch groups in flight (each owns streams + a workspace slice)")
     ap.add_argument("--outputs", type=int, default=2, help="ring of output witness tensors (34 MB x batch each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=32)
@@ -88,9 +92,11 @@ def main():
     free_b, _ = torch.cuda.mem_get_info(dev)
     n_out = max(1, min(args.outputs, args.steps + args.warmup))
     coalesce = max(1, min(args.coalesce, args.steps))
-    while coalesce > 1 and pkg.engine_workspace_bytes(n, 32, coalesce) + n_out * out_bytes > 0.92 * free_b:
-        coalesce -= 1
-    eng = pkg.WitnessEngine(n, 32, max_steps=coalesce, device=dev)
+    buffers = max(1, min(args.buffers, (args.steps + coalesce - 1) // coalesce))
+    # leave >= 25 % of HBM to the runtime (per-queue scratch = stacks of the chain kernels)
+    while buffers > 1 and pkg.engine_workspace_bytes(n, 32, coalesce, buffers) + n_out * out_bytes > 0.68 * free_b:
+        buffers -= 1
+    eng = pkg.WitnessEngine(n, 32, max_steps=coalesce, device=dev, n_buffers=buffers)
     outs = [eng.new_witness_tensor() for _ in range(n_out)]
     results = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(n_out)]
     torch.cuda.synchronize()
@@ -151,7 +157,7 @@ def main():
         "dtype": "u32 (12 x 32-bit limb Montgomery integers mod the 381-bit BLS12-381 prime; SHA-256 words)",
         "data": "synthetic",
         "config": {"workload": "configs[1]: batch of 1024 independent BLS-verify instances per GPU per step, 32-byte messages, full witness vectors written",
-                   "instances_per_gpu_per_step": n, "batches_fused_per_launch_group": coalesce, "output_ring": n_out, "n_witness": lay["n_witness"], "results_ok": ok},
+                   "instances_per_gpu_per_step": n, "batches_fused_per_launch_group": coalesce, "groups_in_flight": buffers, "output_ring": n_out, "n_witness": lay["n_witness"], "results_ok": ok},
         "roofline": {"bound": "hbm", "kernel": "k_sha_expand", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                      "traffic": None, "algorithmic_bytes_per_launch": expand_bytes, "avg_launch_ms": exp_avg_ms},
         "roofline_whole_path": {"bound": "hbm", "algorithmic_bytes_per_instance": bytes_per_instance,

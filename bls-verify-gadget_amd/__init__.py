@@ -52,8 +52,8 @@ def lib():
         L = ctypes.CDLL(LIB_PATH)
         vp, u32, u64 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64
         L.blsw_layout.argtypes = [u32, ctypes.POINTER(blsw_layout_t)]
-        L.blsw_engine_workspace_bytes.argtypes = [u64, u32, u32, ctypes.POINTER(u64)]
-        L.blsw_engine_create.argtypes = [ctypes.POINTER(vp), u64, u32, u32, vp, u64]
+        L.blsw_engine_workspace_bytes.argtypes = [u64, u32, u32, u32, ctypes.POINTER(u64)]
+        L.blsw_engine_create.argtypes = [ctypes.POINTER(vp), u64, u32, u32, u32, vp, u64]
         L.blsw_engine_destroy.argtypes = [vp]
         L.blsw_engine_submit.argtypes = [vp, vp, vp, vp, vp, u64, vp, vp]
         L.blsw_engine_flush.argtypes = [vp, vp]
@@ -78,9 +78,9 @@ def layout(msg_len=32):
     return {n: getattr(L, n) for n in _LAYOUT_FIELDS}
 
 
-def engine_workspace_bytes(n, msg_len=32, max_steps=1):
+def engine_workspace_bytes(n, msg_len=32, max_steps=1, n_buffers=1):
     b = ctypes.c_uint64(0)
-    rc = lib().blsw_engine_workspace_bytes(n, msg_len, max_steps, ctypes.byref(b))
+    rc = lib().blsw_engine_workspace_bytes(n, msg_len, max_steps, n_buffers, ctypes.byref(b))
     if rc:
         raise BlswError("blsw_engine_workspace_bytes failed: %d" % rc)
     return b.value
@@ -97,17 +97,18 @@ def _require_cuda():
 class WitnessEngine:
     """Thin wrapper of blsw_engine_*: submit batches, flush, read results. max_steps batches are fused per launch group."""
 
-    def __init__(self, n, msg_len=32, max_steps=1, device=None):
+    def __init__(self, n, msg_len=32, max_steps=1, device=None, n_buffers=None):
         torch = _require_cuda()
         self.torch = torch
         self.n, self.msg_len, self.max_steps = int(n), int(msg_len), int(max_steps)
+        self.n_buffers = int(n_buffers) if n_buffers is not None else (3 if self.max_steps > 1 else 1)
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         self.layout = layout(msg_len)
         self.n_witness = self.layout["n_witness"]
-        self.workspace = torch.empty(engine_workspace_bytes(self.n, msg_len, self.max_steps), dtype=torch.uint8, device=self.device)
+        self.workspace = torch.empty(engine_workspace_bytes(self.n, msg_len, self.max_steps, self.n_buffers), dtype=torch.uint8, device=self.device)
         self._e = ctypes.c_void_p()
         with torch.cuda.device(self.device):
-            rc = lib().blsw_engine_create(ctypes.byref(self._e), self.n, self.msg_len, self.max_steps, self.workspace.data_ptr(), self.workspace.numel())
+            rc = lib().blsw_engine_create(ctypes.byref(self._e), self.n, self.msg_len, self.max_steps, self.n_buffers, self.workspace.data_ptr(), self.workspace.numel())
         if rc:
             raise BlswError("blsw_engine_create failed: %d" % rc)
         self._keep = []
@@ -146,7 +147,7 @@ class WitnessEngine:
         rc = lib().blsw_engine_flush(self._e, s.cuda_stream)
         if rc:
             raise BlswError("blsw_engine_flush failed: %d" % rc)
-        self._keep = self._keep[-4 * self.max_steps:]
+        self._keep = self._keep[-(self.n_buffers + 1) * self.max_steps:]
 
     def last_expand_ms(self):
         ms = ctypes.c_float(0)

@@ -19,7 +19,7 @@ struct OpsFp {
     static BLSW_HD F neg(const F& a) { return fp_neg(a); }
     static BLSW_HD F mul_w(Emitter& e, const F& a, const F& b) { return fp_mul_w(e, a, b); }
     static BLSW_HD F sqr_w(Emitter& e, const F& a) { return fp_mul_w(e, a, a); }
-    static BLSW_FN F mul3b(const F& a) {  // * 12
+    static BLSW_HD F mul3b(const F& a) {  // * 12
         F a4 = fp_dbl(fp_dbl(a));
         return fp_add(fp_dbl(a4), a4);
     }
@@ -35,7 +35,7 @@ struct OpsFp2 {
     static BLSW_HD F neg(const F& a) { return fp2_neg(a); }
     static BLSW_HD F mul_w(Emitter& e, const F& a, const F& b) { return fp2_mul_w(e, a, b); }
     static BLSW_HD F sqr_w(Emitter& e, const F& a) { return fp2_sqr_w(e, a); }
-    static BLSW_FN F mul3b(const F& a) {  // * 12(1+u)
+    static BLSW_HD F mul3b(const F& a) {  // * 12(1+u)
         F x = fp2_mul_xi(a);
         F a4 = fp2_dbl(fp2_dbl(x));
         return fp2_add(fp2_dbl(a4), a4);

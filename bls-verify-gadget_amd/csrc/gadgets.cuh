@@ -40,7 +40,7 @@ struct Emitter {
 };
 
 // ---- FpVar
-BLSW_FN Fp fp_mul_w(Emitter& e, const Fp& a, const Fp& b) {
+BLSW_HD Fp fp_mul_w(Emitter& e, const Fp& a, const Fp& b) {
     Fp r = fp_mul(a, b);
     e.put(r);
     return r;
@@ -55,7 +55,7 @@ BLSW_FN bool fp_is_eq_w(Emitter& e, const Fp& self, const Fp& other) {
     e.put(ne ? m : fp_one());
     return !ne;
 }
-BLSW_FN Fp fp_select_w(Emitter& e, bool cond, const Fp& t, const Fp& f) {
+BLSW_HD Fp fp_select_w(Emitter& e, bool cond, const Fp& t, const Fp& f) {
     Fp r;
 #pragma unroll
     for (int i = 0; i < 12; i++) r.l[i] = cond ? t.l[i] : f.l[i];
@@ -99,8 +99,8 @@ BLSW_FN bool fp2_is_eq_w(Emitter& e, const Fp2& self, const Fp2& other) {
     return r;
 }
 // v.is_eq(Constant zero) / v.is_zero(): evaluated as zero.is_eq(v)
-BLSW_FN bool fp2_is_zero_w(Emitter& e, const Fp2& v) { return fp2_is_eq_w(e, fp2_zero(), v); }
-BLSW_FN Fp2 fp2_select_w(Emitter& e, bool cond, const Fp2& t, const Fp2& f) {
+BLSW_HD bool fp2_is_zero_w(Emitter& e, const Fp2& v) { return fp2_is_eq_w(e, fp2_zero(), v); }
+BLSW_HD Fp2 fp2_select_w(Emitter& e, bool cond, const Fp2& t, const Fp2& f) {
     Fp c0 = fp_select_w(e, cond, t.c0, f.c0);
     Fp c1 = fp_select_w(e, cond, t.c1, f.c1);
     return {c0, c1};

@@ -4,6 +4,7 @@
 // SHA-256 (93 % of the witness bytes) at HBM-write speed. See DESIGN.md for the data layout.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include "chains.cuh"
 #include "layout.h"
 
@@ -152,30 +153,40 @@ __global__ __launch_bounds__(64) void k_sha_values(Group g) {
     for (int j = 0; j < 4; j++) st_fp(g.ws.u + (uint64_t)j * g.N + I, hash_to_field_elem(uw + 16 * j));
 }
 
-// bitstream -> Fp elements: element e of the expand segment = bit ? R mod p : 0. One 16-byte chunk per thread
-// per step, consecutive threads write consecutive 16 B: every store instruction covers 1 KiB contiguous per wave.
-// Direct mode: blockIdx.y = instance of the (single) step.
-__global__ __launch_bounds__(256) void k_sha_expand(const uint32_t* __restrict__ bits, uint64_t N, uint64_t first, uint32_t sha_bits,
+// bitstream -> Fp elements: element e of the expand segment = bit ? R mod p : 0. Thread t of a 384-thread block owns
+// the 16-byte column c = t % 3 of elements e0 + 128k, so its three R limbs-of-four are loop invariants and one store
+// instruction of a wave covers 1 KiB contiguous. ~10 VALU instructions per 16 bytes stored; streaming (nontemporal)
+// stores: the tensor is not read again on the device. blockIdx.y = instance of the step.
+#define BLSW_EXPAND_ITERS 32
+template <bool NT>
+__global__ __launch_bounds__(384) void k_sha_expand(const uint32_t* __restrict__ bits, uint64_t N, uint64_t first, uint32_t sha_bits,
                                                     uint32_t off_expand, uint64_t* __restrict__ d_witness, uint64_t stride) {
     constexpr uint32_t R1[12] = BLSW_R1_LIMBS;
     const uint64_t inst = blockIdx.y;
-    const uint32_t nchunks = sha_bits * 3;
     uint4* out = reinterpret_cast<uint4*>(d_witness + (inst * stride + off_expand) * 6);
     const uint32_t* b = bits + first + inst;
-    uint32_t q0 = blockIdx.x * (256 * 16) + threadIdx.x;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        uint32_t q = q0 + k * 256;
-        if (q < nchunks) {
-            uint32_t e = q / 3, c = q - e * 3;
+    const uint32_t t = threadIdx.x, c = t % 3;
+    const uint32_t e0 = blockIdx.x * (128 * BLSW_EXPAND_ITERS) + t / 3;
+    uint4 rc;
+    rc.x = c == 0 ? R1[0] : (c == 1 ? R1[4] : R1[8]);
+    rc.y = c == 0 ? R1[1] : (c == 1 ? R1[5] : R1[9]);
+    rc.z = c == 0 ? R1[2] : (c == 1 ? R1[6] : R1[10]);
+    rc.w = c == 0 ? R1[3] : (c == 1 ? R1[7] : R1[11]);
+#pragma unroll 8
+    for (int k = 0; k < BLSW_EXPAND_ITERS; k++) {
+        uint32_t e = e0 + 128 * k;
+        if (e < sha_bits) {
             uint32_t w = b[(uint64_t)(e >> 5) * N];
             uint32_t m = 0u - ((w >> (e & 31)) & 1u);
-            uint4 v;
-            v.x = (c == 0 ? R1[0] : (c == 1 ? R1[4] : R1[8])) & m;
-            v.y = (c == 0 ? R1[1] : (c == 1 ? R1[5] : R1[9])) & m;
-            v.z = (c == 0 ? R1[2] : (c == 1 ? R1[6] : R1[10])) & m;
-            v.w = (c == 0 ? R1[3] : (c == 1 ? R1[7] : R1[11])) & m;
-            out[q] = v;
+            uint4 v = make_uint4(rc.x & m, rc.y & m, rc.z & m, rc.w & m);
+            if (NT) {
+                __builtin_nontemporal_store(v.x, &out[(uint64_t)e * 3 + c].x);
+                __builtin_nontemporal_store(v.y, &out[(uint64_t)e * 3 + c].y);
+                __builtin_nontemporal_store(v.z, &out[(uint64_t)e * 3 + c].z);
+                __builtin_nontemporal_store(v.w, &out[(uint64_t)e * 3 + c].w);
+            } else {
+                out[(uint64_t)e * 3 + c] = v;
+            }
         }
     }
 }
@@ -373,6 +384,7 @@ inline int hip_ok(hipError_t e, const char* what) {
 // the `place` stream writes the step's complete witness tensor: k_sha_expand (bit -> Fp, ~31 MB per instance, the
 // HBM-bound kernel) and k_place_field (staging -> its place around the SHA segment). Two group buffers ping-pong,
 // so the next group's chains overlap the previous group's placement.
+#define BLSW_MAX_BUFFERS 32
 struct GroupBuf {
     void* base;
     Workspace ws;
@@ -386,7 +398,7 @@ struct blsw_engine {
     uint64_t n;
     uint32_t msg_len, max_steps;
     blsw_layout_t L, LS;
-    GroupBuf buf[4];
+    GroupBuf buf[BLSW_MAX_BUFFERS];
     int nbuf;
     int cur;
     uint32_t pending;
@@ -396,6 +408,22 @@ struct blsw_engine {
     bool staged;  // false: direct mode (max_steps == 1, no staging; witnesses written in place by the chains)
 };
 
+static unsigned place_lds_bytes() {
+    static int v = -1;
+    if (v < 0) {
+        const char* s = getenv("BLSW_PLACE_LDS");
+        v = s ? atoi(s) : 80000;  // <= 2 placement workgroups per CU: leaves issue slots and cache to the chain waves
+    }
+    return (unsigned)v;
+}
+static bool place_nt() {
+    static int v = -1;
+    if (v < 0) {
+        const char* s = getenv("BLSW_EXPAND_NT");
+        v = s ? atoi(s) : 1;
+    }
+    return v != 0;
+}
 static int launch_group(blsw_engine* e, hipStream_t user_stream) {
     GroupBuf& b = e->buf[e->cur];
     const uint32_t steps = e->pending;
@@ -443,10 +471,14 @@ static int launch_group(blsw_engine* e, hipStream_t user_stream) {
     for (uint32_t s = 0; s < steps && any_out; s++) {
         const StepDesc& d = b.h_desc[s];
         if (!d.out) continue;
-        dim3 grid((e->L.sha_bits * 3 + 4095) / 4096, (unsigned)e->n);
+        dim3 grid((e->L.sha_bits + 128 * BLSW_EXPAND_ITERS - 1) / (128 * BLSW_EXPAND_ITERS), (unsigned)e->n);
         hipEventRecord(e->ev_exp0, e->place);
-        hipLaunchKernelGGL(k_sha_expand, grid, dim3(256), 0, e->place, g.ws.bits, g.N, (uint64_t)s * e->n, e->L.sha_bits, e->L.off_expand, d.out,
-                           d.out_stride);
+        if (place_nt())
+            hipLaunchKernelGGL(k_sha_expand<true>, grid, dim3(384), place_lds_bytes(), e->place, g.ws.bits, g.N, (uint64_t)s * e->n, e->L.sha_bits,
+                               e->L.off_expand, d.out, d.out_stride);
+        else
+            hipLaunchKernelGGL(k_sha_expand<false>, grid, dim3(384), place_lds_bytes(), e->place, g.ws.bits, g.N, (uint64_t)s * e->n, e->L.sha_bits,
+                               e->L.off_expand, d.out, d.out_stride);
         hipEventRecord(e->ev_exp1, e->place);
         e->have_expand_timing = 1;
         if (e->staged) {
@@ -473,34 +505,34 @@ int blsw_layout(uint32_t msg_len, blsw_layout_t* out) {
     return BLSW_OK;
 }
 
-static int engine_nbuf(uint32_t max_steps) { return max_steps > 1 ? 3 : 1; }
-int blsw_engine_workspace_bytes(uint64_t n, uint32_t msg_len, uint32_t max_steps, uint64_t* bytes) {
-    if (!bytes || n == 0 || max_steps == 0) return BLSW_ERR_ARG;
+int blsw_engine_workspace_bytes(uint64_t n, uint32_t msg_len, uint32_t max_steps, uint32_t n_buffers, uint64_t* bytes) {
+    if (!bytes || n == 0 || max_steps == 0 || n_buffers == 0 || n_buffers > BLSW_MAX_BUFFERS) return BLSW_ERR_ARG;
     blsw_layout_t L;
     make_layout(msg_len, &L);
-    Workspace w = carve(nullptr, n * max_steps, L, max_steps > 1);
-    *bytes = (uint64_t)engine_nbuf(max_steps) * align_up(w.total_bytes, 4096);
+    Workspace w = carve(nullptr, n * max_steps, L, max_steps > 1 || n_buffers > 1);
+    *bytes = (uint64_t)n_buffers * align_up(w.total_bytes, 4096);
     return BLSW_OK;
 }
 
-int blsw_engine_create(blsw_engine_t** out, uint64_t n, uint32_t msg_len, uint32_t max_steps, void* d_workspace, uint64_t workspace_bytes) {
-    if (!out || n == 0 || max_steps == 0 || !d_workspace) return BLSW_ERR_ARG;
+int blsw_engine_create(blsw_engine_t** out, uint64_t n, uint32_t msg_len, uint32_t max_steps, uint32_t n_buffers, void* d_workspace,
+                       uint64_t workspace_bytes) {
+    if (!out || n == 0 || max_steps == 0 || !d_workspace || n_buffers == 0 || n_buffers > BLSW_MAX_BUFFERS) return BLSW_ERR_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return BLSW_ERR_NO_DEVICE;
     uint64_t need = 0;
-    blsw_engine_workspace_bytes(n, msg_len, max_steps, &need);
+    blsw_engine_workspace_bytes(n, msg_len, max_steps, n_buffers, &need);
     if (workspace_bytes < need) return BLSW_ERR_WORKSPACE;
     blsw_engine* e = new blsw_engine();
     e->n = n;
     e->msg_len = msg_len;
     e->max_steps = max_steps;
-    e->staged = max_steps > 1;
+    e->staged = max_steps > 1 || n_buffers > 1;
     make_layout(msg_len, &e->L);
     e->LS = staging_layout(e->L);
     e->cur = 0;
     e->pending = 0;
     e->have_expand_timing = 0;
-    e->nbuf = engine_nbuf(max_steps);
+    e->nbuf = (int)n_buffers;
     int prio_lo = 0, prio_hi = 0;
     hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);  // (least, greatest): numerically lower = higher priority
     for (int k = 0; k < e->nbuf; k++) {

@@ -13,15 +13,15 @@ struct Fp6 {
 struct Fp12 {
     Fp6 c0, c1;
 };
-BLSW_FN Fp6 fp6_add(const Fp6& a, const Fp6& b) { return {fp2_add(a.c0, b.c0), fp2_add(a.c1, b.c1), fp2_add(a.c2, b.c2)}; }
-BLSW_FN Fp6 fp6_sub(const Fp6& a, const Fp6& b) { return {fp2_sub(a.c0, b.c0), fp2_sub(a.c1, b.c1), fp2_sub(a.c2, b.c2)}; }
-BLSW_FN Fp6 fp6_neg(const Fp6& a) { return {fp2_neg(a.c0), fp2_neg(a.c1), fp2_neg(a.c2)}; }
-BLSW_FN Fp6 fp6_dbl(const Fp6& a) { return {fp2_dbl(a.c0), fp2_dbl(a.c1), fp2_dbl(a.c2)}; }
-BLSW_FN Fp6 fp6_mul_v(const Fp6& a) { return {fp2_mul_xi(a.c2), a.c0, a.c1}; }
+BLSW_HD Fp6 fp6_add(const Fp6& a, const Fp6& b) { return {fp2_add(a.c0, b.c0), fp2_add(a.c1, b.c1), fp2_add(a.c2, b.c2)}; }
+BLSW_HD Fp6 fp6_sub(const Fp6& a, const Fp6& b) { return {fp2_sub(a.c0, b.c0), fp2_sub(a.c1, b.c1), fp2_sub(a.c2, b.c2)}; }
+BLSW_HD Fp6 fp6_neg(const Fp6& a) { return {fp2_neg(a.c0), fp2_neg(a.c1), fp2_neg(a.c2)}; }
+BLSW_HD Fp6 fp6_dbl(const Fp6& a) { return {fp2_dbl(a.c0), fp2_dbl(a.c1), fp2_dbl(a.c2)}; }
+BLSW_HD Fp6 fp6_mul_v(const Fp6& a) { return {fp2_mul_xi(a.c2), a.c0, a.c1}; }
 BLSW_HD Fp6 fp6_zero() { return {fp2_zero(), fp2_zero(), fp2_zero()}; }
 BLSW_HD Fp6 fp6_one() { return {fp2_one(), fp2_zero(), fp2_zero()}; }
 BLSW_HD Fp12 fp12_one() { return {fp6_one(), fp6_zero()}; }
-BLSW_FN Fp12 fp12_conj(const Fp12& a) { return {a.c0, fp6_neg(a.c1)}; }
+BLSW_HD Fp12 fp12_conj(const Fp12& a) { return {a.c0, fp6_neg(a.c1)}; }
 
 // CubicExtVar mul: v0, v1, v2, (a1+a2)(b1+b2), (a0+a1)(b0+b1), (a0+a2)(b0+b2)   -> 18 Fp witnesses
 BLSW_FN Fp6 fp6_mul_w(Emitter& e, const Fp6& a, const Fp6& b) {
@@ -46,7 +46,7 @@ BLSW_FN Fp6 fp6_mul(const Fp6& a, const Fp6& b) {
             fp2_sub(fp2_add(fp2_sub(t2, v0), v1), v2)};
 }
 // QuadExtVar::mul_equals over Fp: only v1 = a.c1*b.c1 is a witness
-BLSW_FN void fp2_mul_equals_w(Emitter& e, const Fp2& a, const Fp2& b) { fp_mul_w(e, a.c1, b.c1); }
+BLSW_HD void fp2_mul_equals_w(Emitter& e, const Fp2& a, const Fp2& b) { fp_mul_w(e, a.c1, b.c1); }
 // CubicExtVar::mul_equals: v0, v1, v2 (9 witnesses) then three Fp2 mul_equals (1 witness each)
 BLSW_FN void fp6_mul_equals_w(Emitter& e, const Fp6& a, const Fp6& b) {
     fp2_mul_w(e, a.c0, b.c0);

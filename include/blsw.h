@@ -52,10 +52,14 @@ int blsw_layout(uint32_t msg_len, blsw_layout_t* out);
  * chain; a group of 32 batches fills the 1024 SIMDs of an MI355X). max_steps == 1 is the direct mode: the chains
  * write every witness in place. With max_steps > 1 field witnesses are staged element-major (coalesced stores) and
  * each batch's witness tensor is then written, in submission order, by the streaming placement kernels.
+ * n_buffers groups can be in flight at once (each with its own streams and workspace slice). Keep
+ * max_steps * n / 64 wavefronts * the largest per-lane stack (11 KB) under the runtime's 140 MB per-dispatch scratch
+ * limit (max_steps <= 8 for n = 1024): larger dispatches fall into ROCr's allocate-per-dispatch scratch path.
  * The caller owns the device workspace (blsw_engine_workspace_bytes). One engine per device; not thread-safe. */
 typedef struct blsw_engine blsw_engine_t;
-int blsw_engine_workspace_bytes(uint64_t n, uint32_t msg_len, uint32_t max_steps, uint64_t* bytes);
-int blsw_engine_create(blsw_engine_t** out, uint64_t n, uint32_t msg_len, uint32_t max_steps, void* d_workspace, uint64_t workspace_bytes);
+int blsw_engine_workspace_bytes(uint64_t n, uint32_t msg_len, uint32_t max_steps, uint32_t n_buffers, uint64_t* bytes);
+int blsw_engine_create(blsw_engine_t** out, uint64_t n, uint32_t msg_len, uint32_t max_steps, uint32_t n_buffers, void* d_workspace,
+                       uint64_t workspace_bytes);
 int blsw_engine_destroy(blsw_engine_t* e);
 
 /* Submits one batch of n independent (pk, msg, sig) instances: the witness vectors of the circuit of

@@ -37,7 +37,7 @@ def test_library_exports_and_layout():
         assert sym + "(" in header
         assert getattr(L, sym) is not None
     assert pkg.layout(32) == hostsim_lib.layout(32)
-    assert pkg.engine_workspace_bytes(1024, 32, 1) > 0 and pkg.engine_workspace_bytes(1024, 32, 4) > pkg.engine_workspace_bytes(1024, 32, 1)
+    assert pkg.engine_workspace_bytes(1024, 32, 1, 1) > 0 and pkg.engine_workspace_bytes(1024, 32, 4, 3) > pkg.engine_workspace_bytes(1024, 32, 1, 1)
 
 
 def _check(oracle, pk, msg, sig):
