@@ -57,7 +57,7 @@ def main():
     ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--batch", type=int, default=1024, help="instances per GPU per step (configs[1]: 1024)")
-    ap.add_argument("--coalesce", type=int, default=20, help="max submitted batches fused into one launch group")
+    ap.add_argument("--coalesce", type=int, default=16, help="max submitted batches fused into one launch group")
     ap.add_argument("--buffers", type=int, default=3, help="launch groups in flight (each owns streams + a workspace slice)")
     ap.add_argument("--outputs", type=int, default=2, help="ring of output witness tensors (34 MB x batch each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

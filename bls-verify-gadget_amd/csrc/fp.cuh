@@ -142,17 +142,28 @@ BLSW_HD Fp fp_dbl(const Fp& a) { return fp_add(a, a); }
 // Montgomery product a*b*R^-1 mod p, CIOS over 32-bit limbs: 144 + 144 v_mad_u64_u32 + 12 v_mul_lo_u32
 // (the "300 MAD per Fp-mul" of SURVEY §8d). Per row the 12 products are independent (no carry in the mad
 // chain); the high halves are folded in by one add-with-carry pass. Kept out of line: one body per code object.
-BLSW_HD_NOINLINE Fp fp_mul(const Fp a, const Fp b) {
+// Operands travel as six 16-byte vectors so that BOTH stay in VGPRs across the call (a by-value struct pair
+// would send the second operand through the stack).
+#if defined(__HIPCC__)
+typedef uint4 blsw_u4;
+#else
+struct blsw_u4 {
+    uint32_t x, y, z, w;
+};
+#endif
+BLSW_HD_NOINLINE Fp fp_mul_v(blsw_u4 a0, blsw_u4 a1, blsw_u4 a2, blsw_u4 b0, blsw_u4 b1, blsw_u4 b2) {
     constexpr uint32_t P[12] = BLSW_P_LIMBS;
+    const uint32_t al[12] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w};
+    const uint32_t bl[12] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w};
     uint32_t t[13];
 #pragma unroll
     for (int i = 0; i < 13; i++) t[i] = 0;
 #pragma unroll
     for (int i = 0; i < 12; i++) {
-        const uint32_t bi = b.l[i];
+        const uint32_t bi = bl[i];
         uint64_t x[12];
 #pragma unroll
-        for (int j = 0; j < 12; j++) x[j] = (uint64_t)a.l[j] * bi + t[j];
+        for (int j = 0; j < 12; j++) x[j] = (uint64_t)al[j] * bi + t[j];
         uint32_t c = 0;
         t[0] = (uint32_t)x[0];
 #pragma unroll
@@ -171,6 +182,11 @@ BLSW_HD_NOINLINE Fp fp_mul(const Fp a, const Fp b) {
 #pragma unroll
     for (int i = 0; i < 12; i++) r.l[i] = t[i];
     return fp_cond_sub_p(r, 0);
+}
+BLSW_HD Fp fp_mul(const Fp& a, const Fp& b) {
+    blsw_u4 a0 = {a.l[0], a.l[1], a.l[2], a.l[3]}, a1 = {a.l[4], a.l[5], a.l[6], a.l[7]}, a2 = {a.l[8], a.l[9], a.l[10], a.l[11]};
+    blsw_u4 b0 = {b.l[0], b.l[1], b.l[2], b.l[3]}, b1 = {b.l[4], b.l[5], b.l[6], b.l[7]}, b2 = {b.l[8], b.l[9], b.l[10], b.l[11]};
+    return fp_mul_v(a0, a1, a2, b0, b1, b2);
 }
 BLSW_HD Fp fp_sqr(const Fp& a) { return fp_mul(a, a); }
 

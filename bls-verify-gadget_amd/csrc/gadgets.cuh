@@ -64,13 +64,13 @@ BLSW_HD Fp fp_select_w(Emitter& e, bool cond, const Fp& t, const Fp& f) {
 }
 
 // ---- Fp2Var (QuadExtVar over FpVar)
-BLSW_FN Fp2 fp2_mul_w(Emitter& e, const Fp2& a, const Fp2& b) {
+BLSW_HD Fp2 fp2_mul_w(Emitter& e, const Fp2& a, const Fp2& b) {
     Fp v0 = fp_mul_w(e, a.c0, b.c0);
     Fp v1 = fp_mul_w(e, a.c1, b.c1);
     Fp s = fp_mul_w(e, fp_add(a.c0, a.c1), fp_add(b.c0, b.c1));
     return {fp_sub(v0, v1), fp_sub(fp_sub(s, v0), v1)};
 }
-BLSW_FN Fp2 fp2_sqr_w(Emitter& e, const Fp2& a) {
+BLSW_HD Fp2 fp2_sqr_w(Emitter& e, const Fp2& a) {
     Fp v2 = fp_mul_w(e, a.c0, a.c1);
     Fp t = fp_mul_w(e, fp_sub(a.c0, a.c1), fp_add(a.c0, a.c1));
     return {t, fp_dbl(v2)};
