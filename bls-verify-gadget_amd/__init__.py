@@ -60,13 +60,14 @@ def lib():
         L.blsw_engine_last_expand_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
         L.blsw_hash_to_g2_workspace_bytes.argtypes = [u64, u32, ctypes.POINTER(u64)]
         L.blsw_hash_to_g2_batch.argtypes = [vp, u32, u64, vp, vp, u64, vp]
+        L.blsw_decode_batch.argtypes = [vp, vp, u64, vp, vp, vp, vp]
         L.blsw_microbench.argtypes = [ctypes.c_int, u32, u32, ctypes.POINTER(ctypes.c_double)]
         _lib = L
     return _lib
 
 
 EXPORTED_SYMBOLS = ["blsw_version", "blsw_layout", "blsw_engine_workspace_bytes", "blsw_engine_create", "blsw_engine_destroy", "blsw_engine_submit",
-                    "blsw_engine_flush", "blsw_engine_last_expand_ms", "blsw_hash_to_g2_workspace_bytes", "blsw_hash_to_g2_batch", "blsw_microbench"]
+                    "blsw_engine_flush", "blsw_engine_last_expand_ms", "blsw_hash_to_g2_workspace_bytes", "blsw_hash_to_g2_batch", "blsw_decode_batch", "blsw_microbench"]
 
 
 def layout(msg_len=32):
@@ -207,6 +208,36 @@ class BlsSignatureVerifyGadget:
         self.engine.submit(public_key.xy, signature.xy, message, witness=w, result=self.result, stream=stream)
         self.engine.flush(stream=stream)
         return self.result
+
+
+ST_OK, ST_BAD_ENCODING, ST_NOT_ON_CURVE, ST_NOT_IN_SUBGROUP, ST_IDENTITY = 0, 1, 2, 3, 4
+
+
+def decode_batch(pk48, sig96):
+    """PublicKey::try_from / Signature::try_from for a batch (bls.rs:219-242, 316-339): uint8 cuda tensors [n,48], [n,96] ->
+    (pk_xy [n,12] int64, sig_xy [n,24] int64, status [n,2] int32)."""
+    torch = _require_cuda()
+    n = pk48.shape[0]
+    assert pk48.shape == (n, 48) and sig96.shape == (n, 96) and pk48.is_contiguous() and sig96.is_contiguous()
+    pk_xy = torch.empty((n, 12), dtype=torch.int64, device=pk48.device)
+    sig_xy = torch.empty((n, 24), dtype=torch.int64, device=pk48.device)
+    status = torch.empty((n, 2), dtype=torch.int32, device=pk48.device)
+    rc = lib().blsw_decode_batch(pk48.data_ptr(), sig96.data_ptr(), n, pk_xy.data_ptr(), sig_xy.data_ptr(), status.data_ptr(),
+                                 torch.cuda.current_stream(pk48.device).cuda_stream)
+    if rc:
+        raise BlswError("blsw_decode_batch failed: %d" % rc)
+    return pk_xy, sig_xy, status
+
+
+def verify_bytes_batch(pk48, msg, sig96):
+    """tests/tests.rs:239-268 semantics on the GPU: decode, run the gadget, accept iff both points decode to non-identity
+    subgroup points and the in-circuit result is true. Returns a bool tensor [n]."""
+    torch = _require_cuda()
+    pk_xy, sig_xy, status = decode_batch(pk48, sig96)
+    g = BlsSignatureVerifyGadget(pk48.shape[0], msg.shape[1], device=pk48.device, want_witness=False)
+    res = g.verify(ParametersVar(), PublicKeyVar.new_witness(pk_xy), msg, SignatureVar.new_witness(sig_xy))
+    torch.cuda.synchronize(pk48.device)
+    return (status[:, 0] == ST_OK) & (status[:, 1] == ST_OK) & (res == 1)
 
 
 def microbench(which, iters=4096, blocks=4096):

@@ -1,0 +1,243 @@
+// Input decode, one point per lane: ZCash-format compressed G1 / G2 points as ark-bls12-381 ^0.4.0
+// (de)serialises them (`PublicKey::try_from` / `Signature::try_from` -> deserialize_compressed, src/bls.rs:219-242,
+// 316-339) -> affine Montgomery coordinates + a status code. Checks: flags, x < p, on curve, prime-order subgroup.
+// Pinned by tests/test_cases/deserialization_G1/*.json (10) and deserialization_G2/*.json (12).
+#pragma once
+#include "fp.cuh"
+
+namespace blsw {
+
+#define BLSW_SQRT_EXP_WORDS                                                                                                               \
+    {                                                                                                                                     \
+        0xffffeaabu, 0xee7fbfffu, 0xac54ffffu, 0x07aaffffu, 0x3dac3d89u, 0xd9cc34a8u, 0x3ce144afu, 0xd91dd2e1u, 0x90d2eb35u, 0x92c6e9edu, \
+            0x8e5ff9a6u, 0x0680447au                                                                                                      \
+    }
+#define BLSW_R_WORDS                                                                                             \
+    {                                                                                                            \
+        0x00000001u, 0xffffffffu, 0xfffe5bfeu, 0x53bda402u, 0x09a1d805u, 0x3339d808u, 0x299d7d48u, 0x73eda753u \
+    }
+enum { DEC_OK = 0, DEC_BAD_ENCODING = 1, DEC_NOT_ON_CURVE = 2, DEC_NOT_IN_SUBGROUP = 3, DEC_IDENTITY = 4 };
+
+// 48 big-endian bytes (top three bits already masked by the caller) -> canonical limbs; false if >= p
+BLSW_FN bool fp_from_be48(const uint8_t* in, uint8_t mask0, Fp& out_mont) {
+    constexpr uint32_t P[12] = BLSW_P_LIMBS;
+    constexpr uint32_t R2[12] = BLSW_R2_LIMBS;
+    Fp c;
+    for (int w = 0; w < 12; w++) {
+        const uint8_t* b = in + 44 - 4 * w;
+        uint32_t b0 = b[0];
+        if (w == 11) b0 &= mask0;
+        c.l[w] = (b0 << 24) | ((uint32_t)b[1] << 16) | ((uint32_t)b[2] << 8) | b[3];
+    }
+    uint32_t borrow = 0;
+    for (int i = 0; i < 12; i++) (void)subb32(c.l[i], P[i], borrow);
+    if (!borrow) return false;  // c >= p
+    Fp r2;
+    for (int i = 0; i < 12; i++) r2.l[i] = R2[i];
+    out_mont = fp_mul(c, r2);
+    return true;
+}
+// a^((p+1)/4); true iff a is a square (then out^2 == a)
+BLSW_FN bool fp_sqrt(const Fp& a, Fp& out) {
+    constexpr uint32_t E[12] = BLSW_SQRT_EXP_WORDS;
+    Fp r = a;  // bit 378 is the top bit of the exponent
+#pragma unroll 1
+    for (int i = 377; i >= 0; i--) {
+        r = fp_sqr(r);
+        if ((E[i >> 5] >> (i & 31)) & 1) r = fp_mul(r, a);
+    }
+    out = r;
+    return fp_eq(fp_sqr(r), a);
+}
+// canonical comparison a > -a  (ark-serialize "lexicographically largest" flag)
+BLSW_FN bool fp_lex_largest(const Fp& a) {
+    Fp ca = fp_to_canonical(a), cn = fp_to_canonical(fp_neg(a));
+    for (int i = 11; i >= 0; i--) {
+        if (ca.l[i] > cn.l[i]) return true;
+        if (ca.l[i] < cn.l[i]) return false;
+    }
+    return false;
+}
+BLSW_FN int fp_cmp_canonical(const Fp& a, const Fp& b) {
+    Fp ca = fp_to_canonical(a), cb = fp_to_canonical(b);
+    for (int i = 11; i >= 0; i--) {
+        if (ca.l[i] > cb.l[i]) return 1;
+        if (ca.l[i] < cb.l[i]) return -1;
+    }
+    return 0;
+}
+BLSW_FN bool fp2_lex_largest(const Fp2& a) {  // c1 is the most significant component
+    Fp2 n = fp2_neg(a);
+    int c = fp_cmp_canonical(a.c1, n.c1);
+    if (c != 0) return c > 0;
+    return fp_cmp_canonical(a.c0, n.c0) > 0;
+}
+BLSW_FN bool fp2_sqrt(const Fp2& a, Fp2& out) {
+    if (fp2_is_zero(a)) {
+        out = a;
+        return true;
+    }
+    Fp r;
+    if (fp_is_zero(a.c1)) {
+        if (fp_sqrt(a.c0, r)) {
+            out = {r, fp_zero()};
+            return true;
+        }
+        if (fp_sqrt(fp_neg(a.c0), r)) {
+            out = {fp_zero(), r};
+            return true;
+        }
+        return false;
+    }
+    Fp alpha;
+    if (!fp_sqrt(fp_add(fp_sqr(a.c0), fp_sqr(a.c1)), alpha)) return false;
+    // two_inv in Montgomery form
+    constexpr uint32_t TI[12] = {0x00015554u, 0x18040000u, 0x3ab00001u, 0x85500005u, 0x253c276fu, 0x633cb57cu,
+                                 0x31ebb502u, 0x6e22d1ecu, 0xf2d14ca2u, 0xd3916126u, 0x1a006596u, 0x17fbb857u};
+    Fp two_inv;
+    for (int i = 0; i < 12; i++) two_inv.l[i] = TI[i];
+    Fp delta = fp_mul(fp_add(a.c0, alpha), two_inv);
+    Fp x0;
+    if (!fp_sqrt(delta, x0)) {
+        delta = fp_mul(fp_sub(a.c0, alpha), two_inv);
+        if (!fp_sqrt(delta, x0)) return false;
+    }
+    Fp x1 = fp_mul(a.c1, fp_inv(fp_dbl(x0)));
+    Fp2 rr = {x0, x1};
+    Fp2 chk = fp2_sqr(rr);
+    if (!(fp_eq(chk.c0, a.c0) && fp_eq(chk.c1, a.c1))) return false;
+    out = rr;
+    return true;
+}
+
+// ---- value-only Jacobian arithmetic over Fp2 (a = 0) for the G2 subgroup check
+struct Jac2 {
+    Fp2 x, y, z;
+};
+BLSW_FN Jac2 jac2_dbl(const Jac2& p) {
+    Fp2 A = fp2_sqr(p.x), B = fp2_sqr(p.y), C = fp2_sqr(B);
+    Fp2 t = fp2_add(p.x, B);
+    Fp2 D = fp2_dbl(fp2_sub(fp2_sub(fp2_sqr(t), A), C));
+    Fp2 E = fp2_add(fp2_dbl(A), A);
+    Fp2 F = fp2_sqr(E);
+    Fp2 x3 = fp2_sub(F, fp2_dbl(D));
+    Fp2 c8 = fp2_dbl(fp2_dbl(fp2_dbl(C)));
+    Fp2 y3 = fp2_sub(fp2_mul(E, fp2_sub(D, x3)), c8);
+    Fp2 z3 = fp2_dbl(fp2_mul(p.y, p.z));
+    return {x3, y3, z3};
+}
+// complete-enough mixed addition for the double-and-add ladder [r]P: handles p = identity, p = +-q
+BLSW_FN Jac2 jac2_add_mixed(const Jac2& p, const Fp2& qx, const Fp2& qy) {
+    if (fp2_is_zero(p.z)) return {qx, qy, fp2_one()};
+    Fp2 z1z1 = fp2_sqr(p.z);
+    Fp2 u2 = fp2_mul(qx, z1z1);
+    Fp2 s2 = fp2_mul(fp2_mul(qy, p.z), z1z1);
+    Fp2 h = fp2_sub(u2, p.x);
+    Fp2 rr = fp2_dbl(fp2_sub(s2, p.y));
+    if (fp2_is_zero(h)) {
+        if (fp2_is_zero(rr)) return jac2_dbl(p);
+        return {fp2_one(), fp2_one(), fp2_zero()};
+    }
+    Fp2 hh = fp2_sqr(h);
+    Fp2 i = fp2_dbl(fp2_dbl(hh));
+    Fp2 j = fp2_mul(h, i);
+    Fp2 v = fp2_mul(p.x, i);
+    Fp2 x3 = fp2_sub(fp2_sub(fp2_sqr(rr), j), fp2_dbl(v));
+    Fp2 y3 = fp2_sub(fp2_mul(rr, fp2_sub(v, x3)), fp2_dbl(fp2_mul(p.y, j)));
+    Fp2 z3 = fp2_sub(fp2_sub(fp2_sqr(fp2_add(p.z, h)), z1z1), hh);
+    return {x3, y3, z3};
+}
+struct Jac1v {
+    Fp x, y, z;
+};
+BLSW_FN Jac1v jac1v_dbl(const Jac1v& p) {
+    Fp A = fp_sqr(p.x), B = fp_sqr(p.y), C = fp_sqr(B);
+    Fp t = fp_add(p.x, B);
+    Fp D = fp_dbl(fp_sub(fp_sub(fp_sqr(t), A), C));
+    Fp E = fp_add(fp_dbl(A), A);
+    Fp F = fp_sqr(E);
+    Fp x3 = fp_sub(F, fp_dbl(D));
+    Fp c8 = fp_dbl(fp_dbl(fp_dbl(C)));
+    Fp y3 = fp_sub(fp_mul(E, fp_sub(D, x3)), c8);
+    Fp z3 = fp_dbl(fp_mul(p.y, p.z));
+    return {x3, y3, z3};
+}
+BLSW_FN Jac1v jac1v_add_mixed(const Jac1v& p, const Fp& qx, const Fp& qy) {
+    if (fp_is_zero(p.z)) return {qx, qy, fp_one()};
+    Fp z1z1 = fp_sqr(p.z);
+    Fp u2 = fp_mul(qx, z1z1);
+    Fp s2 = fp_mul(fp_mul(qy, p.z), z1z1);
+    Fp h = fp_sub(u2, p.x);
+    Fp rr = fp_dbl(fp_sub(s2, p.y));
+    if (fp_is_zero(h)) {
+        if (fp_is_zero(rr)) return jac1v_dbl(p);
+        return {fp_one(), fp_one(), fp_zero()};
+    }
+    Fp hh = fp_sqr(h);
+    Fp i = fp_dbl(fp_dbl(hh));
+    Fp j = fp_mul(h, i);
+    Fp v = fp_mul(p.x, i);
+    Fp x3 = fp_sub(fp_sub(fp_sqr(rr), j), fp_dbl(v));
+    Fp y3 = fp_sub(fp_mul(rr, fp_sub(v, x3)), fp_dbl(fp_mul(p.y, j)));
+    Fp z3 = fp_sub(fp_sub(fp_sqr(fp_add(p.z, h)), z1z1), hh);
+    return {x3, y3, z3};
+}
+
+// G1: 48 bytes -> (x, y) Montgomery ((0,0) for the identity) + status
+BLSW_FN int g1_decode(const uint8_t* in, Fp& x, Fp& y) {
+    constexpr uint32_t RW[8] = BLSW_R_WORDS;
+    x = fp_zero();
+    y = fp_zero();
+    const bool c = in[0] >> 7, inf = (in[0] >> 6) & 1, sort = (in[0] >> 5) & 1;
+    if (sort && (!c || inf)) return DEC_BAD_ENCODING;
+    if (!c) return DEC_BAD_ENCODING;
+    if (inf) return DEC_IDENTITY;
+    Fp px;
+    if (!fp_from_be48(in, 0x1f, px)) return DEC_BAD_ENCODING;
+    Fp rhs = fp_add(fp_mul(fp_sqr(px), px), fp_from_u32(4));
+    Fp py;
+    if (!fp_sqrt(rhs, py)) return DEC_NOT_ON_CURVE;
+    if (fp_lex_largest(py) != sort) py = fp_neg(py);
+    // [r]P == O ?
+    Jac1v acc = {px, py, fp_one()};
+#pragma unroll 1
+    for (int i = 253; i >= 0; i--) {
+        acc = jac1v_dbl(acc);
+        if ((RW[i >> 5] >> (i & 31)) & 1) acc = jac1v_add_mixed(acc, px, py);
+    }
+    if (!fp_is_zero(acc.z)) return DEC_NOT_IN_SUBGROUP;
+    x = px;
+    y = py;
+    return DEC_OK;
+}
+// G2: 96 bytes = x.c1 || x.c0 -> (x.c0, x.c1, y.c0, y.c1) + status
+BLSW_FN int g2_decode(const uint8_t* in, Fp2& x, Fp2& y) {
+    constexpr uint32_t RW[8] = BLSW_R_WORDS;
+    x = fp2_zero();
+    y = fp2_zero();
+    const bool c = in[0] >> 7, inf = (in[0] >> 6) & 1, sort = (in[0] >> 5) & 1;
+    if (sort && (!c || inf)) return DEC_BAD_ENCODING;
+    if (!c) return DEC_BAD_ENCODING;
+    if (inf) return DEC_IDENTITY;
+    Fp2 px;
+    if (!fp_from_be48(in, 0x1f, px.c1)) return DEC_BAD_ENCODING;
+    if (!fp_from_be48(in + 48, 0xff, px.c0)) return DEC_BAD_ENCODING;
+    Fp four = fp_from_u32(4);
+    Fp2 b = {four, four};
+    Fp2 rhs = fp2_add(fp2_mul(fp2_sqr(px), px), b);
+    Fp2 py;
+    if (!fp2_sqrt(rhs, py)) return DEC_NOT_ON_CURVE;
+    if (fp2_lex_largest(py) != sort) py = fp2_neg(py);
+    Jac2 acc = {px, py, fp2_one()};
+#pragma unroll 1
+    for (int i = 253; i >= 0; i--) {
+        acc = jac2_dbl(acc);
+        if ((RW[i >> 5] >> (i & 31)) & 1) acc = jac2_add_mixed(acc, px, py);
+    }
+    if (!fp2_is_zero(acc.z)) return DEC_NOT_IN_SUBGROUP;
+    x = px;
+    y = py;
+    return DEC_OK;
+}
+
+}  // namespace blsw

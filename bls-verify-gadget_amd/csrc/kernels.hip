@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include "chains.cuh"
+#include "decode.cuh"
 #include "layout.h"
 
 using namespace blsw;
@@ -158,7 +159,8 @@ __global__ __launch_bounds__(64) void k_sha_values(Group g) {
 // instruction of a wave covers 1 KiB contiguous. ~10 VALU instructions per 16 bytes stored; streaming (nontemporal)
 // stores: the tensor is not read again on the device. blockIdx.y = instance of the step.
 #define BLSW_EXPAND_ITERS 32
-template <bool NT>
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <int NT>
 __global__ __launch_bounds__(384) void k_sha_expand(const uint32_t* __restrict__ bits, uint64_t N, uint64_t first, uint32_t sha_bits,
                                                     uint32_t off_expand, uint64_t* __restrict__ d_witness, uint64_t stride) {
     constexpr uint32_t R1[12] = BLSW_R1_LIMBS;
@@ -179,7 +181,15 @@ __global__ __launch_bounds__(384) void k_sha_expand(const uint32_t* __restrict__
             uint32_t w = b[(uint64_t)(e >> 5) * N];
             uint32_t m = 0u - ((w >> (e & 31)) & 1u);
             uint4 v = make_uint4(rc.x & m, rc.y & m, rc.z & m, rc.w & m);
-            if (NT) {
+            if (NT == 2) {
+                uint4* dst = &out[(uint64_t)e * 3 + c];
+                u32x4 vv = {v.x, v.y, v.z, v.w};
+                asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(vv) : "memory");
+            } else if (NT == 3) {
+                uint4* dst = &out[(uint64_t)e * 3 + c];
+                u32x4 vv = {v.x, v.y, v.z, v.w};
+                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(vv) : "memory");
+            } else if (NT == 1) {
                 __builtin_nontemporal_store(v.x, &out[(uint64_t)e * 3 + c].x);
                 __builtin_nontemporal_store(v.y, &out[(uint64_t)e * 3 + c].y);
                 __builtin_nontemporal_store(v.z, &out[(uint64_t)e * 3 + c].z);
@@ -321,6 +331,31 @@ __global__ __launch_bounds__(64) void k_pairing(Group g) {
     if (r) r[id.i] = res ? 1 : 0;
 }
 
+// input decode: lanes [0, n) decompress pk (48 B), lanes [n, 2n) decompress sig (96 B); status[i][0] / status[i][1]
+__global__ __launch_bounds__(64) void k_decode(const uint8_t* __restrict__ pk48, const uint8_t* __restrict__ sig96, uint64_t n, uint64_t* pk_xy,
+                                               uint64_t* sig_xy, int32_t* status) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 2 * n) return;
+    if (t < n) {
+        Fp x, y;
+        int st = g1_decode(pk48 + t * 48, x, y);
+        Fp* o = reinterpret_cast<Fp*>(pk_xy + t * 12);
+        st_fp(o, x);
+        st_fp(o + 1, y);
+        status[2 * t] = st;
+    } else {
+        uint64_t i = t - n;
+        Fp2 x, y;
+        int st = g2_decode(sig96 + i * 96, x, y);
+        Fp* o = reinterpret_cast<Fp*>(sig_xy + i * 24);
+        st_fp(o, x.c0);
+        st_fp(o + 1, x.c1);
+        st_fp(o + 2, y.c0);
+        st_fp(o + 3, y.c1);
+        status[2 * i + 1] = st;
+    }
+}
+
 // H(m) projective -> affine (hash_to_g2 batch output)
 __global__ __launch_bounds__(64) void k_h_to_affine(uint64_t n, Workspace ws, uint64_t* d_out) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -412,17 +447,17 @@ static unsigned place_lds_bytes() {
     static int v = -1;
     if (v < 0) {
         const char* s = getenv("BLSW_PLACE_LDS");
-        v = s ? atoi(s) : 80000;  // <= 2 placement workgroups per CU: leaves issue slots and cache to the chain waves
+        v = s ? atoi(s) : 0;  // optional occupancy limiter for the placement kernel (bytes of dynamic LDS per workgroup)
     }
     return (unsigned)v;
 }
-static bool place_nt() {
+static int place_nt() {
     static int v = -1;
     if (v < 0) {
         const char* s = getenv("BLSW_EXPAND_NT");
         v = s ? atoi(s) : 1;
     }
-    return v != 0;
+    return v;
 }
 static int launch_group(blsw_engine* e, hipStream_t user_stream) {
     GroupBuf& b = e->buf[e->cur];
@@ -473,12 +508,15 @@ static int launch_group(blsw_engine* e, hipStream_t user_stream) {
         if (!d.out) continue;
         dim3 grid((e->L.sha_bits + 128 * BLSW_EXPAND_ITERS - 1) / (128 * BLSW_EXPAND_ITERS), (unsigned)e->n);
         hipEventRecord(e->ev_exp0, e->place);
-        if (place_nt())
-            hipLaunchKernelGGL(k_sha_expand<true>, grid, dim3(384), place_lds_bytes(), e->place, g.ws.bits, g.N, (uint64_t)s * e->n, e->L.sha_bits,
-                               e->L.off_expand, d.out, d.out_stride);
-        else
-            hipLaunchKernelGGL(k_sha_expand<false>, grid, dim3(384), place_lds_bytes(), e->place, g.ws.bits, g.N, (uint64_t)s * e->n, e->L.sha_bits,
-                               e->L.off_expand, d.out, d.out_stride);
+#define BLSW_LAUNCH_EXPAND(MODE)                                                                                                                   \
+    hipLaunchKernelGGL(k_sha_expand<MODE>, grid, dim3(384), place_lds_bytes(), e->place, g.ws.bits, g.N, (uint64_t)s * e->n, e->L.sha_bits, \
+                       e->L.off_expand, d.out, d.out_stride)
+        switch (place_nt()) {
+            case 0: BLSW_LAUNCH_EXPAND(0); break;
+            case 2: BLSW_LAUNCH_EXPAND(2); break;
+            case 3: BLSW_LAUNCH_EXPAND(3); break;
+            default: BLSW_LAUNCH_EXPAND(1); break;
+        }
         hipEventRecord(e->ev_exp1, e->place);
         e->have_expand_timing = 1;
         if (e->staged) {
@@ -640,6 +678,12 @@ int blsw_hash_to_g2_batch(const uint8_t* d_msg, uint32_t msg_len, uint64_t n, ui
     hipLaunchKernelGGL(k_map, dim3(g2), dim3(64), 0, st, g);
     hipLaunchKernelGGL(k_cofactor, dim3(g1), dim3(64), 0, st, g);
     hipLaunchKernelGGL(k_h_to_affine, dim3(g1), dim3(64), 0, st, n, g.ws, d_out_affine);
+    return hip_ok(hipGetLastError(), "launch");
+}
+int blsw_decode_batch(const uint8_t* d_pk48, const uint8_t* d_sig96, uint64_t n, uint64_t* d_pk_xy, uint64_t* d_sig_xy, int32_t* d_status, void* stream_) {
+    if (!d_pk48 || !d_sig96 || !d_pk_xy || !d_sig_xy || !d_status || n == 0) return BLSW_ERR_ARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream_);
+    hipLaunchKernelGGL(k_decode, dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, st, d_pk48, d_sig96, n, d_pk_xy, d_sig_xy, d_status);
     return hip_ok(hipGetLastError(), "launch");
 }
 int blsw_hash_to_g2_workspace_bytes(uint64_t n, uint32_t msg_len, uint64_t* bytes) {

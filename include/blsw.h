@@ -78,6 +78,14 @@ int blsw_engine_flush(blsw_engine_t* e, void* stream);
 /* duration (ms) of the last bit->Fp expansion kernel (HIP events on the stream it ran on); blocks until it has finished */
 int blsw_engine_last_expand_ms(blsw_engine_t* e, float* ms);
 
+/* Input decode (PublicKey::try_from / Signature::try_from -> deserialize_compressed, src/bls.rs:219-242, 316-339):
+ *   d_pk48 [n][48], d_sig96 [n][96]  ZCash-format compressed points
+ *   d_pk_xy [n][12], d_sig_xy [n][24] affine Montgomery coordinates in the layout blsw_engine_submit takes (identity / failure = zeros)
+ *   d_status [n][2] int32: BLSW_ST_* of the key and of the signature (flags, x < p, on curve, prime-order subgroup;
+ *   BLSW_ST_IDENTITY = well-formed encoding of the point at infinity)
+ * tests/tests.rs:244-263 semantics: an instance verifies iff both statuses are BLSW_ST_OK and the gadget result is 1. */
+int blsw_decode_batch(const uint8_t* d_pk48, const uint8_t* d_sig96, uint64_t n, uint64_t* d_pk_xy, uint64_t* d_sig_xy, int32_t* d_status, void* stream);
+
 /* hash_to_g2 only (src/hasher.rs:727-740 / src/bls.rs:477-493): d_out_affine [n][24] u64 (x.c0, x.c1, y.c0, y.c1) Montgomery */
 int blsw_hash_to_g2_workspace_bytes(uint64_t n, uint32_t msg_len, uint64_t* bytes);
 int blsw_hash_to_g2_batch(const uint8_t* d_msg, uint32_t msg_len, uint64_t n, uint64_t* d_out_affine, void* d_workspace, uint64_t workspace_bytes,

@@ -5,6 +5,7 @@
 #include <cstring>
 #include <vector>
 #include "../../bls-verify-gadget_amd/csrc/chains.cuh"
+#include "../../bls-verify-gadget_amd/csrc/decode.cuh"
 #include "../../bls-verify-gadget_amd/csrc/layout.h"
 
 using namespace blsw;
@@ -57,6 +58,22 @@ int hostsim_witness(const uint64_t* pk_xy, const uint8_t* msg, uint32_t msg_len,
     bool res = chain_final_exp_is_one({base, L.off_final_exp}, {base, L.off_is_one}, fm);
     (void)seg_ends;
     return res ? 1 : 0;
+}
+int hostsim_g1_decode(const uint8_t* in, uint64_t* out_xy) {
+    Fp x, y;
+    int st = g1_decode(in, x, y);
+    memcpy(out_xy, x.l, 48);
+    memcpy(out_xy + 6, y.l, 48);
+    return st;
+}
+int hostsim_g2_decode(const uint8_t* in, uint64_t* out_xy) {
+    Fp2 x, y;
+    int st = g2_decode(in, x, y);
+    memcpy(out_xy, x.c0.l, 48);
+    memcpy(out_xy + 6, x.c1.l, 48);
+    memcpy(out_xy + 12, y.c0.l, 48);
+    memcpy(out_xy + 18, y.c1.l, 48);
+    return st;
 }
 // field micro-checks
 void hostsim_fp_mul(const uint64_t* a, const uint64_t* b, uint64_t* r) {

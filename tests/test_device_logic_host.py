@@ -76,3 +76,55 @@ def test_synthetic_and_edge_cases(oracle):
 def test_other_message_lengths(oracle, msg):
     pk, _, sig, _ = synth.make_batch(oracle, 16)
     _check(oracle, pk[1], msg, sig[1])
+
+
+def _hs_decode(kind, data):
+    import ctypes
+
+    H = hostsim_lib.load()
+    n = 12 if kind == "g1" else 24
+    out = np.zeros(n, dtype=np.uint64)
+    buf = (ctypes.c_uint8 * len(data)).from_buffer_copy(data)
+    fn = H.hostsim_g1_decode if kind == "g1" else H.hostsim_g2_decode
+    st = fn(buf, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)))
+    return st, out
+
+
+@pytest.mark.parametrize("name,case", eth_cases("deserialization_G1"))
+def test_decode_g1_device_logic(oracle, name, case):
+    # tests/tests.rs:336-349; wrong lengths are rejected before the kernel (the ABI takes fixed 48-byte records)
+    b = unhex(case["input"]["pubkey"])
+    if len(b) != 48:
+        assert case["output"] is False
+        return
+    st, xy = _hs_decode("g1", b)
+    assert (st in (0, 4)) == case["output"]
+    ost, oxy, oinf = oracle.g1_decompress(b)
+    assert (ost == 0) == (st in (0, 4))
+    if st == 0:
+        assert np.array_equal(xy, oxy)
+
+
+@pytest.mark.parametrize("name,case", eth_cases("deserialization_G2"))
+def test_decode_g2_device_logic(oracle, name, case):
+    b = unhex(case["input"]["signature"])
+    if len(b) != 96:
+        assert case["output"] is False
+        return
+    st, xy = _hs_decode("g2", b)
+    assert (st in (0, 4)) == case["output"]
+    ost, oxy, oinf = oracle.g2_decompress(b)
+    assert (ost == 0) == (st in (0, 4))
+    if st == 0:
+        assert np.array_equal(xy, oxy)
+
+
+def test_decode_all_verify_fixture_points(oracle):
+    for name, case in eth_cases("verify"):
+        for kind, key in (("g1", "pubkey"), ("g2", "signature")):
+            b = unhex(case["input"][key])
+            st, xy = _hs_decode(kind, b)
+            ost, oxy, oinf = (oracle.g1_decompress if kind == "g1" else oracle.g2_decompress)(b)
+            assert (ost == 0) == (st in (0, 4)), name
+            if st == 0:
+                assert np.array_equal(xy, oxy), name
