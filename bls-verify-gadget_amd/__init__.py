@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(HERE, "libblsw.so")
 FP_BYTES = 48
 _LAYOUT_FIELDS = (
     "msg_len n_instance_vars n_witness sha_bits off_msg off_pk_alloc off_sig_alloc off_pk_not_zero off_expand off_map0 off_map1 "
-    "off_add off_cofactor off_prep_h off_prep_pk off_prep_sig off_miller off_final_exp off_is_one"
+    "off_add off_cofactor off_prep_h off_prep_pk off_prep_sig off_miller off_final_exp off_is_one n_keys off_keys off_bitmap off_count off_agg"
 ).split()
 
 
@@ -60,6 +60,9 @@ def lib():
         L.blsw_engine_last_expand_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
         L.blsw_hash_to_g2_workspace_bytes.argtypes = [u64, u32, ctypes.POINTER(u64)]
         L.blsw_hash_to_g2_batch.argtypes = [vp, u32, u64, vp, vp, u64, vp]
+        L.blsw_layout_aggregate.argtypes = [u32, u32, ctypes.POINTER(blsw_layout_t)]
+        L.blsw_aggregate_workspace_bytes.argtypes = [u64, u32, u32, ctypes.POINTER(u64)]
+        L.blsw_aggregate_verify_batch.argtypes = [vp, vp, u32, vp, vp, u32, u64, vp, u64, vp, vp, vp, u64, vp]
         L.blsw_decode_batch.argtypes = [vp, vp, u64, vp, vp, vp, vp]
         L.blsw_microbench.argtypes = [ctypes.c_int, u32, u32, ctypes.POINTER(ctypes.c_double)]
         _lib = L
@@ -67,7 +70,8 @@ def lib():
 
 
 EXPORTED_SYMBOLS = ["blsw_version", "blsw_layout", "blsw_engine_workspace_bytes", "blsw_engine_create", "blsw_engine_destroy", "blsw_engine_submit",
-                    "blsw_engine_flush", "blsw_engine_last_expand_ms", "blsw_hash_to_g2_workspace_bytes", "blsw_hash_to_g2_batch", "blsw_decode_batch", "blsw_microbench"]
+                    "blsw_engine_flush", "blsw_engine_last_expand_ms", "blsw_hash_to_g2_workspace_bytes", "blsw_hash_to_g2_batch", "blsw_decode_batch", "blsw_layout_aggregate", "blsw_aggregate_workspace_bytes",
+                    "blsw_aggregate_verify_batch", "blsw_microbench"]
 
 
 def layout(msg_len=32):
@@ -238,6 +242,40 @@ def verify_bytes_batch(pk48, msg, sig96):
     res = g.verify(ParametersVar(), PublicKeyVar.new_witness(pk_xy), msg, SignatureVar.new_witness(sig_xy))
     torch.cuda.synchronize(pk48.device)
     return (status[:, 0] == ST_OK) & (status[:, 1] == ST_OK) & (res == 1)
+
+
+def layout_aggregate(msg_len, n_keys):
+    L = blsw_layout_t()
+    rc = lib().blsw_layout_aggregate(msg_len, n_keys, ctypes.byref(L))
+    if rc:
+        raise BlswError("blsw_layout_aggregate failed: %d" % rc)
+    return {n: getattr(L, n) for n in _LAYOUT_FIELDS}
+
+
+def aggregate_verify(parameters, public_keys, bitmap, message, signature, want_witness=True):
+    """BlsSignatureVerifyGadget::aggregate_verify (constraints.rs:153-167) for n instances: public_keys.xy [n, K, 12] int64,
+    bitmap [n, K] uint8 (0/1), message [n, msg_len] uint8, signature.xy [n, 24]. Returns (result int32 [n], count int32 [n], witness)."""
+    torch = _require_cuda()
+    assert isinstance(parameters, ParametersVar)
+    pks, sig = public_keys.xy, signature.xy
+    n, K = pks.shape[0], pks.shape[1]
+    assert K >= 1 and bitmap.shape == (n, K)  # constraints.rs:160-162: equal lengths, at least one key
+    msg_len = message.shape[1]
+    lay = layout_aggregate(msg_len, K)
+    wb = ctypes.c_uint64(0)
+    lib().blsw_aggregate_workspace_bytes(n, msg_len, K, ctypes.byref(wb))
+    dev = pks.device
+    ws = torch.empty(wb.value, dtype=torch.uint8, device=dev)
+    res = torch.empty(n, dtype=torch.int32, device=dev)
+    cnt = torch.empty(n, dtype=torch.int32, device=dev)
+    wit = torch.empty((n, lay["n_witness"], 6), dtype=torch.int64, device=dev) if want_witness else None
+    rc = lib().blsw_aggregate_verify_batch(pks.contiguous().data_ptr(), bitmap.contiguous().data_ptr(), K, sig.data_ptr(), message.data_ptr(), msg_len, n,
+                                           wit.data_ptr() if wit is not None else None, lay["n_witness"], res.data_ptr(), cnt.data_ptr(), ws.data_ptr(),
+                                           ws.numel(), torch.cuda.current_stream(dev).cuda_stream)
+    if rc:
+        raise BlswError("blsw_aggregate_verify_batch failed: %d" % rc)
+    torch.cuda.synchronize(dev)
+    return res, cnt, wit
 
 
 def microbench(which, iters=4096, blocks=4096):

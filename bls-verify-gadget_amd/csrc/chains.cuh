@@ -27,7 +27,8 @@ BLSW_FN bool fp_is_eq_pre_w(Emitter& e, const Fp& diff, const Fp& diff_inv) {
 struct G1ChainOut {
     Fp ax, ay;  // prepare_g1(pk): affine coordinates (after the infinity select)
 };
-BLSW_FN G1ChainOut chain_g1_alloc(Emitter e_alloc, Emitter e_notzero, Emitter e_prep, const Fp& pkx, const Fp& pky) {
+// G1Var::new_variable(Witness): native g*(h^-1 mod r), allocation, in-circuit multiplication by the cofactor
+BLSW_FN Proj<OpsFp> chain_g1_alloc_only(Emitter e_alloc, const Fp& pkx, const Fp& pky) {
     constexpr uint32_t H1[4] = BLSW_H1_WORDS;
     constexpr uint32_t H1INV[8] = BLSW_H1INV_WORDS;
     bool inf = fp_is_zero(pkx) && fp_is_zero(pky);
@@ -48,8 +49,10 @@ BLSW_FN G1ChainOut chain_g1_alloc(Emitter e_alloc, Emitter e_notzero, Emitter e_
     e_alloc.put(ge.x);
     e_alloc.put(ge.y);
     e_alloc.put(ge.z);
-    Proj<OpsFp> pk = proj_mul_bits_be_w<OpsFp>(e_alloc, ge, H1, BLSW_H1_NBITS);
-    // pk.enforce_not_equal(G1Var::zero()), zero = (0, 1, 0) constant
+    return proj_mul_bits_be_w<OpsFp>(e_alloc, ge, H1, BLSW_H1_NBITS);
+}
+// pk.enforce_not_equal(G1Var::zero()) (constraints.rs:97-99) and prepare_g1(pk) (constraints.rs:119) on a variable pk
+BLSW_FN G1ChainOut chain_g1_post(Emitter e_notzero, Emitter e_prep, const Proj<OpsFp>& pk) {
     Fp nz = fp_neg(pk.z);
     Fp nzi = fp_inv(nz);
     bool x_eq = fp_is_eq_pre_w(e_notzero, fp_zero(), fp_zero());  // (x*0) vs (0*z)
@@ -68,6 +71,33 @@ BLSW_FN G1ChainOut chain_g1_alloc(Emitter e_alloc, Emitter e_notzero, Emitter e_
     o.ax = fp_select_w(e_prep, infinity, fp_zero(), nzx);
     o.ay = fp_select_w(e_prep, infinity, fp_zero(), nzy);
     return o;
+}
+BLSW_FN G1ChainOut chain_g1_alloc(Emitter e_alloc, Emitter e_notzero, Emitter e_prep, const Fp& pkx, const Fp& pky) {
+    Proj<OpsFp> pk = chain_g1_alloc_only(e_alloc, pkx, pky);
+    return chain_g1_post(e_notzero, e_prep, pk);
+}
+// mapped_aggregate (constraints.rs:169-191): count = UInt32 witness 0; per key: ret += bit.select(key, zero) and
+// count = addmany(count, bit.select(1, 0)). K::ld(k) returns key k of this instance as a projective point.
+template <class K>
+BLSW_FN Proj<OpsFp> chain_mapped_aggregate(Emitter e_count, Emitter e_agg, const K& keys, const uint8_t* bitmap, uint32_t n_keys, uint32_t* count_out) {
+    for (int i = 0; i < 32; i++) e_count.put_bool(false);  // UInt32::new_variable(|| Ok(0), Witness)
+    Proj<OpsFp> ret = {fp_zero(), fp_one(), fp_zero()};
+    uint32_t count = 0;
+#pragma unroll 1
+    for (uint32_t k = 0; k < n_keys; k++) {
+        bool bit = bitmap[k] != 0;
+        Proj<OpsFp> key = keys.ld(k);
+        Proj<OpsFp> sel;
+        sel.x = fp_select_w(e_agg, bit, key.x, fp_zero());
+        sel.y = fp_select_w(e_agg, bit, key.y, fp_one());
+        sel.z = fp_select_w(e_agg, bit, key.z, fp_zero());
+        ret = (k == 0) ? sel : proj_add_w<OpsFp, 0>(e_agg, ret, sel);  // zero + sel returns sel (constant special case)
+        uint64_t sum = (uint64_t)count + (bit ? 1u : 0u);
+        for (int i = 0; i < 33; i++) e_agg.put_bool((sum >> i) & 1);  // addmany of two operands: 33 result bits
+        count = (uint32_t)sum;
+    }
+    if (count_out) *count_out = count;
+    return ret;
 }
 
 // ------------------------------------------------------------------------------------------------ G2 allocation

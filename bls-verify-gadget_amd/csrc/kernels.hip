@@ -56,6 +56,10 @@ struct StepDesc {
     uint64_t* out;        // [n][out_stride] field elements, or nullptr (results only)
     uint64_t out_stride;  // in field elements
     int32_t* result;
+    // aggregate_verify only
+    const uint64_t* keys;   // [n][n_keys][12]
+    const uint8_t* bitmap;  // [n][n_keys]
+    uint32_t* count;        // [n]
 };
 // a group of `steps` batches of n instances each, processed by one set of launches (N = steps * n lanes per chain)
 struct Group {
@@ -230,6 +234,49 @@ __global__ __launch_bounds__(64) void k_g1(Group g) {
     G1ChainOut o = chain_g1_alloc(EMIT(g, id, off_pk_alloc), EMIT(g, id, off_pk_not_zero), EMIT(g, id, off_prep_pk), ld_fp(p), ld_fp(p + 1));
     st_fp(g.ws.pkaff + I, o.ax);
     st_fp(g.ws.pkaff + g.N + I, o.ay);
+}
+
+// aggregate_verify: lane t = k * N + I allocates key k of instance I (N * n_keys lanes), result to ws.keyproj
+__global__ __launch_bounds__(64) void k_agg_keys(Group g, Fp* keyproj) {
+    __builtin_amdgcn_s_setprio(3);
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t N = g.N, nk = g.L.n_keys;
+    if (t >= N * nk) return;
+    uint32_t k = (uint32_t)(t / N);
+    LaneId id = lane_id(g, t - (uint64_t)k * N);
+    const Fp* p = reinterpret_cast<const Fp*>(g.desc[id.s].keys + ((uint64_t)id.i * nk + k) * 12);
+    Proj<OpsFp> r = chain_g1_alloc_only(emitter(g, id, g.L.off_keys + k * SEG_PK_ALLOC, g.LS.off_keys + k * SEG_PK_ALLOC), ld_fp(p), ld_fp(p + 1));
+    Fp* o = keyproj + t;
+    st_fp(o, r.x);
+    st_fp(o + N * nk, r.y);
+    st_fp(o + 2 * N * nk, r.z);
+}
+struct KeyProjSrc {
+    const Fp* p;  // keyproj + I
+    uint64_t N, total;
+    __device__ __forceinline__ Proj<OpsFp> ld(uint32_t k) const {
+        const Fp* q = p + (uint64_t)k * N;
+        return {ld_fp(q), ld_fp(q + total), ld_fp(q + 2 * total)};
+    }
+};
+// aggregate_verify: bitmap booleans, mapped_aggregate, then pk != 0 and prepare_g1 on the aggregated key
+__global__ __launch_bounds__(64) void k_agg_sum(Group g, const Fp* keyproj) {
+    __builtin_amdgcn_s_setprio(3);
+    uint64_t I = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (I >= g.N) return;
+    LaneId id = lane_id(g, I);
+    const uint32_t nk = g.L.n_keys;
+    const uint8_t* bm = g.desc[id.s].bitmap + (uint64_t)id.i * nk;
+    Emitter eb = EMIT(g, id, off_bitmap);
+    for (uint32_t k = 0; k < nk; k++) eb.put_bool(bm[k] != 0);  // Boolean::new_witness per key (constraints.rs:414-419)
+    KeyProjSrc src = {keyproj + I, g.N, g.N * nk};
+    uint32_t count = 0;
+    Proj<OpsFp> pk = chain_mapped_aggregate(EMIT(g, id, off_count), EMIT(g, id, off_agg), src, bm, nk, &count);
+    G1ChainOut o = chain_g1_post(EMIT(g, id, off_pk_not_zero), EMIT(g, id, off_prep_pk), pk);
+    st_fp(g.ws.pkaff + I, o.ax);
+    st_fp(g.ws.pkaff + g.N + I, o.ay);
+    uint32_t* c = g.desc[id.s].count;
+    if (c) c[id.i] = count;
 }
 
 __global__ __launch_bounds__(64) void k_g2_alloc(Group g) {
@@ -632,6 +679,9 @@ int blsw_engine_submit(blsw_engine_t* e, const uint64_t* d_pk_xy, const uint64_t
     d.out = d_witness;
     d.out_stride = witness_stride;
     d.result = d_result;
+    d.keys = nullptr;
+    d.bitmap = nullptr;
+    d.count = nullptr;
     e->pending++;
     if (e->pending == e->max_steps) return launch_group(e, reinterpret_cast<hipStream_t>(stream_));
     return BLSW_OK;
@@ -670,7 +720,7 @@ int blsw_hash_to_g2_batch(const uint8_t* d_msg, uint32_t msg_len, uint64_t n, ui
     g.msg_len = msg_len;
     g.desc = d_desc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream_);
-    StepDesc h = {nullptr, nullptr, d_msg, nullptr, 0, nullptr};
+    StepDesc h = {nullptr, nullptr, d_msg, nullptr, 0, nullptr, nullptr, nullptr, nullptr};
     hipMemcpyAsync(d_desc, &h, sizeof(h), hipMemcpyHostToDevice, st);
     hipStreamSynchronize(st);  // `h` is a stack object
     const unsigned g1 = (unsigned)((n + 63) / 64), g2 = (unsigned)((2 * n + 63) / 64);
@@ -678,6 +728,66 @@ int blsw_hash_to_g2_batch(const uint8_t* d_msg, uint32_t msg_len, uint64_t n, ui
     hipLaunchKernelGGL(k_map, dim3(g2), dim3(64), 0, st, g);
     hipLaunchKernelGGL(k_cofactor, dim3(g1), dim3(64), 0, st, g);
     hipLaunchKernelGGL(k_h_to_affine, dim3(g1), dim3(64), 0, st, n, g.ws, d_out_affine);
+    return hip_ok(hipGetLastError(), "launch");
+}
+int blsw_layout_aggregate(uint32_t msg_len, uint32_t n_keys, blsw_layout_t* out) {
+    if (!out || msg_len > 65535) return BLSW_ERR_ARG;
+    make_layout(msg_len, out, n_keys);
+    return BLSW_OK;
+}
+static uint64_t agg_workspace(uint64_t n, const blsw_layout_t& L, uint64_t* off_desc, uint64_t* off_keyproj, uint64_t* off_ws) {
+    uint64_t o = 0;
+    *off_desc = o;
+    o = align_up(o + sizeof(StepDesc), 256);
+    *off_keyproj = o;
+    o = align_up(o + 3ull * n * L.n_keys * sizeof(Fp), 256);
+    *off_ws = o;
+    return o + carve(nullptr, n, L, false).total_bytes;
+}
+int blsw_aggregate_workspace_bytes(uint64_t n, uint32_t msg_len, uint32_t n_keys, uint64_t* bytes) {
+    if (!bytes || n == 0 || n_keys == 0) return BLSW_ERR_ARG;
+    blsw_layout_t L;
+    make_layout(msg_len, &L, n_keys);
+    uint64_t a, b, c;
+    *bytes = agg_workspace(n, L, &a, &b, &c);
+    return BLSW_OK;
+}
+int blsw_aggregate_verify_batch(const uint64_t* d_pks_xy, const uint8_t* d_bitmap, uint32_t n_keys, const uint64_t* d_sig_xy, const uint8_t* d_msg,
+                                uint32_t msg_len, uint64_t n, uint64_t* d_witness, uint64_t witness_stride, int32_t* d_result, uint32_t* d_count,
+                                void* d_workspace, uint64_t workspace_bytes, void* stream_) {
+    if (!d_pks_xy || !d_bitmap || n_keys == 0 || !d_sig_xy || (!d_msg && msg_len) || n == 0 || !d_workspace) return BLSW_ERR_ARG;
+    Group g;
+    make_layout(msg_len, &g.L, n_keys);
+    g.LS = g.L;
+    if (d_witness && witness_stride < g.L.n_witness) return BLSW_ERR_ARG;
+    uint64_t off_desc, off_keyproj, off_ws;
+    if (agg_workspace(n, g.L, &off_desc, &off_keyproj, &off_ws) > workspace_bytes) return BLSW_ERR_WORKSPACE;
+    char* base = reinterpret_cast<char*>(d_workspace);
+    StepDesc* d_desc = reinterpret_cast<StepDesc*>(base + off_desc);
+    Fp* keyproj = reinterpret_cast<Fp*>(base + off_keyproj);
+    g.ws = carve(base + off_ws, n, g.L, false);
+    g.N = n;
+    g.n = (uint32_t)n;
+    g.msg_len = msg_len;
+    g.desc = d_desc;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream_);
+    StepDesc h = {nullptr, d_sig_xy, d_msg, d_witness, witness_stride, d_result, d_pks_xy, d_bitmap, d_count};
+    hipMemcpyAsync(d_desc, &h, sizeof(h), hipMemcpyHostToDevice, st);
+    hipStreamSynchronize(st);  // `h` is a stack object
+    const unsigned g1 = (unsigned)((n + 63) / 64), g2 = (unsigned)((2 * n + 63) / 64), gk = (unsigned)((n * n_keys + 63) / 64);
+    hipLaunchKernelGGL(k_agg_keys, dim3(gk), dim3(64), 0, st, g, keyproj);
+    hipLaunchKernelGGL(k_agg_sum, dim3(g1), dim3(64), 0, st, g, (const Fp*)keyproj);
+    hipLaunchKernelGGL(k_g2_alloc, dim3(g1), dim3(64), 0, st, g);
+    hipLaunchKernelGGL(k_prepare, dim3(g1), dim3(64), 0, st, g, 1);
+    hipLaunchKernelGGL(k_sha, dim3(g1), dim3(64), 0, st, g, d_witness ? 1 : 0, 1);
+    if (d_witness) {
+        dim3 grid((g.L.sha_bits + 128 * BLSW_EXPAND_ITERS - 1) / (128 * BLSW_EXPAND_ITERS), (unsigned)n);
+        hipLaunchKernelGGL(k_sha_expand<0>, grid, dim3(384), 0, st, g.ws.bits, g.N, (uint64_t)0, g.L.sha_bits, g.L.off_expand, d_witness, witness_stride);
+    }
+    hipLaunchKernelGGL(k_map, dim3(g2), dim3(64), 0, st, g);
+    hipLaunchKernelGGL(k_cofactor, dim3(g1), dim3(64), 0, st, g);
+    hipLaunchKernelGGL(k_prepare, dim3(g1), dim3(64), 0, st, g, 0);
+    hipLaunchKernelGGL(k_pairing, dim3(g1), dim3(64), 0, st, g);
     return hip_ok(hipGetLastError(), "launch");
 }
 int blsw_decode_batch(const uint8_t* d_pk48, const uint8_t* d_sig96, uint64_t n, uint64_t* d_pk_xy, uint64_t* d_sig_xy, int32_t* d_status, void* stream_) {

@@ -23,7 +23,7 @@ enum : uint32_t {
     SEG_IS_ONE = 35,
 };
 
-inline void make_layout(uint32_t msg_len, blsw_layout_t* L) {
+inline void make_layout(uint32_t msg_len, blsw_layout_t* L, uint32_t n_keys = 0) {
     std::vector<uint8_t> msg(msg_len ? msg_len : 1, 0);
     BitSink s;
     s.init(nullptr, 0);
@@ -33,12 +33,26 @@ inline void make_layout(uint32_t msg_len, blsw_layout_t* L) {
     L->n_instance_vars = 1;
     L->sha_bits = (uint32_t)s.nbits;
     uint32_t o = 0;
+    L->n_keys = n_keys;
+    L->off_keys = L->off_bitmap = L->off_count = L->off_agg = 0;
+    if (n_keys) {  // keys, bitmap booleans, msg, sig, count, per-key (select 3 + add 12 (not the first) + addmany 33)
+        L->off_keys = o;
+        o += n_keys * SEG_PK_ALLOC;
+        L->off_bitmap = o;
+        o += n_keys;
+    }
     L->off_msg = o;
     o += 8 * msg_len;
     L->off_pk_alloc = o;
-    o += SEG_PK_ALLOC;
+    if (!n_keys) o += SEG_PK_ALLOC;
     L->off_sig_alloc = o;
     o += SEG_SIG_ALLOC;
+    if (n_keys) {
+        L->off_count = o;
+        o += 32;
+        L->off_agg = o;
+        o += 48 * n_keys - 12;
+    }
     L->off_pk_not_zero = o;
     o += SEG_PK_NOT_ZERO;
     L->off_expand = o;

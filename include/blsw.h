@@ -42,10 +42,24 @@ typedef struct {
     uint32_t sha_bits;        /* boolean witnesses of the expand_message segment (16 lib_str bits + SHA-256 gadget) */
     uint32_t off_msg, off_pk_alloc, off_sig_alloc, off_pk_not_zero, off_expand, off_map0, off_map1, off_add, off_cofactor, off_prep_h, off_prep_pk,
         off_prep_sig, off_miller, off_final_exp, off_is_one;
+    /* aggregate_verify circuits (src/constraints.rs:378-441); all zero for the single-key circuit (then off_pk_alloc is used) */
+    uint32_t n_keys, off_keys, off_bitmap, off_count, off_agg;
 } blsw_layout_t;
 
 /* layout(circuit shape) — replaces reading cs.num_witness_variables() after synthesis (constraints.rs:369-373). Host only. */
 int blsw_layout(uint32_t msg_len, blsw_layout_t* out);
+
+/* layout of the aggregate_verify circuit with n_keys public keys (keys Witness, bitmap booleans Witness, msg, sig, then
+ * mapped_aggregate + verify: src/constraints.rs:153-191, 378-441). n_keys == 0 gives blsw_layout. Host only. */
+int blsw_layout_aggregate(uint32_t msg_len, uint32_t n_keys, blsw_layout_t* out);
+int blsw_aggregate_workspace_bytes(uint64_t n, uint32_t msg_len, uint32_t n_keys, uint64_t* bytes);
+/* BlsSignatureVerifyGadget::aggregate_verify for n independent instances of n_keys keys each (same message per instance):
+ *   d_pks_xy [n][n_keys][12] u64, d_bitmap [n][n_keys] bytes (0/1: Boolean::new_witness), d_sig_xy [n][24], d_msg [n][msg_len]
+ *   d_witness [n][witness_stride] (may be NULL), d_result [n] int32 (the Boolean), d_count [n] uint32 (the UInt32 count)
+ * Direct mode, asynchronous on `stream`. */
+int blsw_aggregate_verify_batch(const uint64_t* d_pks_xy, const uint8_t* d_bitmap, uint32_t n_keys, const uint64_t* d_sig_xy, const uint8_t* d_msg,
+                                uint32_t msg_len, uint64_t n, uint64_t* d_witness, uint64_t witness_stride, int32_t* d_result, uint32_t* d_count,
+                                void* d_workspace, uint64_t workspace_bytes, void* stream);
 
 /* Execution engine. Batches of n instances are SUBMITTED with their input / output pointers and processed in groups
  * of up to max_steps batches by one set of kernel launches (one batch of 1024 instances is only 16 wavefronts per

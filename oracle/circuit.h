@@ -584,4 +584,57 @@ inline Bool bls_verify_circuit(const G1Aff& pk, const uint8_t* msg, size_t msg_l
     return bls_verify_gadget(g1, pk_var, msg_var, sig_var, tr);
 }
 
+
+// ------------------------------------------------------------------ aggregate_verify (constraints.rs:153-191)
+inline U32 u32witness(uint32_t v) {
+    U32 r;
+    for (int i = 0; i < 32; i++) r.b[i] = balloc((v >> i) & 1);
+    return r;
+}
+// Boolean::conditionally_select on a variable condition with constant arms (bits of count_one / count_zero)
+inline Bool bselect_const_arms(const Bool& cond, bool t, bool f) {
+    if (cond.kind == 0) return bconst(cond.val ? t : f);
+    if (!f) return band(cond, bconst(t));            // (x, Constant(false)) => cond.and(x)
+    if (!t) return band(bnot(cond), bconst(f));      // (Constant(false), x) => cond.not().and(x)
+    return bconst(true);                             // both true
+}
+// mapped_aggregate (constraints.rs:169-191)
+inline G1Var mapped_aggregate(const std::vector<G1Var>& keys, const std::vector<Bool>& bitmap, U32* count_out) {
+    G1Var zero = pv_zero<FpT>();
+    G1Var ret = zero;
+    CSREF.mark("agg.count");
+    U32 count = u32witness(0);
+    CSREF.mark("agg.loop");
+    for (size_t i = 0; i < keys.size(); i++) {
+        G1Var sel = pv_select<FpT>(bitmap[i], keys[i], zero);
+        ret = pv_add<FpT>(ret, sel);
+        U32 inc;
+        for (int b = 0; b < 32; b++) inc.b[b] = bselect_const_arms(bitmap[i], b == 0, false);
+        count = u32addmany({count, inc});
+    }
+    if (count_out) *count_out = count;
+    return ret;
+}
+// the circuit of constraints.rs:378-441: keys (Witness), bitmap booleans (Witness), msg bytes (Witness), params Constant,
+// sig (Witness), then aggregate_verify
+inline Bool bls_aggregate_verify_circuit(const std::vector<G1Aff>& pks, const std::vector<uint8_t>& bitmap, const uint8_t* msg, size_t msg_len,
+                                         const G2Aff& sig, uint32_t* count_value, VerifyTrace* tr = nullptr) {
+    assert(pks.size() == bitmap.size() && !pks.empty());
+    CSREF.mark("agg.keys");
+    std::vector<G1Var> keys;
+    for (auto& pk : pks) keys.push_back(g1_new_witness(pk));
+    CSREF.mark("agg.bitmap");
+    std::vector<Bool> bits;
+    for (uint8_t b : bitmap) bits.push_back(balloc(b != 0));
+    CSREF.mark("msg");
+    std::vector<U8> msg_var = u8witness_vec(msg, msg_len);
+    G1Var g1 = pv_constant<FpT>(g1_generator());
+    CSREF.mark("sig_alloc");
+    G2Var sig_var = g2_new_witness(sig);
+    U32 count;
+    G1Var agg = mapped_aggregate(keys, bits, &count);
+    if (count_value) *count_value = count.value();
+    return bls_verify_gadget(g1, agg, msg_var, sig_var, tr);
+}
+
 }  // namespace orc

@@ -59,6 +59,52 @@ int hostsim_witness(const uint64_t* pk_xy, const uint8_t* msg, uint32_t msg_len,
     (void)seg_ends;
     return res ? 1 : 0;
 }
+struct HostKeys {
+    const std::vector<Proj<OpsFp>>* v;
+    Proj<OpsFp> ld(uint32_t k) const { return (*v)[k]; }
+};
+// aggregate_verify circuit for one instance: pks_xy [K][12], bitmap [K]
+int hostsim_witness_aggregate(const uint64_t* pks_xy, const uint8_t* bitmap, uint32_t K, const uint8_t* msg, uint32_t msg_len, const uint64_t* sig_xy,
+                              uint64_t* out, uint32_t* count_out, blsw_layout_t* Lout) {
+    blsw_layout_t L;
+    make_layout(msg_len, &L, K);
+    if (Lout) *Lout = L;
+    if (!out) return 0;
+    uint32_t* base = reinterpret_cast<uint32_t*>(out);
+    std::vector<Proj<OpsFp>> keys;
+    for (uint32_t k = 0; k < K; k++)
+        keys.push_back(chain_g1_alloc_only({base, L.off_keys + k * SEG_PK_ALLOC}, load_fp(pks_xy + 12 * k), load_fp(pks_xy + 12 * k + 6)));
+    Emitter eb = {base, L.off_bitmap};
+    for (uint32_t k = 0; k < K; k++) eb.put_bool(bitmap[k] != 0);
+    Emitter em = {base, L.off_msg};
+    for (uint32_t i = 0; i < msg_len; i++)
+        for (int j = 0; j < 8; j++) em.put_bool((msg[i] >> j) & 1);
+    Fp2 sx = {load_fp(sig_xy), load_fp(sig_xy + 6)}, sy = {load_fp(sig_xy + 12), load_fp(sig_xy + 18)};
+    chain_g2_alloc({base, L.off_sig_alloc}, sx, sy);
+    HostKeys hk = {&keys};
+    Proj<OpsFp> agg = chain_mapped_aggregate({base, L.off_count}, {base, L.off_agg}, hk, bitmap, K, count_out);
+    G1ChainOut g1 = chain_g1_post({base, L.off_pk_not_zero}, {base, L.off_prep_pk}, agg);
+    std::vector<uint32_t> bits((L.sha_bits + 31) / 32 + 1, 0);
+    BitSink s;
+    s.init(bits.data(), 1);
+    uint32_t uw[64];
+    expand_message_w(s, msg, msg_len, false, uw);
+    Emitter ex = {base, L.off_expand};
+    for (uint32_t i = 0; i < L.sha_bits; i++) ex.put_bool((bits[i >> 5] >> (i & 31)) & 1);
+    Fp2 u0 = {hash_to_field_elem(uw), hash_to_field_elem(uw + 16)};
+    Fp2 u1 = {hash_to_field_elem(uw + 32), hash_to_field_elem(uw + 48)};
+    Proj<OpsFp2> q0 = chain_map_to_curve({base, L.off_map0}, u0);
+    Proj<OpsFp2> q1 = chain_map_to_curve({base, L.off_map1}, u1);
+    Proj<OpsFp2> hh = chain_cofactor({base, L.off_add}, {base, L.off_cofactor}, q0, q1);
+    std::vector<Fp> ch(68 * 4), cs(68 * 4);
+    chain_prepare_g2({base, L.off_prep_h}, hh, CoeffLinear{ch.data()});
+    bool sinf = fp2_is_zero(sx) && fp2_is_zero(sy);
+    Proj<OpsFp2> sp = {sinf ? fp2_zero() : sx, sinf ? fp2_one() : sy, sinf ? fp2_zero() : fp2_one()};
+    chain_prepare_g2({base, L.off_prep_sig}, sp, CoeffLinear{cs.data()});
+    Fp12 fm = chain_miller({base, L.off_miller}, g1.ax, g1.ay, CoeffLinear{cs.data()}, CoeffLinear{ch.data()});
+    bool res = chain_final_exp_is_one({base, L.off_final_exp}, {base, L.off_is_one}, fm);
+    return res ? 1 : 0;
+}
 int hostsim_g1_decode(const uint8_t* in, uint64_t* out_xy) {
     Fp x, y;
     int st = g1_decode(in, x, y);

@@ -10,7 +10,7 @@ u64p = ctypes.POINTER(ctypes.c_uint64)
 
 _FIELDS = (
     "msg_len n_instance_vars n_witness sha_bits off_msg off_pk_alloc off_sig_alloc off_pk_not_zero off_expand off_map0 off_map1 "
-    "off_add off_cofactor off_prep_h off_prep_pk off_prep_sig off_miller off_final_exp off_is_one"
+    "off_add off_cofactor off_prep_h off_prep_pk off_prep_sig off_miller off_final_exp off_is_one n_keys off_keys off_bitmap off_count off_agg"
 ).split()
 
 
@@ -43,3 +43,19 @@ def witness(pk_xy, msg, sig_xy):
     buf = (ctypes.c_uint8 * max(1, len(msg))).from_buffer_copy(bytes(msg) if len(msg) else b"\0")
     r = load().hostsim_witness(pk_xy.ctypes.data_as(u64p), buf, len(msg), sig_xy.ctypes.data_as(u64p), out.ctypes.data_as(u64p), None)
     return r, out
+
+
+def witness_aggregate(pks_xy, bitmap, msg, sig_xy):
+    pks_xy = np.ascontiguousarray(pks_xy, dtype=np.uint64)
+    sig_xy = np.ascontiguousarray(sig_xy, dtype=np.uint64)
+    bitmap = np.ascontiguousarray(bitmap, dtype=np.uint8)
+    K = pks_xy.shape[0]
+    L = Lay()
+    buf = (ctypes.c_uint8 * max(1, len(msg))).from_buffer_copy(bytes(msg) if len(msg) else b"\0")
+    u8p = ctypes.POINTER(ctypes.c_uint8)
+    load().hostsim_witness_aggregate(pks_xy.ctypes.data_as(u64p), bitmap.ctypes.data_as(u8p), K, buf, len(msg), sig_xy.ctypes.data_as(u64p), None, None, ctypes.byref(L))
+    out = np.zeros((L.n_witness, 6), dtype=np.uint64)
+    cnt = ctypes.c_uint32(0)
+    r = load().hostsim_witness_aggregate(pks_xy.ctypes.data_as(u64p), bitmap.ctypes.data_as(u8p), K, buf, len(msg), sig_xy.ctypes.data_as(u64p),
+                                         out.ctypes.data_as(u64p), ctypes.byref(cnt), ctypes.byref(L))
+    return r, cnt.value, out, {n: getattr(L, n) for n in _FIELDS}

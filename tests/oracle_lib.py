@@ -29,6 +29,7 @@ class Oracle:
     def __init__(self, lib):
         self.lib = lib
         lib.orc_witness.restype = ctypes.c_uint64
+        lib.orc_witness_aggregate.restype = ctypes.c_uint64
         lib.orc_layout.restype = ctypes.c_uint64
         lib.orc_check_satisfied.restype = ctypes.c_int64
 
@@ -116,6 +117,25 @@ class Oracle:
         w = np.zeros((n, 6), dtype=np.uint64)
         self.lib.orc_witness(pk_xy.ctypes.data_as(u64p), self._buf(msg), ctypes.c_size_t(len(msg)), sig_xy.ctypes.data_as(u64p), w.ctypes.data_as(u64p), ctypes.c_uint64(n), ctypes.byref(ncons), ctypes.byref(res))
         return n, ncons.value, bool(res.value), w
+
+    def witness_aggregate(self, pks_xy, bitmap, msg, sig_xy, want_vector=True):
+        pks_xy = np.ascontiguousarray(pks_xy, dtype=np.uint64)
+        sig_xy = np.ascontiguousarray(sig_xy, dtype=np.uint64)
+        bitmap = np.ascontiguousarray(bitmap, dtype=np.uint8)
+        k = pks_xy.shape[0]
+        ncons, res, cnt = ctypes.c_uint64(0), ctypes.c_int(0), ctypes.c_uint32(0)
+        starts = (ctypes.c_uint64 * 64)()
+        names = ctypes.create_string_buffer(4096)
+        args = lambda w, cap: (pks_xy.ctypes.data_as(u64p), bitmap.ctypes.data_as(u8p), ctypes.c_uint64(k), self._buf(msg), ctypes.c_size_t(len(msg)),
+                               sig_xy.ctypes.data_as(u64p), w, ctypes.c_uint64(cap), ctypes.byref(ncons), ctypes.byref(res), ctypes.byref(cnt), starts,
+                               ctypes.c_uint64(64), names, ctypes.c_size_t(4096))
+        n = self.lib.orc_witness_aggregate(*args(None, 0))
+        marks = dict(zip(names.value.decode().split("\n"), list(starts)))
+        w = None
+        if want_vector:
+            w = np.zeros((n, 6), dtype=np.uint64)
+            self.lib.orc_witness_aggregate(*args(w.ctypes.data_as(u64p), n))
+        return n, bool(res.value), cnt.value, marks, w
 
     def witness_batch(self, pk_xy, msgs, sig_xy, threads=1, want_digests=True):
         pk_xy = np.ascontiguousarray(pk_xy, dtype=np.uint64)

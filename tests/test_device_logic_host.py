@@ -128,3 +128,25 @@ def test_decode_all_verify_fixture_points(oracle):
             assert (ost == 0) == (st in (0, 4)), name
             if st == 0:
                 assert np.array_equal(xy, oxy), name
+
+
+def test_aggregate_verify_device_logic(oracle):
+    # constraints.rs:378-521 shape with 6 keys: key1 + 5 x key2, bitmap first two (true) / all (false); bit-exact vs oracle
+    pk1 = "a491d1b0ecd9bb917989f0e74f0dea0422eac4a873e5e2644f368dffb9a6e20fd6e10c1b77654d067c0618f6e5a7f79a"
+    pk2 = "b301803f8b5ac4a1133581fc676dfedc60d891dd5fa99028805e5ea5b08d3491af75d0707adab3b70c6a6a580217bf81"
+    sig = "912c3615f69575407db9392eb21fee18fff797eeb2fbe1816366ca2a08ae574d8824dbfafb4c9eaa1cf61b63c6f9b69911f269b664c42947dd1b53ef1081926c1e82bb2a465f927124b08391a5249036146d6f3f1e17ff5f162f779746d830d1"
+    msg = bytes.fromhex("56" * 32)
+    _, p1, _ = oracle.g1_decompress(bytes.fromhex(pk1))
+    _, p2, _ = oracle.g1_decompress(bytes.fromhex(pk2))
+    _, s, _ = oracle.g2_decompress(bytes.fromhex(sig))
+    K = 6
+    pks = np.stack([p1] + [p2] * (K - 1))
+    for bm, want, want_count in ((np.array([1, 1, 0, 0, 0, 0], dtype=np.uint8), True, 2), (np.ones(K, dtype=np.uint8), False, K),
+                                 (np.array([0, 1, 0, 1, 0, 0], dtype=np.uint8), False, 2)):
+        n, res, cnt, marks, w = oracle.witness_aggregate(pks, bm, msg, s)
+        r, c, out, lay = hostsim_lib.witness_aggregate(pks, bm, msg, s)
+        assert lay["n_witness"] == n and lay["off_keys"] == marks["agg.keys"] and lay["off_bitmap"] == marks["agg.bitmap"]
+        assert lay["off_count"] == marks["agg.count"] and lay["off_agg"] == marks["agg.loop"] and lay["off_pk_not_zero"] == marks["verify.pk_not_zero"]
+        bad = np.nonzero((w != out).any(axis=1))[0]
+        assert len(bad) == 0, "first mismatching witness index %d" % bad[0]
+        assert bool(r) == res == want and c == cnt == want_count

@@ -194,3 +194,57 @@ def test_decode_and_verify_bytes_fixtures(pkg, oracle):
     st = st.cpu().numpy()
     assert [bool(st[i, 0] in (0, 4)) for i in range(len(g1))] == [o for _, o in g1]
     assert [bool(st[i, 1] in (0, 4)) for i in range(len(g2))] == [o for _, o in g2]
+
+
+def _agg_run(pkg, pks, bm, msg, sig):
+    import torch
+
+    res, cnt, wit = pkg.aggregate_verify(pkg.ParametersVar(), pkg.PublicKeyVar.new_witness(torch.from_numpy(pks.view(np.int64)).cuda()),
+                                         torch.from_numpy(bm).cuda(), torch.from_numpy(msg).cuda(), pkg.SignatureVar.new_witness(torch.from_numpy(sig.view(np.int64)).cuda()))
+    return res.cpu().numpy().astype(bool), cnt.cpu().numpy(), wit.cpu().numpy().view(np.uint64)
+
+
+def test_aggregate_verify_reference_512_keys(pkg, oracle):
+    # constraints.rs:378-521: 512 keys (key1 + 511 x key2); bitmap first two -> true, all -> false. Two instances in one batch.
+    pk1 = "a491d1b0ecd9bb917989f0e74f0dea0422eac4a873e5e2644f368dffb9a6e20fd6e10c1b77654d067c0618f6e5a7f79a"
+    pk2 = "b301803f8b5ac4a1133581fc676dfedc60d891dd5fa99028805e5ea5b08d3491af75d0707adab3b70c6a6a580217bf81"
+    sigh = "912c3615f69575407db9392eb21fee18fff797eeb2fbe1816366ca2a08ae574d8824dbfafb4c9eaa1cf61b63c6f9b69911f269b664c42947dd1b53ef1081926c1e82bb2a465f927124b08391a5249036146d6f3f1e17ff5f162f779746d830d1"
+    _, p1, _ = oracle.g1_decompress(bytes.fromhex(pk1))
+    _, p2, _ = oracle.g1_decompress(bytes.fromhex(pk2))
+    _, s, _ = oracle.g2_decompress(bytes.fromhex(sigh))
+    K = 512
+    one = np.stack([p1] + [p2] * (K - 1))
+    pks = np.stack([one, one])
+    bm = np.zeros((2, K), dtype=np.uint8)
+    bm[0, :2] = 1
+    bm[1, :] = 1
+    msg = np.full((2, 32), 0x56, dtype=np.uint8)
+    sig = np.stack([s, s])
+    got, cnt, w = _agg_run(pkg, pks, bm, msg, sig)
+    assert got.tolist() == [True, False] and cnt.tolist() == [2, 512]
+    for i in range(2):
+        n, res, c, _, ow = oracle.witness_aggregate(pks[i], bm[i], msg[i].tobytes(), sig[i])
+        assert n == w.shape[1] and res == bool(got[i]) and c == cnt[i]
+        bad = np.nonzero((ow != w[i]).any(axis=1))[0]
+        assert len(bad) == 0, "instance %d: first mismatching witness index %d" % (i, bad[0])
+
+
+def test_fast_aggregate_verify_fixtures(pkg, oracle):
+    # tests/test_cases/fast_aggregate_verify/*.json (tests.rs:296-334) with every key selected
+    done = 0
+    for name, c in eth_cases("fast_aggregate_verify"):
+        i = c["input"]
+        pks = [oracle.g1_decompress(unhex(p)) for p in i["pubkeys"]]
+        st, sxy, sinf = oracle.g2_decompress(unhex(i["signature"]))
+        if not pks or any(p[0] for p in pks) or st or sinf:
+            assert c["output"] is False  # undecodable / empty inputs are rejected before the gadget
+            continue
+        pk = np.stack([p[1] for p in pks])[None]
+        bm = np.ones((1, pk.shape[1]), dtype=np.uint8)
+        msg = np.frombuffer(unhex(i["message"]), dtype=np.uint8)[None].copy()
+        got, cnt, w = _agg_run(pkg, pk, bm, msg, sxy[None])
+        assert bool(got[0]) == c["output"] and cnt[0] == pk.shape[1]
+        n, res, cc, _, ow = oracle.witness_aggregate(pk[0], bm[0], msg[0].tobytes(), sxy)
+        assert np.array_equal(ow, w[0])
+        done += 1
+    assert done >= 6
