@@ -57,7 +57,7 @@ def lib():
         L.blsw_engine_destroy.argtypes = [vp]
         L.blsw_engine_submit.argtypes = [vp, vp, vp, vp, vp, u64, vp, vp]
         L.blsw_engine_flush.argtypes = [vp, vp]
-        L.blsw_engine_last_expand_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+        L.blsw_engine_expand_stats.argtypes = [vp, ctypes.POINTER(u32), ctypes.POINTER(ctypes.c_float)]
         L.blsw_hash_to_g2_workspace_bytes.argtypes = [u64, u32, ctypes.POINTER(u64)]
         L.blsw_hash_to_g2_batch.argtypes = [vp, u32, u64, vp, vp, u64, vp]
         L.blsw_layout_aggregate.argtypes = [u32, u32, ctypes.POINTER(blsw_layout_t)]
@@ -70,7 +70,7 @@ def lib():
 
 
 EXPORTED_SYMBOLS = ["blsw_version", "blsw_layout", "blsw_engine_workspace_bytes", "blsw_engine_create", "blsw_engine_destroy", "blsw_engine_submit",
-                    "blsw_engine_flush", "blsw_engine_last_expand_ms", "blsw_hash_to_g2_workspace_bytes", "blsw_hash_to_g2_batch", "blsw_decode_batch", "blsw_layout_aggregate", "blsw_aggregate_workspace_bytes",
+                    "blsw_engine_flush", "blsw_engine_expand_stats", "blsw_hash_to_g2_workspace_bytes", "blsw_hash_to_g2_batch", "blsw_decode_batch", "blsw_layout_aggregate", "blsw_aggregate_workspace_bytes",
                     "blsw_aggregate_verify_batch", "blsw_microbench"]
 
 
@@ -154,12 +154,13 @@ class WitnessEngine:
             raise BlswError("blsw_engine_flush failed: %d" % rc)
         self._keep = self._keep[-(self.n_buffers + 1) * self.max_steps:]
 
-    def last_expand_ms(self):
-        ms = ctypes.c_float(0)
-        rc = lib().blsw_engine_last_expand_ms(self._e, ctypes.byref(ms))
+    def expand_stats(self):
+        """(number of k_sha_expand launches since the last call, their average duration in ms); synchronises with them."""
+        ms, cnt = ctypes.c_float(0), ctypes.c_uint32(0)
+        rc = lib().blsw_engine_expand_stats(self._e, ctypes.byref(cnt), ctypes.byref(ms))
         if rc:
-            raise BlswError("blsw_engine_last_expand_ms failed: %d" % rc)
-        return ms.value
+            raise BlswError("blsw_engine_expand_stats failed: %d" % rc)
+        return cnt.value, ms.value
 
 
 class ParametersVar:

@@ -89,8 +89,9 @@ int blsw_engine_submit(blsw_engine_t* e, const uint64_t* d_pk_xy, const uint64_t
                        uint64_t witness_stride, int32_t* d_result, void* stream);
 /* Issues everything pending and makes `stream` wait for all batches submitted so far (asynchronous for the host). */
 int blsw_engine_flush(blsw_engine_t* e, void* stream);
-/* duration (ms) of the last bit->Fp expansion kernel (HIP events on the stream it ran on); blocks until it has finished */
-int blsw_engine_last_expand_ms(blsw_engine_t* e, float* ms);
+/* average duration (ms) of the bit->Fp expansion kernel launches issued since the previous call (HIP events on the stream they
+ * ran on, at most 1024 launches); blocks until they have finished and resets the statistics */
+int blsw_engine_expand_stats(blsw_engine_t* e, uint32_t* count, float* avg_ms);
 
 /* Input decode (PublicKey::try_from / Signature::try_from -> deserialize_compressed, src/bls.rs:219-242, 316-339):
  *   d_pk48 [n][48], d_sig96 [n][96]  ZCash-format compressed points
