@@ -162,7 +162,12 @@ __global__ __launch_bounds__(64) void k_sha_values(Group g) {
 // the 16-byte column c = t % 3 of elements e0 + 128k, so its three R limbs-of-four are loop invariants and one store
 // instruction of a wave covers 1 KiB contiguous. ~10 VALU instructions per 16 bytes stored; streaming (nontemporal)
 // stores: the tensor is not read again on the device. blockIdx.y = instance of the step.
+#ifndef BLSW_EXPAND_ITERS
 #define BLSW_EXPAND_ITERS 32
+#endif
+#ifndef BLSW_EXPAND_UNROLL
+#define BLSW_EXPAND_UNROLL 8
+#endif
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 template <int NT>
 __global__ __launch_bounds__(384) void k_sha_expand(const uint32_t* __restrict__ bits, uint64_t N, uint64_t first, uint32_t sha_bits,
@@ -178,7 +183,7 @@ __global__ __launch_bounds__(384) void k_sha_expand(const uint32_t* __restrict__
     rc.y = c == 0 ? R1[1] : (c == 1 ? R1[5] : R1[9]);
     rc.z = c == 0 ? R1[2] : (c == 1 ? R1[6] : R1[10]);
     rc.w = c == 0 ? R1[3] : (c == 1 ? R1[7] : R1[11]);
-#pragma unroll 8
+#pragma unroll BLSW_EXPAND_UNROLL
     for (int k = 0; k < BLSW_EXPAND_ITERS; k++) {
         uint32_t e = e0 + 128 * k;
         if (e < sha_bits) {
@@ -506,8 +511,8 @@ static unsigned place_lds_bytes() {
 static int place_nt() {
     static int v = -1;
     if (v < 0) {
-        const char* s = getenv("BLSW_EXPAND_NT");
-        v = s ? atoi(s) : 1;
+        const char* s = getenv("BLSW_EXPAND_NT");  // 0 plain stores (default, fastest kernel), 1 nontemporal, 2 sc1, 3 sc0 sc1
+        v = s ? atoi(s) : 0;
     }
     return v;
 }

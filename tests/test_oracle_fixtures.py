@@ -113,3 +113,36 @@ def test_hash_strings_consistent(oracle):
         assert c.hex() == want
         st, _, inf = oracle.g2_decompress(c)
         assert st == 0 and not inf
+
+
+def test_gadget_aggregate_verify_reference(oracle):
+    # constraints.rs:378-521: 512 keys (key1 + 511 x key2); first two selected -> true (count 2); all selected -> false
+    pk1 = "a491d1b0ecd9bb917989f0e74f0dea0422eac4a873e5e2644f368dffb9a6e20fd6e10c1b77654d067c0618f6e5a7f79a"
+    pk2 = "b301803f8b5ac4a1133581fc676dfedc60d891dd5fa99028805e5ea5b08d3491af75d0707adab3b70c6a6a580217bf81"
+    sig = "912c3615f69575407db9392eb21fee18fff797eeb2fbe1816366ca2a08ae574d8824dbfafb4c9eaa1cf61b63c6f9b69911f269b664c42947dd1b53ef1081926c1e82bb2a465f927124b08391a5249036146d6f3f1e17ff5f162f779746d830d1"
+    _, p1, _ = oracle.g1_decompress(bytes.fromhex(pk1))
+    _, p2, _ = oracle.g1_decompress(bytes.fromhex(pk2))
+    _, s, _ = oracle.g2_decompress(bytes.fromhex(sig))
+    K = 512
+    pks = np.stack([p1] + [p2] * (K - 1))
+    bm = np.zeros(K, dtype=np.uint8)
+    bm[:2] = 1
+    n, res, cnt, marks, _ = oracle.witness_aggregate(pks, bm, bytes.fromhex("56" * 32), s, want_vector=False)
+    assert res is True and cnt == 2
+    bm[:] = 1
+    n, res, cnt, marks, _ = oracle.witness_aggregate(pks, bm, bytes.fromhex("56" * 32), s, want_vector=False)
+    assert res is False and cnt == 512
+
+
+@pytest.mark.parametrize("name,case", eth_cases("fast_aggregate_verify"))
+def test_gadget_fast_aggregate_verify(oracle, name, case):
+    # the same fixtures through the in-circuit aggregate_verify with every key selected
+    i = case["input"]
+    pks = [oracle.g1_decompress(unhex(p)) for p in i["pubkeys"]]
+    st, sxy, sinf = oracle.g2_decompress(unhex(i["signature"]))
+    if not pks or any(p[0] for p in pks) or st or sinf:
+        assert case["output"] is False
+        return
+    pk = np.stack([p[1] for p in pks])
+    n, res, cnt, _, _ = oracle.witness_aggregate(pk, np.ones(len(pks), dtype=np.uint8), unhex(i["message"]), sxy, want_vector=False)
+    assert res == case["output"] and cnt == len(pks)
