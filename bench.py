@@ -54,8 +54,8 @@ def synth_inputs(n, seed=0x5EED):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=256)
-    ap.add_argument("--warmup", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=512)
+    ap.add_argument("--warmup", type=int, default=48)
     ap.add_argument("--batch", type=int, default=1024, help="instances per GPU per step (configs[1]: 1024)")
     ap.add_argument("--coalesce", type=int, default=16, help="max submitted batches fused into one launch group")
     ap.add_argument("--buffers", type=int, default=3, help="launch groups in flight (each owns streams + a workspace slice)")

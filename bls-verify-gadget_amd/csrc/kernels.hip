@@ -467,8 +467,7 @@ inline int hip_ok(hipError_t e, const char* what) {
 // one batch of 1024 instances is only 16 waves per chain. Per group:
 //   main : sha_values -> map -> cofactor -> prepare(H) ............ -> pairing
 //   aux0 : g1_alloc, g2_alloc                                        (needs only pk / sig)
-//   aux1 : prepare(sig)                                              (needs only sig)
-//   aux2 : sha witness bits
+//   aux1 : prepare(sig), sha witness bits                            (need only sig / msg)
 // Field witnesses go to an element-major staging area (coalesced stores); then, per step and in submission order,
 // the `place` stream writes the step's complete witness tensor: k_sha_expand (bit -> Fp, ~31 MB per instance, the
 // HBM-bound kernel) and k_place_field (staging -> its place around the SHA segment). Two group buffers ping-pong,
@@ -480,7 +479,7 @@ struct GroupBuf {
     Workspace ws;
     StepDesc* h_desc;  // pinned host
     StepDesc* d_desc;
-    hipStream_t st[4];  // main, aux0..2
+    hipStream_t st[3];  // main, aux0, aux1
     hipEvent_t ev_start, ev_aux[3], ev_chains, ev_done;
     bool used;
 };
@@ -535,19 +534,18 @@ static int launch_group(blsw_engine* e, hipStream_t user_stream) {
     hipStreamWaitEvent(st, e->ev_in, 0);
     hipMemcpyAsync(b.d_desc, b.h_desc, sizeof(StepDesc) * steps, hipMemcpyHostToDevice, st);
     hipEventRecord(b.ev_start, st);
-    for (int i = 0; i < 3; i++) hipStreamWaitEvent(b.st[1 + i], b.ev_start, 0);
+    for (int i = 0; i < 2; i++) hipStreamWaitEvent(b.st[1 + i], b.ev_start, 0);
     bool any_out = false;
     for (uint32_t s = 0; s < steps; s++) any_out = any_out || b.h_desc[s].out != nullptr;
     // aux0: group allocations
     hipLaunchKernelGGL(k_g1, dim3(g1), dim3(64), 0, b.st[1], g);
     hipLaunchKernelGGL(k_g2_alloc, dim3(g1), dim3(64), 0, b.st[1], g);
     hipEventRecord(b.ev_aux[0], b.st[1]);
-    // aux1: prepare_g2(sig)
+    // aux1: prepare_g2(sig), then the SHA-256 witness bits
     hipLaunchKernelGGL(k_prepare, dim3(g1), dim3(64), 0, b.st[2], g, 1);
     hipEventRecord(b.ev_aux[1], b.st[2]);
-    // aux2: SHA-256 witness bits
-    if (any_out) hipLaunchKernelGGL(k_sha, dim3(g1), dim3(64), 0, b.st[3], g, 1, 0);
-    hipEventRecord(b.ev_aux[2], b.st[3]);
+    if (any_out) hipLaunchKernelGGL(k_sha, dim3(g1), dim3(64), 0, b.st[2], g, 1, 0);
+    hipEventRecord(b.ev_aux[2], b.st[2]);
     // main: the hash-to-G2 critical path, then the pairing
     hipLaunchKernelGGL(k_sha_values, dim3(g1), dim3(64), 0, st, g);
     hipLaunchKernelGGL(k_map, dim3(g2), dim3(64), 0, st, g);
@@ -641,7 +639,7 @@ int blsw_engine_create(blsw_engine_t** out, uint64_t n, uint32_t msg_len, uint32
         b.used = false;
         if (hip_ok(hipHostMalloc(reinterpret_cast<void**>(&b.h_desc), sizeof(StepDesc) * max_steps, hipHostMallocDefault), "host alloc")) return BLSW_ERR_HIP;
         if (hip_ok(hipMalloc(reinterpret_cast<void**>(&b.d_desc), sizeof(StepDesc) * max_steps), "desc alloc")) return BLSW_ERR_HIP;
-        for (int i = 0; i < 4; i++)
+        for (int i = 0; i < 3; i++)
             if (hip_ok(hipStreamCreateWithPriority(&b.st[i], hipStreamNonBlocking, prio_hi), "stream create")) return BLSW_ERR_HIP;
         for (int i = 0; i < 3; i++) hipEventCreateWithFlags(&b.ev_aux[i], hipEventDisableTiming);
         hipEventCreateWithFlags(&b.ev_start, hipEventDisableTiming);
@@ -661,7 +659,7 @@ int blsw_engine_destroy(blsw_engine_t* e) {
         GroupBuf& b = e->buf[k];
         hipHostFree(b.h_desc);
         hipFree(b.d_desc);
-        for (int i = 0; i < 4; i++) hipStreamDestroy(b.st[i]);
+        for (int i = 0; i < 3; i++) hipStreamDestroy(b.st[i]);
         for (int i = 0; i < 3; i++) hipEventDestroy(b.ev_aux[i]);
         hipEventDestroy(b.ev_start);
         hipEventDestroy(b.ev_chains);
