@@ -70,6 +70,7 @@ struct Group {
     blsw_layout_t L;       // offsets in the witness vector
     blsw_layout_t LS;      // offsets in the staging rows (the vector with the SHA segment cut out)
     Workspace ws;
+    int chain_prio;        // chain waves raise s_setprio
 };
 inline blsw_layout_t staging_layout(const blsw_layout_t& L) {
     blsw_layout_t S = L;
@@ -128,7 +129,7 @@ __device__ __forceinline__ Emitter emitter(const Group& g, const LaneId& id, uin
 // ---------------------------------------------------------------- kernels (one instance per lane)
 // SHA-256 witness bits of expand_message (+ the message bits themselves)
 __global__ __launch_bounds__(64) void k_sha(Group g, int want_bits, int write_u) {
-    __builtin_amdgcn_s_setprio(3);  // latency-critical chain: win VALU issue arbitration against the streaming placement waves
+    if (g.chain_prio) __builtin_amdgcn_s_setprio(3);  // latency-critical chain: win VALU issue arbitration against the streaming placement waves
     uint64_t I = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (I >= g.N) return;
     LaneId id = lane_id(g, I);
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(64) void k_sha(Group g, int want_bits, int write_u)
 
 // value-only expand_message + hash_to_field: hands u0, u1 to k_map without waiting for the witness-bit pass
 __global__ __launch_bounds__(64) void k_sha_values(Group g) {
-    __builtin_amdgcn_s_setprio(3);  // latency-critical chain: win VALU issue arbitration against the streaming placement waves
+    if (g.chain_prio) __builtin_amdgcn_s_setprio(3);  // latency-critical chain: win VALU issue arbitration against the streaming placement waves
     uint64_t I = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (I >= g.N) return;
     LaneId id = lane_id(g, I);
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(256) void k_place_field(const Fp* __restrict__ stag
 }
 
 __global__ __launch_bounds__(64) void k_g1(Group g) {
-    __builtin_amdgcn_s_setprio(3);  // latency-critical chain: win VALU issue arbitration against the streaming placement waves
+    if (g.chain_prio) __builtin_amdgcn_s_setprio(3);  // latency-critical chain: win VALU issue arbitration against the streaming placement waves
     uint64_t I = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (I >= g.N) return;
     LaneId id = lane_id(g, I);
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(64) void k_g1(Group g) {
 
 // aggregate_verify: lane t = k * N + I allocates key k of instance I (N * n_keys lanes), result to ws.keyproj
 __global__ __launch_bounds__(64) void k_agg_keys(Group g, Fp* keyproj) {
-    __builtin_amdgcn_s_setprio(3);
+    if (g.chain_prio) __builtin_amdgcn_s_setprio(3);
     uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t N = g.N, nk = g.L.n_keys;
     if (t >= N * nk) return;
@@ -268,7 +269,7 @@ struct KeyProjSrc {
 };
 // aggregate_verify: bitmap booleans, mapped_aggregate, then pk != 0 and prepare_g1 on the aggregated key
 __global__ __launch_bounds__(64) void k_agg_sum(Group g, const Fp* keyproj) {
-    __builtin_amdgcn_s_setprio(3);
+    if (g.chain_prio) __builtin_amdgcn_s_setprio(3);
     uint64_t I = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (I >= g.N) return;
     LaneId id = lane_id(g, I);
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(64) void k_agg_sum(Group g, const Fp* keyproj) {
 }
 
 __global__ __launch_bounds__(64) void k_g2_alloc(Group g) {
-    __builtin_amdgcn_s_setprio(3);  // latency-critical chain: win VALU issue arbitration against the streaming placement waves
+    if (g.chain_prio) __builtin_amdgcn_s_setprio(3);  // latency-critical chain: win VALU issue arbitration against the streaming placement waves
     uint64_t I = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (I >= g.N) return;
     LaneId id = lane_id(g, I);
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(64) void k_g2_alloc(Group g) {
 
 // lanes [0, N): u0 -> Q0 ; lanes [N, 2N): u1 -> Q1
 __global__ __launch_bounds__(64) void k_map(Group g) {
-    __builtin_amdgcn_s_setprio(3);  // latency-critical chain: win VALU issue arbitration against the streaming placement waves
+    if (g.chain_prio) __builtin_amdgcn_s_setprio(3);  // latency-critical chain: win VALU issue arbitration against the streaming placement waves
     uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= 2 * g.N) return;
     uint32_t which = t >= g.N;
@@ -324,7 +325,7 @@ __device__ __forceinline__ Proj<OpsFp2> ld_proj2(const Fp* p, uint64_t n) {
     return r;
 }
 __global__ __launch_bounds__(64) void k_cofactor(Group g) {
-    __builtin_amdgcn_s_setprio(3);  // latency-critical chain: win VALU issue arbitration against the streaming placement waves
+    if (g.chain_prio) __builtin_amdgcn_s_setprio(3);  // latency-critical chain: win VALU issue arbitration against the streaming placement waves
     uint64_t I = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (I >= g.N) return;
     LaneId id = lane_id(g, I);
@@ -349,7 +350,7 @@ struct CoeffStrided {
 };
 // which = 0: prepare_g2(H(m)) ; which = 1: prepare_g2(sig)
 __global__ __launch_bounds__(64) void k_prepare(Group g, int which) {
-    __builtin_amdgcn_s_setprio(3);  // latency-critical chain: win VALU issue arbitration against the streaming placement waves
+    if (g.chain_prio) __builtin_amdgcn_s_setprio(3);  // latency-critical chain: win VALU issue arbitration against the streaming placement waves
     uint64_t I = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (I >= g.N) return;
     LaneId id = lane_id(g, I);
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(64) void k_prepare(Group g, int which) {
 
 // Miller loop + final exponentiation + is_one
 __global__ __launch_bounds__(64) void k_pairing(Group g) {
-    __builtin_amdgcn_s_setprio(3);  // latency-critical chain: win VALU issue arbitration against the streaming placement waves
+    if (g.chain_prio) __builtin_amdgcn_s_setprio(3);  // latency-critical chain: win VALU issue arbitration against the streaming placement waves
     uint64_t I = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (I >= g.N) return;
     LaneId id = lane_id(g, I);
@@ -507,11 +508,19 @@ static unsigned place_lds_bytes() {
     }
     return (unsigned)v;
 }
+static int prio_mode() {  // 0: chains high / placement low; 1: placement high / chains low (default); 2: all equal
+    static int v = -1;
+    if (v < 0) {
+        const char* s = getenv("BLSW_PRIO_MODE");
+        v = s ? atoi(s) : 1;
+    }
+    return v;
+}
 static int place_nt() {
     static int v = -1;
     if (v < 0) {
-        const char* s = getenv("BLSW_EXPAND_NT");  // 0 plain stores (default, fastest kernel), 1 nontemporal, 2 sc1, 3 sc0 sc1
-        v = s ? atoi(s) : 0;
+        const char* s = getenv("BLSW_EXPAND_NT");  // 0 plain stores, 1 nontemporal (default: keeps the chains' stacks cached), 2 sc1, 3 sc0 sc1
+        v = s ? atoi(s) : 1;
     }
     return v;
 }
@@ -527,6 +536,7 @@ static int launch_group(blsw_engine* e, hipStream_t user_stream) {
     g.L = e->L;
     g.LS = e->LS;
     g.ws = carve(b.base, g.N, e->L, e->staged);
+    g.chain_prio = prio_mode() == 0;
     const unsigned g1 = (unsigned)((g.N + 63) / 64), g2 = (unsigned)((2 * g.N + 63) / 64);
     hipStream_t st = b.st[0];
     // inputs are ready once the submitting stream reaches this point
@@ -640,13 +650,13 @@ int blsw_engine_create(blsw_engine_t** out, uint64_t n, uint32_t msg_len, uint32
         if (hip_ok(hipHostMalloc(reinterpret_cast<void**>(&b.h_desc), sizeof(StepDesc) * max_steps, hipHostMallocDefault), "host alloc")) return BLSW_ERR_HIP;
         if (hip_ok(hipMalloc(reinterpret_cast<void**>(&b.d_desc), sizeof(StepDesc) * max_steps), "desc alloc")) return BLSW_ERR_HIP;
         for (int i = 0; i < 3; i++)
-            if (hip_ok(hipStreamCreateWithPriority(&b.st[i], hipStreamNonBlocking, prio_hi), "stream create")) return BLSW_ERR_HIP;
+            if (hip_ok(hipStreamCreateWithPriority(&b.st[i], hipStreamNonBlocking, prio_mode() == 1 ? prio_lo : prio_hi), "stream create")) return BLSW_ERR_HIP;
         for (int i = 0; i < 3; i++) hipEventCreateWithFlags(&b.ev_aux[i], hipEventDisableTiming);
         hipEventCreateWithFlags(&b.ev_start, hipEventDisableTiming);
         hipEventCreateWithFlags(&b.ev_chains, hipEventDisableTiming);
         hipEventCreateWithFlags(&b.ev_done, hipEventDisableTiming);
     }
-    if (hip_ok(hipStreamCreateWithPriority(&e->place, hipStreamNonBlocking, prio_lo), "stream create")) return BLSW_ERR_HIP;
+    if (hip_ok(hipStreamCreateWithPriority(&e->place, hipStreamNonBlocking, prio_mode() == 0 ? prio_lo : prio_hi), "stream create")) return BLSW_ERR_HIP;
     hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming);
     *out = e;
     return hip_ok(hipGetLastError(), "engine create");
@@ -740,6 +750,7 @@ int blsw_hash_to_g2_batch(const uint8_t* d_msg, uint32_t msg_len, uint64_t n, ui
     g.n = (uint32_t)n;
     g.msg_len = msg_len;
     g.desc = d_desc;
+    g.chain_prio = 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream_);
     StepDesc h = {nullptr, nullptr, d_msg, nullptr, 0, nullptr, nullptr, nullptr, nullptr};
     hipMemcpyAsync(d_desc, &h, sizeof(h), hipMemcpyHostToDevice, st);
@@ -791,6 +802,7 @@ int blsw_aggregate_verify_batch(const uint64_t* d_pks_xy, const uint8_t* d_bitma
     g.n = (uint32_t)n;
     g.msg_len = msg_len;
     g.desc = d_desc;
+    g.chain_prio = 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream_);
     StepDesc h = {nullptr, d_sig_xy, d_msg, d_witness, witness_stride, d_result, d_pks_xy, d_bitmap, d_count};
     hipMemcpyAsync(d_desc, &h, sizeof(h), hipMemcpyHostToDevice, st);
