@@ -323,8 +323,15 @@ BLSW_FN Proj<OpsFp2> chain_cofactor(Emitter e_add, Emitter e, const Proj<OpsFp2>
         mopt = nz_double_w(e, mopt);
 #pragma unroll 1
         for (int i = 1; i < split; i++) {
-            if (bit_of(HE, off + i)) acc = nz_add_unchecked_w(e, acc, mopt);
-            mopt = nz_double_w(e, mopt);
+            if (bit_of(HE, off + i)) {
+                // the addition's and the doubling's slope denominators are both known here: one shared inversion
+                Fp2 inv_add, inv_dbl;
+                fp2_inv2(fp2_sub(mopt.x, acc.x), fp2_dbl(mopt.y), inv_add, inv_dbl);
+                acc = nz_add_unchecked_pre_w(e, acc, mopt, inv_add);
+                mopt = nz_double_pre_w(e, mopt, inv_dbl);
+            } else {
+                mopt = nz_double_w(e, mopt);
+            }
         }
         Proj<OpsFp2> diff = {acc.x, acc.y, fp2_one()};
         int diff_state = 2;

@@ -150,6 +150,29 @@ BLSW_FN Aff2 nz_add_unchecked_w(Emitter& e, const Aff2& p, const Aff2& q) {
     return {x3, y3};
 }
 
+// variants with the slope denominator's inverse precomputed (see fp2_inv2): same witnesses as the two functions above
+BLSW_FN Aff2 nz_double_pre_w(Emitter& e, const Aff2& p, const Fp2& den_inv) {
+    Fp2 x1_sqr = fp2_sqr_w(e, p.x);
+    Fp2 num = fp2_add(fp2_dbl(x1_sqr), x1_sqr);
+    Fp2 den = fp2_dbl(p.y);
+    Fp2 lambda = fp2_div_pre_w(e, num, den, den_inv);
+    Fp2 l2 = fp2_sqr_w(e, lambda);
+    Fp2 x3 = fp2_sub(l2, fp2_dbl(p.x));
+    Fp2 t = fp2_mul_w(e, lambda, fp2_sub(p.x, x3));
+    Fp2 y3 = fp2_sub(t, p.y);
+    return {x3, y3};
+}
+BLSW_FN Aff2 nz_add_unchecked_pre_w(Emitter& e, const Aff2& p, const Aff2& q, const Fp2& den_inv) {
+    Fp2 num = fp2_sub(q.y, p.y);
+    Fp2 den = fp2_sub(q.x, p.x);
+    Fp2 lambda = fp2_div_pre_w(e, num, den, den_inv);
+    Fp2 l2 = fp2_sqr_w(e, lambda);
+    Fp2 x3 = fp2_sub(fp2_sub(l2, p.x), q.x);
+    Fp2 t = fp2_mul_w(e, lambda, fp2_sub(p.x, x3));
+    Fp2 y3 = fp2_sub(t, p.y);
+    return {x3, y3};
+}
+
 // ---- value-only Jacobian arithmetic over Fp (a = 0), for g * (h^-1 mod r) before G1 allocation
 struct Jac1 {
     Fp x, y, z;

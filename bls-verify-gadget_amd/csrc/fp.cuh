@@ -249,6 +249,26 @@ BLSW_HD_NOINLINE Fp fp_inv_fermat(const Fp& a) {
 #else
 #define BLSW_WAVE_ANY(x) (x)
 #endif
+// signed 32 x 32 + 64 multiply-add: one v_mad_i64_i32 (the compiler otherwise lowers products of masked, provably
+// non-negative limbs to unsigned mads plus sign fix-ups)
+BLSW_HD int64_t mad_i64(int32_t a, int32_t b, int64_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int64_t d;
+    asm("v_mad_i64_i32 %0, vcc, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c) : "vcc");
+    return d;
+#else
+    return (int64_t)a * b + c;
+#endif
+}
+BLSW_HD int64_t mad_i64_k(int32_t konst, int32_t b, int64_t c) {  // `konst` is a compile-time constant: kept in an SGPR
+#if defined(__HIP_DEVICE_COMPILE__)
+    int64_t d;
+    asm("v_mad_i64_i32 %0, vcc, %1, %2, %3" : "=v"(d) : "s"(konst), "v"(b), "v"(c) : "vcc");
+    return d;
+#else
+    return (int64_t)konst * b + c;
+#endif
+}
 BLSW_HD_NOINLINE Fp fp_inv(const Fp& a) {
     constexpr int32_t P30[13] = BLSW_P30;
     constexpr int32_t R2_30[13] = BLSW_R2_30;
@@ -297,19 +317,19 @@ BLSW_HD_NOINLINE Fp fp_inv(const Fp& a) {
         {
             int32_t sd = d[12] >> 31, se = e[12] >> 31;
             int32_t md = (tu & sd) + (tv & se), me = (tq & sd) + (tr & se);
-            int64_t cd = (int64_t)tu * d[0] + (int64_t)tv * e[0];
-            int64_t ce = (int64_t)tq * d[0] + (int64_t)tr * e[0];
+            int64_t cd = mad_i64(tv, e[0], mad_i64(tu, d[0], 0));
+            int64_t ce = mad_i64(tr, e[0], mad_i64(tq, d[0], 0));
             md -= (int32_t)((BLSW_PINV30 * (uint32_t)cd + (uint32_t)md) & (uint32_t)M30);
             me -= (int32_t)((BLSW_PINV30 * (uint32_t)ce + (uint32_t)me) & (uint32_t)M30);
-            cd += (int64_t)P30[0] * md;
-            ce += (int64_t)P30[0] * me;
+            cd = mad_i64_k(P30[0], md, cd);
+            ce = mad_i64_k(P30[0], me, ce);
             cd >>= 30;
             ce >>= 30;
 #pragma unroll
             for (int k = 1; k < 13; k++) {
                 int32_t dk = d[k], ek = e[k];
-                cd += (int64_t)tu * dk + (int64_t)tv * ek + (int64_t)P30[k] * md;
-                ce += (int64_t)tq * dk + (int64_t)tr * ek + (int64_t)P30[k] * me;
+                cd = mad_i64_k(P30[k], md, mad_i64(tv, ek, mad_i64(tu, dk, cd)));
+                ce = mad_i64_k(P30[k], me, mad_i64(tr, ek, mad_i64(tq, dk, ce)));
                 d[k - 1] = (int32_t)cd & M30;
                 e[k - 1] = (int32_t)ce & M30;
                 cd >>= 30;
@@ -320,15 +340,15 @@ BLSW_HD_NOINLINE Fp fp_inv(const Fp& a) {
         }
         // ---- (f, g) <- t * (f, g) / 2^30
         {
-            int64_t cf = (int64_t)tu * f[0] + (int64_t)tv * g[0];
-            int64_t cg = (int64_t)tq * f[0] + (int64_t)tr * g[0];
+            int64_t cf = mad_i64(tv, g[0], mad_i64(tu, f[0], 0));
+            int64_t cg = mad_i64(tr, g[0], mad_i64(tq, f[0], 0));
             cf >>= 30;
             cg >>= 30;
 #pragma unroll
             for (int k = 1; k < 13; k++) {
                 int32_t fk = f[k], gk = g[k];
-                cf += (int64_t)tu * fk + (int64_t)tv * gk;
-                cg += (int64_t)tq * fk + (int64_t)tr * gk;
+                cf = mad_i64(tv, gk, mad_i64(tu, fk, cf));
+                cg = mad_i64(tr, gk, mad_i64(tq, fk, cg));
                 f[k - 1] = (int32_t)cf & M30;
                 g[k - 1] = (int32_t)cg & M30;
                 cf >>= 30;

@@ -453,6 +453,29 @@ __global__ __launch_bounds__(64) void k_bench_fpmul(uint32_t iters, uint32_t* ou
     if (a.l[0] == 0x12345678u && b.l[3] == 0x9abcdef0u) out[0] = a.l[1];
 }
 
+__global__ __launch_bounds__(64) void k_bench_fpinv(uint32_t iters, uint32_t* out) {
+    Fp a = fp_one();
+    a.l[0] ^= threadIdx.x * 2654435761u + 1;
+    a.l[5] ^= blockIdx.x + 1;
+    for (uint32_t i = 0; i < iters; i++) {
+        a = fp_inv(a);
+        a.l[0] ^= i + 1;  // stays < p: only the low limb changes
+        a.l[11] &= 0x0fffffffu;
+    }
+    if (a.l[0] == 0x12345678u && a.l[3] == 0x9abcdef0u) out[0] = a.l[1];
+}
+__global__ __launch_bounds__(64) void k_bench_fp2mulw(uint32_t iters, uint32_t* out) {
+    Fp2 a = fp2_one(), b = fp2_one();
+    a.c0.l[0] ^= threadIdx.x + 1;
+    b.c1.l[1] ^= blockIdx.x + 1;
+    Emitter e = {nullptr, 0};
+    for (uint32_t i = 0; i < iters; i++) {
+        a = fp2_mul_w(e, a, b);
+        b = fp2_sqr_w(e, b);
+    }
+    if (a.c0.l[0] == 0x12345678u && b.c0.l[3] == 0x9abcdef0u) out[0] = a.c1.l[1] + e.pos;
+}
+
 inline int hip_ok(hipError_t e, const char* what) {
     if (e != hipSuccess) {
         fprintf(stderr, "[blsw] %s: %s\n", what, hipGetErrorString(e));
@@ -846,18 +869,24 @@ int blsw_microbench(int which, uint32_t iters, uint32_t blocks, double* ops_per_
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     const int threads = which == 0 ? 256 : 64;
+    const double per_iter[4] = {8.0, 2.0, 1.0, 5.0};  // MADs, fp products, fp inversions, fp products (one Fp2 mul + one Fp2 sqr)
+    if (which < 0 || which > 3) return BLSW_ERR_ARG;
     for (int rep = 0; rep < 2; rep++) {  // first pass warms up
         hipEventRecord(e0, 0);
         if (which == 0)
             hipLaunchKernelGGL(k_bench_mad, dim3(blocks), dim3(threads), 0, 0, iters, d);
-        else
+        else if (which == 1)
             hipLaunchKernelGGL(k_bench_fpmul, dim3(blocks), dim3(threads), 0, 0, iters, d);
+        else if (which == 2)
+            hipLaunchKernelGGL(k_bench_fpinv, dim3(blocks), dim3(threads), 0, 0, iters, d);
+        else
+            hipLaunchKernelGGL(k_bench_fp2mulw, dim3(blocks), dim3(threads), 0, 0, iters, d);
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
     }
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
-    double per_lane = which == 0 ? 8.0 * iters : 2.0 * iters;
+    double per_lane = per_iter[which] * iters;
     *ops_per_s = per_lane * blocks * threads / (ms * 1e-3);
     hipEventDestroy(e0);
     hipEventDestroy(e1);
