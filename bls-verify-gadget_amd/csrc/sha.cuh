@@ -78,7 +78,7 @@ struct BitSink {
     }
 };
 
-BLSW_FN W32 w_xor(BitSink& s, const W32& a, const W32& b) {
+BLSW_HD W32 w_xor(BitSink& s, const W32& a, const W32& b) {
     uint32_t wm = ~a.cm & ~b.cm;
     if (wm) s.push(pext32((a.v ^ a.nm) ^ (b.v ^ b.nm), wm), popc32(wm));
     W32 r;
@@ -87,7 +87,7 @@ BLSW_FN W32 w_xor(BitSink& s, const W32& a, const W32& b) {
     r.nm = (a.nm ^ b.nm ^ (a.cm & a.v) ^ (b.cm & b.v)) & ~r.cm;
     return r;
 }
-BLSW_FN W32 w_and(BitSink& s, const W32& a, const W32& b) {
+BLSW_HD W32 w_and(BitSink& s, const W32& a, const W32& b) {
     uint32_t wm = ~a.cm & ~b.cm;
     if (wm) s.push(pext32(a.v & b.v, wm), popc32(wm));
     W32 r;
@@ -98,7 +98,7 @@ BLSW_FN W32 w_and(BitSink& s, const W32& a, const W32& b) {
     return r;
 }
 // UInt32::addmany over k operands
-BLSW_FN W32 w_addmany(BitSink& s, const W32* ops, int k) {
+BLSW_HD W32 w_addmany(BitSink& s, const W32* ops, int k) {
     uint64_t sum = 0;
     uint32_t allc = 0xffffffffu;
     for (int i = 0; i < k; i++) {
