@@ -39,16 +39,14 @@ MAD_PER_FPMUL = 300
 FPMUL_PER_INV = 570
 
 
-def synth_inputs(n, seed=0x5EED):
-    """Synthetic valid instances. Signing needs a CPU hash-to-G2 -> the oracle, used here for
-    input preparation only. 64 distinct signed instances are tiled to n (no kernel caches anything across lanes)."""
-    from tests import oracle_lib, synth
-
-    o = oracle_lib.load()
+def synth_inputs(pkg, n, seed, dev):
+    """Synthetic valid instances, minted on the GPU by the product's own signer (blsw_sign_batch):
+    64 distinct signed instances are tiled to n (no kernel caches anything across lanes)."""
+    workload = importlib.import_module("bls-verify-gadget_amd.workload")
     base = min(n, 64)
-    pk, msg, sig, expect = synth.make_batch(o, base, seed=seed)
+    pk, msg, sig, expect = workload.make_batch(pkg, base, seed=seed, device=dev)
     reps = (n + base - 1) // base
-    return (np.tile(pk, (reps, 1))[:n].copy(), np.tile(msg, (reps, 1))[:n].copy(), np.tile(sig, (reps, 1))[:n].copy(), np.tile(expect, reps)[:n].copy(), o)
+    return pk.repeat(reps, 1)[:n].contiguous(), msg.repeat(reps, 1)[:n].contiguous(), sig.repeat(reps, 1)[:n].contiguous(), np.tile(expect, reps)[:n].copy()
 
 
 def main():
@@ -81,10 +79,7 @@ def main():
     pkg.lib()
 
     n = args.batch
-    pk, msg, sig, expect, oracle = synth_inputs(n, seed=0x5EED + rank)
-    d_pk = torch.from_numpy(pk.view(np.int64)).to(dev)
-    d_sig = torch.from_numpy(sig.view(np.int64)).to(dev)
-    d_msg = torch.from_numpy(msg).to(dev)
+    d_pk, d_msg, d_sig, expect = synth_inputs(pkg, n, 0x5EED + rank, dev)
     lay = pkg.layout(32)
     # engine: up to `--coalesce` submitted batches are fused into one launch group (fills the SIMDs); witness tensors
     # are written per step, in order, into a ring of `--outputs` output tensors (a consumer would drain them in order)
@@ -142,6 +137,15 @@ def main():
     achieved = expand_bytes / (exp_avg_ms * 1e-3) / 1e9
     bytes_per_instance = 48 * (lay["n_witness"] + lay["n_instance_vars"]) + 320
     opc = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_opcount.json")))
+    # HBM bytes per k_sha_expand launch from the PMC passes committed under profiles/ (rocprofv3 refuses to be combined
+    # with the timed run); only quoted for the workload it was collected on
+    traffic = None
+    try:
+        tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["k_sha_expand"]
+        if tr["instances_per_launch"] == n and lay["msg_len"] == 32:
+            traffic = (tr["write_kib"] + tr["fetch_kib"]) * 1024.0
+    except (OSError, KeyError, ValueError):
+        pass
     mad_per_instance = (opc["fp_mul"] + opc["fp_inv"] * FPMUL_PER_INV) * MAD_PER_FPMUL
     mad_peak = pkg.microbench(0, iters=8192, blocks=8192)
     fpmul_peak = pkg.microbench(1, iters=512, blocks=8192)
@@ -161,7 +165,7 @@ def main():
         "config": {"workload": "configs[1]: batch of 1024 independent BLS-verify instances per GPU per step, 32-byte messages, full witness vectors written",
                    "instances_per_gpu_per_step": n, "batches_fused_per_launch_group": coalesce, "groups_in_flight": buffers, "output_ring": n_out, "n_witness": lay["n_witness"], "results_ok": ok},
         "roofline": {"bound": "hbm", "kernel": "k_sha_expand", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                     "traffic": None, "algorithmic_bytes_per_launch": expand_bytes, "avg_launch_ms": exp_avg_ms, "launches_timed": exp_count},
+                     "traffic": traffic, "traffic_source": "profiles/r01_pmc_hbm_traffic_final.txt (WRITE_SIZE + FETCH_SIZE per launch, bytes)", "algorithmic_bytes_per_launch": expand_bytes, "avg_launch_ms": exp_avg_ms, "launches_timed": exp_count},
         "roofline_whole_path": {"bound": "hbm", "algorithmic_bytes_per_instance": bytes_per_instance,
                                 "achieved": value / world * bytes_per_instance / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                 "frac": value / world * bytes_per_instance / 1e9 / HBM_PEAK_GBPS},
@@ -173,8 +177,12 @@ def main():
         cores = os.cpu_count() or 1
         threads = min(cores, 16)
         m = min(args.cpu_sample, n)
+        from tests import oracle_lib  # the CPU restatement: used for this baseline leg only
+
+        oracle = oracle_lib.load()
+        h_pk, h_msg, h_sig = d_pk[:m].cpu().numpy().view(np.uint64), d_msg[:m].cpu().numpy(), d_sig[:m].cpu().numpy().view(np.uint64)
         t1 = time.perf_counter()
-        oracle.witness_batch(pk[:m], msg[:m], sig[:m], threads=threads, want_digests=False)
+        oracle.witness_batch(h_pk, h_msg, h_sig, threads=threads, want_digests=False)
         cdt = time.perf_counter() - t1
         out["cpu_baseline"] = {"value": m / cdt, "unit": "instances/s", "cores": threads, "kind": "port",
                                "sample": "%d instances of the same batch through the C++ restatement of the reference path (oracle/), %d threads" % (m, threads)}

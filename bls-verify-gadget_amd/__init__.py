@@ -64,6 +64,7 @@ def lib():
         L.blsw_aggregate_workspace_bytes.argtypes = [u64, u32, u32, ctypes.POINTER(u64)]
         L.blsw_aggregate_verify_batch.argtypes = [vp, vp, u32, vp, vp, u32, u64, vp, u64, vp, vp, vp, u64, vp]
         L.blsw_decode_batch.argtypes = [vp, vp, u64, vp, vp, vp, vp]
+        L.blsw_sign_batch.argtypes = [vp, vp, u32, u64, vp, vp, vp, vp, vp, vp, u64, vp]
         L.blsw_microbench.argtypes = [ctypes.c_int, u32, u32, ctypes.POINTER(ctypes.c_double)]
         _lib = L
     return _lib
@@ -71,7 +72,7 @@ def lib():
 
 EXPORTED_SYMBOLS = ["blsw_version", "blsw_layout", "blsw_engine_workspace_bytes", "blsw_engine_create", "blsw_engine_destroy", "blsw_engine_submit",
                     "blsw_engine_flush", "blsw_engine_expand_stats", "blsw_hash_to_g2_workspace_bytes", "blsw_hash_to_g2_batch", "blsw_decode_batch", "blsw_layout_aggregate", "blsw_aggregate_workspace_bytes",
-                    "blsw_aggregate_verify_batch", "blsw_microbench"]
+                    "blsw_aggregate_verify_batch", "blsw_sign_batch", "blsw_microbench"]
 
 
 def layout(msg_len=32):
@@ -302,3 +303,31 @@ def hash_to_g2_batch(message, out=None):
     if rc:
         raise BlswError("blsw_hash_to_g2_batch failed: %d" % rc)
     return out
+
+
+ST_INVALID_SECRET_KEY = 5
+
+
+def sign_batch(sk32_le, message, want_bytes=True):
+    """BLS::sign + PublicKey::from(&sk) for a batch (bls.rs:411-425, 183-195): sk32_le [n, 32] uint8 (little-endian Fr, as
+    PrivateKey::try_from takes it), message [n, msg_len] uint8, cuda tensors.
+    Returns dict(sig96, pk48 (uint8, None unless want_bytes), sig_xy [n,24], pk_xy [n,12] int64 Montgomery, status [n] int32)."""
+    torch = _require_cuda()
+    n, msg_len = message.shape
+    assert sk32_le.shape == (n, 32) and sk32_le.is_contiguous() and message.is_contiguous()
+    dev = message.device
+    wb = ctypes.c_uint64(0)
+    lib().blsw_hash_to_g2_workspace_bytes(n, msg_len, ctypes.byref(wb))
+    ws = torch.empty(wb.value, dtype=torch.uint8, device=dev)
+    sig96 = torch.empty((n, 96), dtype=torch.uint8, device=dev) if want_bytes else None
+    pk48 = torch.empty((n, 48), dtype=torch.uint8, device=dev) if want_bytes else None
+    sig_xy = torch.empty((n, 24), dtype=torch.int64, device=dev)
+    pk_xy = torch.empty((n, 12), dtype=torch.int64, device=dev)
+    status = torch.empty(n, dtype=torch.int32, device=dev)
+    rc = lib().blsw_sign_batch(sk32_le.data_ptr(), message.data_ptr(), msg_len, n, sig96.data_ptr() if want_bytes else None, sig_xy.data_ptr(),
+                               pk48.data_ptr() if want_bytes else None, pk_xy.data_ptr(), status.data_ptr(), ws.data_ptr(), ws.numel(),
+                               torch.cuda.current_stream(dev).cuda_stream)
+    if rc:
+        raise BlswError("blsw_sign_batch failed: %d" % rc)
+    torch.cuda.synchronize(dev)
+    return {"sig96": sig96, "pk48": pk48, "sig_xy": sig_xy, "pk_xy": pk_xy, "status": status}

@@ -240,4 +240,83 @@ BLSW_FN int g2_decode(const uint8_t* in, Fp2& x, Fp2& y) {
     return DEC_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ signer
+// Native BLS::sign / PublicKey::from(&sk) for a batch (src/bls.rs:411-425, 183-195): sig = sk * H(msg), pk = sk * g1,
+// serialised as ark-serialize compressed points (ZCash flags). Value-only Jacobian ladders, one key per lane.
+enum { SIGN_OK = 0, SIGN_BAD_ENCODING = 1, SIGN_INVALID_SECRET_KEY = 5 };
+
+// 32 little-endian bytes (PrivateKey::try_from, bls.rs:97-103: deserialize_compressed of an Fr) -> 8 words.
+// SIGN_BAD_ENCODING if >= r, SIGN_INVALID_SECRET_KEY if zero (bls.rs:417-419)
+BLSW_FN int sk_from_le32(const uint8_t* in, uint32_t* w) {
+    constexpr uint32_t RW[8] = BLSW_R_WORDS;
+    uint32_t any = 0;
+    for (int i = 0; i < 8; i++) {
+        w[i] = (uint32_t)in[4 * i] | ((uint32_t)in[4 * i + 1] << 8) | ((uint32_t)in[4 * i + 2] << 16) | ((uint32_t)in[4 * i + 3] << 24);
+        any |= w[i];
+    }
+    uint32_t borrow = 0;
+    for (int i = 0; i < 8; i++) (void)subb32(w[i], RW[i], borrow);
+    if (!borrow) return SIGN_BAD_ENCODING;
+    if (!any) return SIGN_INVALID_SECRET_KEY;
+    return SIGN_OK;
+}
+// canonical big-endian bytes of a Montgomery-form element
+BLSW_FN void fp_to_be48(const Fp& a, uint8_t* out) {
+    Fp c = fp_to_canonical(a);
+    for (int w = 0; w < 12; w++) {
+        uint8_t* b = out + 44 - 4 * w;
+        b[0] = (uint8_t)(c.l[w] >> 24);
+        b[1] = (uint8_t)(c.l[w] >> 16);
+        b[2] = (uint8_t)(c.l[w] >> 8);
+        b[3] = (uint8_t)c.l[w];
+    }
+}
+BLSW_FN void g1_encode(const Fp& x, const Fp& y, bool infinity, uint8_t* out) {
+    if (infinity) {
+        for (int i = 0; i < 48; i++) out[i] = 0;
+        out[0] = 0xc0;
+        return;
+    }
+    fp_to_be48(x, out);
+    out[0] |= 0x80 | (fp_lex_largest(y) ? 0x20 : 0);
+}
+BLSW_FN void g2_encode(const Fp2& x, const Fp2& y, bool infinity, uint8_t* out) {
+    if (infinity) {
+        for (int i = 0; i < 96; i++) out[i] = 0;
+        out[0] = 0xc0;
+        return;
+    }
+    fp_to_be48(x.c1, out);
+    fp_to_be48(x.c0, out + 48);
+    out[0] |= 0x80 | (fp2_lex_largest(y) ? 0x20 : 0);
+}
+// [k]Q for an affine Q in G2, k given as 8 words; returns affine (x, y); false if the result is the identity
+BLSW_FN bool g2_mul_affine(const Fp2& qx, const Fp2& qy, const uint32_t* k, Fp2& rx, Fp2& ry) {
+    Jac2 acc = {fp2_one(), fp2_one(), fp2_zero()};
+#pragma unroll 1
+    for (int i = 254; i >= 0; i--) {
+        acc = jac2_dbl(acc);
+        if ((k[i >> 5] >> (i & 31)) & 1) acc = jac2_add_mixed(acc, qx, qy);
+    }
+    if (fp2_is_zero(acc.z)) return false;
+    Fp2 zi = fp2_inv(acc.z), zi2 = fp2_sqr(zi);
+    rx = fp2_mul(acc.x, zi2);
+    ry = fp2_mul(acc.y, fp2_mul(zi2, zi));
+    return true;
+}
+BLSW_FN bool g1_mul_affine(const Fp& qx, const Fp& qy, const uint32_t* k, Fp& rx, Fp& ry) {
+    Jac1v acc = {fp_one(), fp_one(), fp_zero()};
+#pragma unroll 1
+    for (int i = 254; i >= 0; i--) {
+        acc = jac1v_dbl(acc);
+        if ((k[i >> 5] >> (i & 31)) & 1) acc = jac1v_add_mixed(acc, qx, qy);
+    }
+    if (fp_is_zero(acc.z)) return false;
+    Fp zi = fp_inv(acc.z), zi2 = fp_sqr(zi);
+    rx = fp_mul(acc.x, zi2);
+    ry = fp_mul(acc.y, fp_mul(zi2, zi));
+    return true;
+}
+
+
 }  // namespace blsw

@@ -425,6 +425,48 @@ __global__ __launch_bounds__(64) void k_h_to_affine(uint64_t n, Workspace ws, ui
     st_fp(o + 3, y.c1);
 }
 
+// native signer (bls.rs:411-425, 183-195): lanes [0, n) sig_i = sk_i * H(msg_i) (H projective in ws.h), lanes [n, 2n)
+// pk_i = sk_i * g1. Outputs (each optional): compressed bytes and affine Montgomery limbs; status[i] (SIGN_*)
+__global__ __launch_bounds__(64) void k_sign(uint64_t n, Workspace ws, const uint8_t* __restrict__ sk32, uint8_t* sig96, uint64_t* sig_xy, uint8_t* pk48,
+                                             uint64_t* pk_xy, int32_t* status) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 2 * n) return;
+    const uint64_t i = t < n ? t : t - n;
+    uint32_t k[8];
+    int st = sk_from_le32(sk32 + i * 32, k);
+    if (t < n) {
+        Fp2 x = fp2_zero(), y = fp2_zero();
+        bool inf = true;
+        if (st == SIGN_OK) {
+            Proj<OpsFp2> h = ld_proj2(ws.h + i, n);
+            if (!fp2_is_zero(h.z)) {
+                Fp2 zi = fp2_inv(h.z);
+                Fp2 hx = fp2_mul(h.x, zi), hy = fp2_mul(h.y, zi);
+                inf = !g2_mul_affine(hx, hy, k, x, y);
+            }
+        }
+        if (sig_xy) {
+            Fp* o = reinterpret_cast<Fp*>(sig_xy + i * 24);
+            st_fp(o, x.c0);
+            st_fp(o + 1, x.c1);
+            st_fp(o + 2, y.c0);
+            st_fp(o + 3, y.c1);
+        }
+        if (sig96) g2_encode(x, y, inf, sig96 + i * 96);
+        status[i] = st;
+    } else {
+        Fp x = fp_zero(), y = fp_zero();
+        bool inf = true;
+        if (st == SIGN_OK) inf = !g1_mul_affine(K_G1_GEN_X(), fp_neg(K_G1_GEN_NEG_Y()), k, x, y);
+        if (pk_xy) {
+            Fp* o = reinterpret_cast<Fp*>(pk_xy + i * 12);
+            st_fp(o, x);
+            st_fp(o + 1, y);
+        }
+        if (pk48) g1_encode(x, y, inf, pk48 + i * 48);
+    }
+}
+
 // ---- micro-benchmarks (roofline denominators): measured on the device, not assumed
 __global__ __launch_bounds__(256) void k_bench_mad(uint32_t iters, uint32_t* out) {
     uint32_t x = threadIdx.x * 2654435761u + blockIdx.x, y = x ^ 0x9e3779b9u;
@@ -783,6 +825,32 @@ int blsw_hash_to_g2_batch(const uint8_t* d_msg, uint32_t msg_len, uint64_t n, ui
     hipLaunchKernelGGL(k_map, dim3(g2), dim3(64), 0, st, g);
     hipLaunchKernelGGL(k_cofactor, dim3(g1), dim3(64), 0, st, g);
     hipLaunchKernelGGL(k_h_to_affine, dim3(g1), dim3(64), 0, st, n, g.ws, d_out_affine);
+    return hip_ok(hipGetLastError(), "launch");
+}
+// BLS::sign + PublicKey::from(&sk) for a batch (bls.rs:411-425, 183-195). Workspace: blsw_hash_to_g2_workspace_bytes.
+int blsw_sign_batch(const uint8_t* d_sk32_le, const uint8_t* d_msg, uint32_t msg_len, uint64_t n, uint8_t* d_sig96, uint64_t* d_sig_xy, uint8_t* d_pk48,
+                    uint64_t* d_pk_xy, int32_t* d_status, void* d_workspace, uint64_t workspace_bytes, void* stream_) {
+    if (!d_sk32_le || (!d_msg && msg_len) || n == 0 || !d_workspace || !d_status) return BLSW_ERR_ARG;
+    Group g;
+    make_layout(msg_len, &g.L);
+    g.LS = staging_layout(g.L);
+    StepDesc* d_desc = reinterpret_cast<StepDesc*>(d_workspace);
+    g.ws = carve(reinterpret_cast<char*>(d_workspace) + 256, n, g.L, false);
+    if (g.ws.total_bytes + 256 > workspace_bytes) return BLSW_ERR_WORKSPACE;
+    g.N = n;
+    g.n = (uint32_t)n;
+    g.msg_len = msg_len;
+    g.desc = d_desc;
+    g.chain_prio = 0;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream_);
+    StepDesc h = {nullptr, nullptr, d_msg, nullptr, 0, nullptr, nullptr, nullptr, nullptr};
+    hipMemcpyAsync(d_desc, &h, sizeof(h), hipMemcpyHostToDevice, st);
+    hipStreamSynchronize(st);  // `h` is a stack object
+    const unsigned g1 = (unsigned)((n + 63) / 64), g2 = (unsigned)((2 * n + 63) / 64);
+    hipLaunchKernelGGL(k_sha_values, dim3(g1), dim3(64), 0, st, g);
+    hipLaunchKernelGGL(k_map, dim3(g2), dim3(64), 0, st, g);
+    hipLaunchKernelGGL(k_cofactor, dim3(g1), dim3(64), 0, st, g);
+    hipLaunchKernelGGL(k_sign, dim3(g2), dim3(64), 0, st, n, g.ws, d_sk32_le, d_sig96, d_sig_xy, d_pk48, d_pk_xy, d_status);
     return hip_ok(hipGetLastError(), "launch");
 }
 int blsw_layout_aggregate(uint32_t msg_len, uint32_t n_keys, blsw_layout_t* out) {

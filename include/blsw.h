@@ -106,6 +106,18 @@ int blsw_hash_to_g2_workspace_bytes(uint64_t n, uint32_t msg_len, uint64_t* byte
 int blsw_hash_to_g2_batch(const uint8_t* d_msg, uint32_t msg_len, uint64_t n, uint64_t* d_out_affine, void* d_workspace, uint64_t workspace_bytes,
                           void* stream);
 
+/* Native signer for a batch: BLS::sign (src/bls.rs:411-425: sig = sk * H(msg); Err(InvalidSecretKey) for sk = 0) and
+ * PublicKey::from(&sk) (src/bls.rs:183-195: pk = sk * g1). One key per instance.
+ *   d_sk32_le [n][32]  secret keys as PrivateKey::try_from(&[u8]) takes them (src/bls.rs:97-103): little-endian Fr
+ *   outputs, each nullable except d_status: d_sig96 [n][96] / d_pk48 [n][48] compressed points as Signature / PublicKey
+ *   serialise (src/bls.rs:244-260, 341-357), d_sig_xy [n][24] / d_pk_xy [n][12] affine Montgomery limbs (engine input)
+ *   d_status [n] int32: BLSW_ST_OK, BLSW_ST_BAD_ENCODING (sk >= r) or BLSW_ST_INVALID_SECRET_KEY (sk = 0); on error
+ *   the outputs of that instance are the identity encoding / zeros.
+ * Workspace: blsw_hash_to_g2_workspace_bytes(n, msg_len). */
+#define BLSW_ST_INVALID_SECRET_KEY 5
+int blsw_sign_batch(const uint8_t* d_sk32_le, const uint8_t* d_msg, uint32_t msg_len, uint64_t n, uint8_t* d_sig96, uint64_t* d_sig_xy, uint8_t* d_pk48,
+                    uint64_t* d_pk_xy, int32_t* d_status, void* d_workspace, uint64_t workspace_bytes, void* stream);
+
 /* Device micro-benchmarks that give the VALU roofline its MEASURED denominator:
  * which = 0: v_mad_u64_u32 rate (32x32+64 multiply-adds per second, all CUs); which = 1: Fp Montgomery products per second. */
 int blsw_microbench(int which, uint32_t iters, uint32_t blocks, double* ops_per_s);

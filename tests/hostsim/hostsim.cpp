@@ -121,6 +121,22 @@ int hostsim_g2_decode(const uint8_t* in, uint64_t* out_xy) {
     memcpy(out_xy + 18, y.c1.l, 48);
     return st;
 }
+// signer logic (decode.cuh): sk (32 LE bytes), H(msg) affine -> sig96, pk48; returns the SIGN_* status
+int hostsim_sign(const uint8_t* sk32, const uint64_t* h_xy, uint8_t* sig96, uint8_t* pk48) {
+    uint32_t k[8];
+    int st = sk_from_le32(sk32, k);
+    Fp2 x = fp2_zero(), y = fp2_zero();
+    Fp px = fp_zero(), py = fp_zero();
+    bool sinf = true, pinf = true;
+    if (st == SIGN_OK) {
+        Fp2 hx = {load_fp(h_xy), load_fp(h_xy + 6)}, hy = {load_fp(h_xy + 12), load_fp(h_xy + 18)};
+        sinf = !g2_mul_affine(hx, hy, k, x, y);
+        pinf = !g1_mul_affine(K_G1_GEN_X(), fp_neg(K_G1_GEN_NEG_Y()), k, px, py);
+    }
+    g2_encode(x, y, sinf, sig96);
+    g1_encode(px, py, pinf, pk48);
+    return st;
+}
 // field micro-checks
 void hostsim_fp_mul(const uint64_t* a, const uint64_t* b, uint64_t* r) {
     Fp z = fp_mul(load_fp(a), load_fp(b));

@@ -59,3 +59,13 @@ def witness_aggregate(pks_xy, bitmap, msg, sig_xy):
     r = load().hostsim_witness_aggregate(pks_xy.ctypes.data_as(u64p), bitmap.ctypes.data_as(u8p), K, buf, len(msg), sig_xy.ctypes.data_as(u64p),
                                          out.ctypes.data_as(u64p), ctypes.byref(cnt), ctypes.byref(L))
     return r, cnt.value, out, {n: getattr(L, n) for n in _FIELDS}
+
+
+def sign(sk_le32, h_xy):
+    """device signer logic on the host: (status, sig96, pk48)"""
+    h_xy = np.ascontiguousarray(h_xy, dtype=np.uint64)
+    sk = (ctypes.c_uint8 * 32).from_buffer_copy(bytes(sk_le32))
+    sig = (ctypes.c_uint8 * 96)()
+    pk = (ctypes.c_uint8 * 48)()
+    st = load().hostsim_sign(sk, h_xy.ctypes.data_as(u64p), sig, pk)
+    return st, bytes(sig), bytes(pk)

@@ -150,3 +150,31 @@ def test_aggregate_verify_device_logic(oracle):
         bad = np.nonzero((w != out).any(axis=1))[0]
         assert len(bad) == 0, "first mismatching witness index %d" % bad[0]
         assert bool(r) == res == want and c == cnt == want_count
+
+
+@pytest.mark.parametrize("name,case", eth_cases("sign"))
+def test_sign_device_logic(oracle, name, case):
+    """Signer ladders + point encoding (decode.cuh) against tests/test_cases/sign/*.json (tests.rs:203-237: big-endian
+    privkey in the JSON; null output <=> sk == 0); H(msg) is supplied by the oracle, pk is checked against the oracle."""
+    sk = int.from_bytes(unhex(case["input"]["privkey"]), "big")
+    msg = unhex(case["input"]["message"])
+    _, h_xy = oracle.hash_to_g2(msg)
+    st, sig, pk = hostsim_lib.sign(sk.to_bytes(32, "little"), h_xy)
+    if case["output"] is None:
+        assert st == 5  # SIGN_INVALID_SECRET_KEY
+        assert sig == bytes([0xC0]) + bytes(95) and pk == bytes([0xC0]) + bytes(47)
+    else:
+        assert st == 0
+        assert sig == unhex(case["output"])
+        assert pk == oracle.sk_to_pk(sk)
+
+
+def test_sign_rejects_noncanonical_secret_key(oracle):
+    r = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+    _, h_xy = oracle.hash_to_g2(b"\0" * 32)
+    assert hostsim_lib.sign(r.to_bytes(32, "little"), h_xy)[0] == 1  # SIGN_BAD_ENCODING
+    assert hostsim_lib.sign((r - 1).to_bytes(32, "little"), h_xy)[0] == 0
+    # bls.rs:602-614 literal key -> pk equals the oracle's (pinned through the aggregate literal in test_oracle_fixtures)
+    sk_le = bytes.fromhex(LIT["sk_limbs"]["hex_le"])
+    st, _, pk = hostsim_lib.sign(sk_le, h_xy)
+    assert st == 0 and pk == oracle.sk_to_pk(int.from_bytes(sk_le, "little"))

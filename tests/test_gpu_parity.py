@@ -248,3 +248,43 @@ def test_fast_aggregate_verify_fixtures(pkg, oracle):
         assert np.array_equal(ow, w[0])
         done += 1
     assert done >= 6
+
+
+def test_sign_batch_fixtures_and_synthetic_workload(pkg, oracle):
+    """blsw_sign_batch (bls.rs:411-425, 183-195) against tests/test_cases/sign/*.json, the CPU oracle, and the oracle-built
+    synthetic batch of tests/synth.py (the bench's inputs are minted by this entry point)."""
+    import torch
+
+    dev = torch.device("cuda:0")
+    cases = [c for _, c in eth_cases("sign")]
+    r_mod = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+    sks = [int.from_bytes(unhex(c["input"]["privkey"]), "big") for c in cases] + [r_mod, r_mod - 1]
+    msgs = [unhex(c["input"]["message"]) for c in cases] + [b"\x11" * 32, b"\x22" * 32]
+    sk = np.frombuffer(b"".join(s.to_bytes(32, "little") for s in sks), dtype=np.uint8).reshape(-1, 32).copy()
+    msg = np.frombuffer(b"".join(msgs), dtype=np.uint8).reshape(-1, 32).copy()
+    r = pkg.sign_batch(torch.from_numpy(sk).to(dev), torch.from_numpy(msg).to(dev))
+    st = r["status"].cpu().numpy()
+    sig = r["sig96"].cpu().numpy()
+    pk = r["pk48"].cpu().numpy()
+    n_zero = 0
+    for i, c in enumerate(cases):
+        if c["output"] is None:
+            assert st[i] == pkg.ST_INVALID_SECRET_KEY and sig[i].tobytes() == bytes([0xC0]) + bytes(95)
+            n_zero += 1
+        else:
+            assert st[i] == 0 and sig[i].tobytes() == unhex(c["output"])
+            assert pk[i].tobytes() == oracle.sk_to_pk(sks[i])
+    assert n_zero == 1
+    assert st[-2] == pkg.ST_BAD_ENCODING and st[-1] == 0
+    assert sig[-1].tobytes() == oracle.sign(r_mod - 1, msgs[-1])
+    # affine limb outputs == decoding the compressed outputs
+    pk_xy, sig_xy, dst = pkg.decode_batch(r["pk48"], r["sig96"])
+    ok = st == 0
+    assert (dst.cpu().numpy()[ok] == 0).all()
+    assert (pk_xy.cpu().numpy()[ok] == r["pk_xy"].cpu().numpy()[ok]).all() and (sig_xy.cpu().numpy()[ok] == r["sig_xy"].cpu().numpy()[ok]).all()
+    # the GPU-minted workload equals the oracle-minted one
+    workload = importlib.import_module("bls-verify-gadget_amd.workload")
+    gpk, gmsg, gsig, gexp = workload.make_batch(pkg, 48, seed=0x5EED, device=dev)
+    opk, omsg, osig, oexp = synth.make_batch(oracle, 48, seed=0x5EED)
+    assert (gpk.cpu().numpy().view(np.uint64) == opk).all() and (gsig.cpu().numpy().view(np.uint64) == osig).all()
+    assert (gmsg.cpu().numpy() == omsg).all() and (gexp == oexp).all()

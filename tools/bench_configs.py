@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Side measurements for SURVEY.md §8d configs 4 and 5 and the entry points around the hot path (one JSON line each):
+hash-to-G2 over 1 M messages, same-message aggregate_verify with 128 keys, input decode, signer. Not the headline bench."""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("HSA_SCRATCH_SINGLE_LIMIT_ASYNC", str(8 << 30))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--hash-n", type=int, default=1 << 20)
+    ap.add_argument("--hash-chunk", type=int, default=1 << 16)
+    ap.add_argument("--agg-n", type=int, default=1024)
+    ap.add_argument("--agg-keys", type=int, default=128)
+    ap.add_argument("--sign-n", type=int, default=16384)
+    args = ap.parse_args()
+    import torch
+
+    dev = torch.device("cuda:0")
+    pkg = importlib.import_module("bls-verify-gadget_amd")
+    workload = importlib.import_module("bls-verify-gadget_amd.workload")
+    pkg.lib()
+
+    def timed(fn):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = fn()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, r
+
+    # config 5: msg_i = SHA-256(seed || "h" || i); instance 0 is the 32-zero-byte message of bls.rs:645 by convention
+    chunk = min(args.hash_chunk, args.hash_n)
+    out = torch.empty((chunk, 24), dtype=torch.int64, device=dev)
+    msgs = workload.messages(0x5EED, 0, chunk, tag=b"h")
+    msgs[0] = 0
+    d = torch.from_numpy(msgs).to(dev)
+    pkg.hash_to_g2_batch(d, out=out)  # warm-up
+    torch.cuda.synchronize()
+    first = out[0].cpu().numpy().view(np.uint64).tolist()
+    total = 0.0
+    done = 0
+    while done < args.hash_n:
+        dt, _ = timed(lambda: pkg.hash_to_g2_batch(d, out=out))
+        total += dt
+        done += chunk
+    print(json.dumps({"workload": "configs[4] hash-to-G2 (SURVEY 8d config 5)", "messages": done, "chunk": chunk, "seconds": total, "value": done / total,
+                      "unit": "messages/s", "first_output_x_c0_limbs": first[:6]}))
+
+    # signer + key derivation
+    sk = np.frombuffer(b"".join((k.to_bytes(32, "little")) for k in workload.secret_keys(0x5EED, 16)) * (args.sign_n // 16), dtype=np.uint8).reshape(-1, 32).copy()
+    m = workload.messages(0x5EED, 0, sk.shape[0])
+    dsk, dm = torch.from_numpy(sk).to(dev), torch.from_numpy(m).to(dev)
+    pkg.sign_batch(dsk, dm)
+    dt, r = timed(lambda: pkg.sign_batch(dsk, dm))
+    print(json.dumps({"workload": "sign + sk->pk (bls.rs:411-425)", "instances": sk.shape[0], "seconds": dt, "value": sk.shape[0] / dt, "unit": "signatures/s"}))
+    # decode of the compressed outputs
+    pkg.decode_batch(r["pk48"], r["sig96"])
+    dt, _ = timed(lambda: pkg.decode_batch(r["pk48"], r["sig96"]))
+    print(json.dumps({"workload": "decode pk48 + sig96 incl. subgroup checks (bls.rs:219-242, 316-339)", "instances": sk.shape[0], "seconds": dt,
+                      "value": sk.shape[0] / dt, "unit": "instances/s"}))
+
+    # config 4 (reference-defined variant): same-message aggregate_verify, K keys, all-ones bitmap
+    n, K = args.agg_n, args.agg_keys
+    sks = workload.secret_keys(0x5EED, K)
+    ksk = np.frombuffer(b"".join(s.to_bytes(32, "little") for s in sks), dtype=np.uint8).reshape(K, 32).copy()
+    msg1 = workload.messages(0x5EED, 7, 1)
+    kr = pkg.sign_batch(torch.from_numpy(ksk).to(dev), torch.from_numpy(np.repeat(msg1, K, 0)).to(dev), want_bytes=False)
+    agg_sk = sum(sks) % workload.R_MOD
+    ar = pkg.sign_batch(torch.from_numpy(np.frombuffer(agg_sk.to_bytes(32, "little"), dtype=np.uint8).reshape(1, 32).copy()).to(dev), torch.from_numpy(msg1).to(dev),
+                        want_bytes=False)
+    pks = kr["pk_xy"].unsqueeze(0).repeat(n, 1, 1).contiguous()
+    bitmap = torch.ones((n, K), dtype=torch.uint8, device=dev)
+    sig = ar["sig_xy"].repeat(n, 1).contiguous()
+    dmsg = torch.from_numpy(np.repeat(msg1, n, 0)).to(dev)
+    for want in (False, True):
+        pkg.aggregate_verify(pkg.ParametersVar(), pkg.PublicKeyVar(pks), bitmap, dmsg, pkg.SignatureVar(sig), want_witness=want)
+        dt, (res, cnt, _) = timed(lambda: pkg.aggregate_verify(pkg.ParametersVar(), pkg.PublicKeyVar(pks), bitmap, dmsg, pkg.SignatureVar(sig), want_witness=want))
+        print(json.dumps({"workload": "configs[3] aggregate_verify, %d keys, all-ones bitmap (constraints.rs:153-191)" % K, "instances": n, "witness_written": want,
+                          "seconds": dt, "value": n / dt, "unit": "instances/s", "all_true": bool((res == 1).all().item()), "count_ok": bool((cnt == K).all().item())}))
+
+
+if __name__ == "__main__":
+    main()
