@@ -8,6 +8,7 @@
 #include "chains.cuh"
 #include "decode.cuh"
 #include "layout.h"
+#include "team.cuh"
 
 using namespace blsw;
 
@@ -23,11 +24,25 @@ struct Workspace {
     Fp* h;           // [6][N]   H(m) projective
     Fp* pkaff;       // [2][N]   prepare_g1(pk)
     Fp* coeff;       // [2][272][N]  line coefficients: 0 = H(m), 1 = sig
-    Fp* staging;     // [staging_rows][N] field witnesses, element-major (engine mode), or nullptr (direct mode)
+    Fp* staging;     // [N/64][split_row][64] field witnesses (engine mode), or nullptr (direct mode): each wave of 64
+                     // instances owns one contiguous tile and appends 3 KiB rows to it (sequential HBM writes per wave)
+    uint64_t staging_rows;
+    Fp* pair;            // [N][pair_rows]: rows >= split_row of the staging coordinates (Miller loop, final exponentiation,
+    uint32_t split_row;  // is_one), instance-major: the six-lane pairing kernel appends each instance's segment sequentially
+    uint32_t pair_rows;  // (split_row = staging_rows, pair_rows = 0 when the single-lane pairing kernel is in use)
     uint64_t sha_words;
     uint64_t total_bytes;
 };
 inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
+// pairing segment: six lanes per instance (default) or the single-lane chain (BLSW_PAIRING=lane, kept for A/B runs)
+static bool pairing_team_mode() {
+    static int mode = -1;
+    if (mode < 0) {
+        const char* s = getenv("BLSW_PAIRING");
+        mode = (s && s[0] == 'l') ? 0 : 1;
+    }
+    return mode == 1;
+}
 Workspace carve(void* base, uint64_t N, const blsw_layout_t& L, bool with_staging) {
     Workspace w;
     w.sha_words = (L.sha_bits + 31) / 32 + 1;
@@ -43,7 +58,11 @@ Workspace carve(void* base, uint64_t N, const blsw_layout_t& L, bool with_stagin
     w.h = reinterpret_cast<Fp*>(take(6 * N * sizeof(Fp)));
     w.pkaff = reinterpret_cast<Fp*>(take(2 * N * sizeof(Fp)));
     w.coeff = reinterpret_cast<Fp*>(take(2ull * 272 * N * sizeof(Fp)));
-    w.staging = with_staging ? reinterpret_cast<Fp*>(take((uint64_t)(L.n_witness - L.sha_bits) * N * sizeof(Fp))) : nullptr;
+    w.staging_rows = L.n_witness - L.sha_bits;
+    w.split_row = pairing_team_mode() ? L.off_miller - L.sha_bits : (uint32_t)w.staging_rows;
+    w.pair_rows = (uint32_t)w.staging_rows - w.split_row;
+    w.staging = with_staging ? reinterpret_cast<Fp*>(take((uint64_t)w.split_row * align_up(N, 64) * sizeof(Fp))) : nullptr;
+    w.pair = with_staging && w.pair_rows ? reinterpret_cast<Fp*>(take((uint64_t)w.pair_rows * N * sizeof(Fp))) : nullptr;
     w.total_bytes = off;
     return w;
 }
@@ -113,9 +132,15 @@ __device__ __forceinline__ LaneId lane_id(const Group& g, uint64_t I) {
 __device__ __forceinline__ Emitter emitter(const Group& g, const LaneId& id, uint32_t off_full, uint32_t off_staging) {
     Emitter e;
     if (g.ws.staging) {
-        e.base = reinterpret_cast<uint32_t*>(g.ws.staging + id.I);
+        if (off_staging >= g.ws.split_row) {  // instance-major rows of the pairing segments
+            e.base = reinterpret_cast<uint32_t*>(g.ws.pair + id.I * g.ws.pair_rows);
+            e.pos = off_staging - g.ws.split_row;
+            e.stride = 12;
+            return e;
+        }
+        e.base = reinterpret_cast<uint32_t*>(g.ws.staging + (id.I >> 6) * (uint64_t)g.ws.split_row * 64 + (id.I & 63));
         e.pos = off_staging;
-        e.stride = g.N * 12;
+        e.stride = 64 * 12;
         return e;
     }
     const StepDesc& d = g.desc[id.s];
@@ -210,15 +235,19 @@ __global__ __launch_bounds__(384) void k_sha_expand(const uint32_t* __restrict__
         }
     }
 }
-// Engine mode: the field witnesses of one step, staged element-major, are moved into place around the SHA segment.
+// Engine mode: the field witnesses of one step are moved into place around the SHA segment. Rows below split_row are staged
+// in 64-instance tiles ([tile][row][64]: 48-byte gathers), the pairing rows instance-major (contiguous copies).
 // 16-byte chunk q of instance i covers elements [0, off_expand) and [off_expand + sha_bits, n_witness). Every block
-// writes 32 KiB contiguous of ONE instance's vector (reads are 48-byte gathers from the staging rows). An LDS-transposed
-// variant with contiguous reads and 384-byte writes was measured slower (3.8 ms vs 1.8 ms per 1024 instances).
-__global__ __launch_bounds__(256) void k_place_field(const Fp* __restrict__ staging, uint64_t N, uint64_t first, uint32_t off_expand, uint32_t sha_bits,
-                                                     uint32_t staging_rows, uint64_t* __restrict__ d_witness, uint64_t stride) {
+// writes 32 KiB contiguous of ONE instance's vector. An LDS-transposed variant with contiguous reads and 384-byte
+// writes was measured slower (3.8 ms vs 1.8 ms per 1024 instances).
+__global__ __launch_bounds__(256) void k_place_field(const Fp* __restrict__ staging, const Fp* __restrict__ pair, uint64_t first, uint32_t off_expand,
+                                                     uint32_t sha_bits, uint32_t staging_rows, uint32_t split_row, uint64_t* __restrict__ d_witness,
+                                                     uint64_t stride) {
     const uint64_t inst = blockIdx.y;
     const uint32_t nchunks = staging_rows * 3;
-    const uint4* src = reinterpret_cast<const uint4*>(staging + first + inst);
+    const uint64_t lane = first + inst;
+    const uint4* src = reinterpret_cast<const uint4*>(staging + (lane >> 6) * (uint64_t)split_row * 64 + (lane & 63));
+    const uint4* src2 = reinterpret_cast<const uint4*>(pair + lane * (uint64_t)(staging_rows - split_row));
     uint4* out = reinterpret_cast<uint4*>(d_witness + inst * stride * 6);
     uint32_t q0 = blockIdx.x * (256 * 8) + threadIdx.x;
 #pragma unroll
@@ -226,7 +255,7 @@ __global__ __launch_bounds__(256) void k_place_field(const Fp* __restrict__ stag
         uint32_t q = q0 + k * 256;
         if (q < nchunks) {
             uint32_t e = q / 3, c = q - e * 3;
-            uint4 v = src[(uint64_t)e * N * 3 + c];
+            uint4 v = e < split_row ? src[(uint64_t)e * 64 * 3 + c] : src2[(uint64_t)(e - split_row) * 3 + c];
             uint32_t dst_e = e < off_expand ? e : e + sha_bits;
             out[(uint64_t)dst_e * 3 + c] = v;
         }
@@ -384,6 +413,40 @@ __global__ __launch_bounds__(64) void k_pairing(Group g) {
     bool res = chain_final_exp_is_one(EMIT(g, id, off_final_exp), EMIT(g, id, off_is_one), f);
     int32_t* r = g.desc[id.s].result;
     if (r) r[id.i] = res ? 1 : 0;
+}
+
+// Miller loop + final exponentiation + is_one, SIX LANES PER INSTANCE (team.cuh): ten instances per wave, every Fp12
+// value distributed over the team's registers, operands and products exchanged through the team's 3.5 KB slot file in LDS
+#define BLSW_TEAMS_PER_WAVE 10
+__global__ __launch_bounds__(64) void k_pairing_team(Group g) {
+    __shared__ Fp2 lds[BLSW_TEAMS_PER_WAVE * TS_NSLOTS];
+    if (g.chain_prio) __builtin_amdgcn_s_setprio(3);
+    const uint32_t team = threadIdx.x / 6, j = threadIdx.x % 6;
+    const uint64_t I0 = (uint64_t)blockIdx.x * BLSW_TEAMS_PER_WAVE + team;
+    const bool active = team < BLSW_TEAMS_PER_WAVE && I0 < g.N;
+    const uint64_t I = active ? I0 : 0, N = g.N;  // idle lanes only take part in the barriers
+    LaneId id = lane_id(g, I);
+    TeamLanes<CoeffStrided> t;
+    t.slots = lds + (active ? team : 0) * TS_NSLOTS;
+    t.j = j;
+    t.active = active;
+    t.coeff_h = {g.ws.coeff + I, N};
+    t.coeff_sig = {g.ws.coeff + 272ull * N + I, N};
+    t.e = EMIT(g, id, off_miller);
+    if (!active) t.e.base = nullptr;
+    t.set_consts(ld_fp(g.ws.pkaff + I), ld_fp(g.ws.pkaff + N + I));
+    Fp2 f = team_miller(t);
+    Emitter e_one = EMIT(g, id, off_is_one);
+    if (!active) e_one.base = nullptr;
+    bool res = team_final_exp_is_one(t, f, e_one);
+    int32_t* r = g.desc[id.s].result;
+    if (active && j == 0 && r) r[id.i] = res ? 1 : 0;
+}
+static void launch_pairing(const Group& g, hipStream_t st) {
+    if (!pairing_team_mode())
+        hipLaunchKernelGGL(k_pairing, dim3((unsigned)((g.N + 63) / 64)), dim3(64), 0, st, g);
+    else
+        hipLaunchKernelGGL(k_pairing_team, dim3((unsigned)((g.N + BLSW_TEAMS_PER_WAVE - 1) / BLSW_TEAMS_PER_WAVE)), dim3(64), 0, st, g);
 }
 
 // input decode: lanes [0, n) decompress pk (48 B), lanes [n, 2n) decompress sig (96 B); status[i][0] / status[i][1]
@@ -628,7 +691,7 @@ static int launch_group(blsw_engine* e, hipStream_t user_stream) {
     hipLaunchKernelGGL(k_prepare, dim3(g1), dim3(64), 0, st, g, 0);
     hipStreamWaitEvent(st, b.ev_aux[0], 0);
     hipStreamWaitEvent(st, b.ev_aux[1], 0);
-    hipLaunchKernelGGL(k_pairing, dim3(g1), dim3(64), 0, st, g);
+    launch_pairing(g, st);
     hipStreamWaitEvent(st, b.ev_aux[2], 0);
     hipEventRecord(b.ev_chains, st);
     // placement, per step, in submission order
@@ -655,8 +718,8 @@ static int launch_group(blsw_engine* e, hipStream_t user_stream) {
         if (e->staged) {
             const uint32_t rows = e->L.n_witness - e->L.sha_bits;
             dim3 grid2((rows * 3 + 2047) / 2048, (unsigned)e->n);
-            hipLaunchKernelGGL(k_place_field, grid2, dim3(256), 0, e->place, g.ws.staging, g.N, (uint64_t)s * e->n, e->L.off_expand, e->L.sha_bits, rows,
-                               d.out, d.out_stride);
+            hipLaunchKernelGGL(k_place_field, grid2, dim3(256), 0, e->place, g.ws.staging, g.ws.pair, (uint64_t)s * e->n, e->L.off_expand, e->L.sha_bits, rows,
+                               g.ws.split_row, d.out, d.out_stride);
         }
     }
     hipEventRecord(b.ev_done, e->place);
@@ -911,7 +974,7 @@ int blsw_aggregate_verify_batch(const uint64_t* d_pks_xy, const uint8_t* d_bitma
     hipLaunchKernelGGL(k_map, dim3(g2), dim3(64), 0, st, g);
     hipLaunchKernelGGL(k_cofactor, dim3(g1), dim3(64), 0, st, g);
     hipLaunchKernelGGL(k_prepare, dim3(g1), dim3(64), 0, st, g, 0);
-    hipLaunchKernelGGL(k_pairing, dim3(g1), dim3(64), 0, st, g);
+    launch_pairing(g, st);
     return hip_ok(hipGetLastError(), "launch");
 }
 int blsw_decode_batch(const uint8_t* d_pk48, const uint8_t* d_sig96, uint64_t n, uint64_t* d_pk_xy, uint64_t* d_sig_xy, int32_t* d_status, void* stream_) {

@@ -7,6 +7,8 @@
 #include "../../bls-verify-gadget_amd/csrc/chains.cuh"
 #include "../../bls-verify-gadget_amd/csrc/decode.cuh"
 #include "../../bls-verify-gadget_amd/csrc/layout.h"
+#include "../../bls-verify-gadget_amd/csrc/team.cuh"
+#include <array>
 
 using namespace blsw;
 
@@ -16,7 +18,94 @@ static Fp load_fp(const uint64_t* p) {
     return r;
 }
 
+
+// the six-lanes-per-instance program of team.cuh, lanes run one after the other per phase
+struct TeamHost {
+    typedef std::array<Fp2, 6> Reg;
+    Fp2 slots[TS_NSLOTS];
+    Emitter e;
+    CoeffLinear coeff_sig, coeff_h;
+    Reg zero() const {
+        Reg r;
+        r.fill(fp2_zero());
+        return r;
+    }
+    Reg exec(const TeamOp& T, const Reg& a, const Reg& b) {
+        for (uint32_t j = 0; j < 6; j++) {
+            team_st(slots, TS_IN0 + j, a[j]);
+            team_st(slots, TS_IN1 + j, b[j]);
+        }
+        for (uint32_t r = 0; r < T.rounds; r++)
+            for (uint32_t j = 0; j < 6; j++) team_task(T.task[r][j], slots, e);
+        Reg out;
+        for (uint32_t j = 0; j < 6; j++) out[j] = team_gather(T.out[j], slots);
+        e.pos += T.n_witness;
+        return out;
+    }
+    Reg conj(const Reg& a) const {
+        Reg r;
+        for (uint32_t j = 0; j < 6; j++) r[j] = team_conj(j, a[j]);
+        return r;
+    }
+    Reg frob(const Reg& a, int power) const {
+        Reg r;
+        for (uint32_t j = 0; j < 6; j++) r[j] = team_frob(j, a[j], power);
+        return r;
+    }
+    void set_consts(const Fp& pkx, const Fp& pky) {
+        for (uint32_t j = 0; j < 6; j++) team_set_consts_lane(j, slots, pkx, pky);
+    }
+    void load_coeffs(uint32_t k) {
+        for (uint32_t j = 0; j < 6; j++) team_load_coeff_lane(j, slots, coeff_sig, coeff_h, k);
+    }
+    Reg first_f() const {
+        Reg r;
+        for (uint32_t j = 0; j < 6; j++) r[j] = team_first_f(j, slots);
+        return r;
+    }
+    Reg inverse_w(const Reg& a) {
+        for (uint32_t j = 0; j < 6; j++) team_st(slots, TS_IN0 + j, a[j]);
+        team_inverse_lane0(slots);
+        Reg inv;
+        for (uint32_t j = 0; j < 6; j++) {
+            inv[j] = team_ld(slots, TS_IN1 + j);
+            Emitter w = e;
+            w.pos += 2 * j;
+            w.put(inv[j].c0);
+            w.put(inv[j].c1);
+        }
+        e.pos += 12;
+        exec(TEAM_OP_INVCHK, a, inv);
+        return inv;
+    }
+    bool is_one_w(const Reg& a, const Emitter& e_one) {
+        bool b[6];
+        for (uint32_t j = 0; j < 6; j++) b[j] = team_is_one_coeff(j, a[j], e_one);
+        bool res = false;
+        for (uint32_t j = 0; j < 6; j++) res = team_is_one_tree(j, b, e_one);
+        return res;
+    }
+};
+static int g_use_team = 0;
+static bool pairing_segment(uint32_t* base, const blsw_layout_t& L, const Fp& ax, const Fp& ay, Fp* cs, Fp* ch) {
+    if (!g_use_team) {
+        Fp12 fm = chain_miller({base, L.off_miller}, ax, ay, CoeffLinear{cs}, CoeffLinear{ch});
+        return chain_final_exp_is_one({base, L.off_final_exp}, {base, L.off_is_one}, fm);
+    }
+    TeamHost t;
+    t.coeff_sig = CoeffLinear{cs};
+    t.coeff_h = CoeffLinear{ch};
+    t.e = {base, L.off_miller};
+    t.set_consts(ax, ay);
+    TeamHost::Reg f = team_miller(t);
+    if (t.e.pos != L.off_final_exp) return false;
+    bool r = team_final_exp_is_one(t, f, Emitter{base, L.off_is_one});
+    if (t.e.pos != L.off_is_one) return false;
+    return r;
+}
+
 extern "C" {
+void hostsim_use_team(int on) { g_use_team = on; }
 int hostsim_layout(uint32_t msg_len, blsw_layout_t* L) {
     make_layout(msg_len, L);
     return 0;
@@ -54,8 +143,7 @@ int hostsim_witness(const uint64_t* pk_xy, const uint8_t* msg, uint32_t msg_len,
     bool sinf = fp2_is_zero(sx) && fp2_is_zero(sy);
     Proj<OpsFp2> sp = {sinf ? fp2_zero() : sx, sinf ? fp2_one() : sy, sinf ? fp2_zero() : fp2_one()};
     chain_prepare_g2({base, L.off_prep_sig}, sp, CoeffLinear{cs.data()});
-    Fp12 fm = chain_miller({base, L.off_miller}, g1.ax, g1.ay, CoeffLinear{cs.data()}, CoeffLinear{ch.data()});
-    bool res = chain_final_exp_is_one({base, L.off_final_exp}, {base, L.off_is_one}, fm);
+    bool res = pairing_segment(base, L, g1.ax, g1.ay, cs.data(), ch.data());
     (void)seg_ends;
     return res ? 1 : 0;
 }

@@ -178,3 +178,19 @@ def test_sign_rejects_noncanonical_secret_key(oracle):
     sk_le = bytes.fromhex(LIT["sk_limbs"]["hex_le"])
     st, _, pk = hostsim_lib.sign(sk_le, h_xy)
     assert st == 0 and pk == oracle.sk_to_pk(int.from_bytes(sk_le, "little"))
+
+
+def test_team_pairing_program(oracle):
+    """team.cuh (six lanes per instance: op tables + lane routines + the Miller / final-exponentiation program) on the host,
+    lanes run one after the other per phase: full witness vector bit-exact against the oracle, true / false / edge inputs."""
+    lib = hostsim_lib.load()
+    lib.hostsim_use_team(1)
+    try:
+        g = LIT["gadget_verify"]
+        _, pk, _ = oracle.g1_decompress(bytes.fromhex(g["pubkey"]))
+        _, sig, _ = oracle.g2_decompress(bytes.fromhex(g["signature"]))
+        got = [_check(oracle, pk, bytes.fromhex(m), sig) for m in g["messages"][:2]]
+        assert got == g["expected"][:2]
+        _check(oracle, np.zeros(12, dtype=np.uint64), bytes.fromhex(g["messages"][0]), np.zeros(24, dtype=np.uint64))
+    finally:
+        lib.hostsim_use_team(0)
