@@ -323,15 +323,16 @@ BLSW_FN Proj<OpsFp2> chain_cofactor(Emitter e_add, Emitter e, const Proj<OpsFp2>
         mopt = nz_double_w(e, mopt);
 #pragma unroll 1
         for (int i = 1; i < split; i++) {
-            if (bit_of(HE, off + i)) {
+            const bool add = bit_of(HE, off + i);  // a constant of the circuit: uniform over the wave
+            Fp2 inv_add, inv_dbl;
+            if (add) {
                 // the addition's and the doubling's slope denominators are both known here: one shared inversion
-                Fp2 inv_add, inv_dbl;
                 fp2_inv2(fp2_sub(mopt.x, acc.x), fp2_dbl(mopt.y), inv_add, inv_dbl);
-                acc = nz_add_unchecked_pre_w(e, acc, mopt, inv_add);
-                mopt = nz_double_pre_w(e, mopt, inv_dbl);
+                acc = nz_add_unchecked_pre_inl(e, acc, mopt, inv_add);
             } else {
-                mopt = nz_double_w(e, mopt);
+                inv_dbl = fp2_inv(fp2_dbl(mopt.y));
             }
+            mopt = nz_double_pre_inl(e, mopt, inv_dbl);
         }
         Proj<OpsFp2> diff = {acc.x, acc.y, fp2_one()};
         int diff_state = 2;

@@ -173,6 +173,33 @@ BLSW_FN Aff2 nz_add_unchecked_pre_w(Emitter& e, const Aff2& p, const Aff2& q, co
     return {x3, y3};
 }
 
+// the same two steps inlined into their caller's loop (clear_cofactor: 636 doublings + 304 additions per instance). As
+// functions, each call saves and restores the callee-saved registers that hold the running points: measured as ~10 GB of
+// scratch write-back per 16 384 instances and a third of the kernel's time.
+BLSW_HD Fp2 fp2_div_pre_inl(Emitter& e, const Fp2& num, const Fp2& den, const Fp2& den_inv) {
+    Fp2 r = fp2_mul(num, den_inv);
+    e.put(r.c0);
+    e.put(r.c1);
+    fp_mul_w(e, r.c1, den.c1);
+    return r;
+}
+BLSW_HD Aff2 nz_double_pre_inl(Emitter& e, const Aff2& p, const Fp2& den_inv) {
+    Fp2 x1_sqr = fp2_sqr_w(e, p.x);
+    Fp2 num = fp2_add(fp2_dbl(x1_sqr), x1_sqr);
+    Fp2 lambda = fp2_div_pre_inl(e, num, fp2_dbl(p.y), den_inv);
+    Fp2 l2 = fp2_sqr_w(e, lambda);
+    Fp2 x3 = fp2_sub(l2, fp2_dbl(p.x));
+    Fp2 t = fp2_mul_w(e, lambda, fp2_sub(p.x, x3));
+    return {x3, fp2_sub(t, p.y)};
+}
+BLSW_HD Aff2 nz_add_unchecked_pre_inl(Emitter& e, const Aff2& p, const Aff2& q, const Fp2& den_inv) {
+    Fp2 lambda = fp2_div_pre_inl(e, fp2_sub(q.y, p.y), fp2_sub(q.x, p.x), den_inv);
+    Fp2 l2 = fp2_sqr_w(e, lambda);
+    Fp2 x3 = fp2_sub(fp2_sub(l2, p.x), q.x);
+    Fp2 t = fp2_mul_w(e, lambda, fp2_sub(p.x, x3));
+    return {x3, fp2_sub(t, p.y)};
+}
+
 // ---- value-only Jacobian arithmetic over Fp (a = 0), for g * (h^-1 mod r) before G1 allocation
 struct Jac1 {
     Fp x, y, z;

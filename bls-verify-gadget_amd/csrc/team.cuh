@@ -82,18 +82,29 @@ BLSW_HD void team_task(const TeamTask& t, Fp2* slots, const Emitter& e) {
     Emitter w = e;
     w.pos += t.hdr >> 16;
     if (kind == TK_K3V || kind == TK_K2V) w.base = nullptr;  // same arithmetic, a linear combination in the circuit
+    // the witnesses of a task are contiguous in the instance's segment: computed first, then stored back to back
+    // (144 contiguous bytes per lane and 864 per team and round reach L2 within one burst)
     Fp2 r = fp2_zero();
-    if (kind == TK_K3 || kind == TK_K3V) {
-        r = fp2_mul_w(w, a, b);
+    if (kind == TK_K3 || kind == TK_K3V) {  // Karatsuba: a0*b0, a1*b1, (a0+a1)*(b0+b1)
+        Fp v0 = fp_mul(a.c0, b.c0), v1 = fp_mul(a.c1, b.c1);
+        Fp s = fp_mul(fp_add(a.c0, a.c1), fp_add(b.c0, b.c1));
+        w.put(v0);
+        w.put(v1);
+        w.put(s);
+        r = {fp_sub(v0, v1), fp_sub(fp_sub(s, v0), v1)};
     } else if (kind == TK_K2 || kind == TK_K2V) {  // Fp2 x (y, 0): a.c0*y, (a.c0+a.c1)*y
-        Fp v0 = fp_mul_w(w, a.c0, b.c0);
-        Fp s = fp_mul_w(w, fp_add(a.c0, a.c1), b.c0);
+        Fp v0 = fp_mul(a.c0, b.c0);
+        Fp s = fp_mul(fp_add(a.c0, a.c1), b.c0);
+        w.put(v0);
+        w.put(s);
         r = {v0, fp_sub(s, v0)};
     } else if (kind == TK_K2B) {  // two separate Fp products by the same y
-        r.c0 = fp_mul_w(w, a.c0, b.c0);
-        r.c1 = fp_mul_w(w, a.c1, b.c0);
+        r.c0 = fp_mul(a.c0, b.c0);
+        r.c1 = fp_mul(a.c1, b.c0);
+        w.put(r.c0);
+        w.put(r.c1);
     } else {  // TK_K1E: QuadExtVar::mul_equals over Fp, only a.c1*b.c1 is a witness
-        fp_mul_w(w, a.c1, b.c1);
+        w.put(fp_mul(a.c1, b.c1));
     }
     if (dst != 0xff) team_st(slots, dst, r);
 }
@@ -172,45 +183,50 @@ BLSW_HD void team_set_consts_lane(uint32_t j, Fp2* slots, const Fp& pkx, const F
 // ------------------------------------------------------------------------------------------------ the program
 // TEAM interface: Reg; exec(op, a, b) -> Reg (advances the witness cursor); conj / frob; load_coeffs(k); first_f();
 // inverse_w(a); is_one_w(a, e_one); set_cursor(e)
+// The two loops that execute 97 % of the ops have ONE inlined call site of the op executor each (exec_hot): a call
+// would save and restore the callee-saved registers holding the distributed values on every op (measured: 12 GB of
+// scratch write-back per 16 384 instances). The straight-line remainder of the final exponentiation uses calls (exec).
 template <class TEAM>
 BLSW_HD typename TEAM::Reg team_miller(TEAM& t) {
     typename TEAM::Reg f = t.zero();
     uint32_t k = 0;
 #pragma unroll 1
     for (int i = 62; i >= 0; i--) {
-        t.load_coeffs(k);
-        if (i == 62) {
-            f = t.first_f();
-        } else {
-            f = t.exec(TEAM_OP_SQR, f, f);
-            f = t.exec(TEAM_OP_ELLC, f, f);
-        }
-        f = t.exec(TEAM_OP_ELLV, f, f);
-        k++;
-        if ((BLSW_X_ABS >> i) & 1) {
-            t.load_coeffs(k);
-            f = t.exec(TEAM_OP_ELLC, f, f);
-            f = t.exec(TEAM_OP_ELLV, f, f);
-            k++;
+        // phases of one bit: 0 square, 1 ell(-g1, sig), 2 ell(pk, H), then 3, 4 = the two ell again (addition step) on set bits
+        const int n_phases = ((BLSW_X_ABS >> i) & 1) ? 5 : 3;
+#pragma unroll 1
+        for (int ph = (i == 62 ? 1 : 0); ph < n_phases; ph++) {
+            if (ph == 1 || ph == 3) t.load_coeffs(k);
+            if (i == 62 && ph == 1) {
+                f = t.first_f();  // f = 1 is a constant: the first ell is a linear combination
+                continue;
+            }
+            const TeamOp& T = ph == 0 ? TEAM_OP_SQR : ((ph & 1) ? TEAM_OP_ELLC : TEAM_OP_ELLV);
+            f = t.exec_hot(T, f, f);
+            if (ph == 2 || ph == 4) k++;
         }
     }
     return t.conj(f);
 }
 template <class TEAM>
-BLSW_HD typename TEAM::Reg team_exp_by_x(TEAM& t, const typename TEAM::Reg& f) {
+BLSW_HD typename TEAM::Reg team_exp_by_x_body(TEAM& t, const typename TEAM::Reg& f) {
     const uint64_t plus = (1ull << 16) | (1ull << 48) | (1ull << 57) | (1ull << 60);
     const uint64_t minus = (1ull << 62);
-    typename TEAM::Reg f_inv = t.conj(f);
     typename TEAM::Reg res = f;
 #pragma unroll 1
     for (int i = 63; i >= 0; i--) {
-        res = t.exec(TEAM_OP_CYC, res, res);
-        if ((plus >> i) & 1)
-            res = t.exec(TEAM_OP_MUL, res, f);
-        else if ((minus >> i) & 1)
-            res = t.exec(TEAM_OP_MUL, res, f_inv);
+        const bool p = (plus >> i) & 1, m = (minus >> i) & 1;
+#pragma unroll 1
+        for (int ph = 0; ph < ((p || m) ? 2 : 1); ph++) {
+            const TeamOp& T = ph == 0 ? TEAM_OP_CYC : TEAM_OP_MUL;
+            res = t.exec_hot(T, res, ph == 0 ? res : (m ? t.conj(f) : f));
+        }
     }
     return t.conj(res);
+}
+template <class TEAM>
+BLSW_HD typename TEAM::Reg team_exp_by_x(TEAM& t, const typename TEAM::Reg& f) {
+    return t.exp_by_x(f);
 }
 // final_exponentiation . is_one (chains.cuh::chain_final_exp_is_one); the cursor of `t` must be at off_final_exp
 template <class TEAM>
@@ -268,7 +284,7 @@ BLSW_TEAM_DEV TeamTask team_fetch(const TeamTask* p) {
     r.b = team_fetch(&p->b);
     return r;
 }
-__device__ __noinline__ Fp2 team_exec_lane(const TeamOp& T, Fp2* slots, uint32_t j, bool active, const Fp2& in0, const Fp2& in1, Emitter& e) {
+BLSW_TEAM_DEV Fp2 team_exec_lane_inl(const TeamOp& T, Fp2* slots, uint32_t j, bool active, const Fp2& in0, const Fp2& in1, Emitter& e) {
     TeamTask cur = team_fetch(&T.task[0][j]);
     const TeamLin outl = team_fetch(&T.out[j]);
     if (active) {
@@ -291,6 +307,10 @@ __device__ __noinline__ Fp2 team_exec_lane(const TeamOp& T, Fp2* slots, uint32_t
     return out;
 }
 
+__device__ __noinline__ Fp2 team_exec_lane(const TeamOp& T, Fp2* slots, uint32_t j, bool active, const Fp2& in0, const Fp2& in1, Emitter& e) {
+    return team_exec_lane_inl(T, slots, j, active, in0, in1, e);
+}
+
 template <class C>
 struct TeamLanes {
     typedef Fp2 Reg;
@@ -301,6 +321,8 @@ struct TeamLanes {
     C coeff_sig, coeff_h;
     BLSW_TEAM_DEV Reg zero() const { return fp2_zero(); }
     BLSW_TEAM_DEV Reg exec(const TeamOp& T, const Reg& a, const Reg& b) { return team_exec_lane(T, slots, j, active, a, b, e); }
+    BLSW_TEAM_DEV Reg exec_hot(const TeamOp& T, const Reg& a, const Reg& b) { return team_exec_lane_inl(T, slots, j, active, a, b, e); }
+    __device__ __noinline__ Reg exp_by_x(const Reg& f) { return team_exp_by_x_body(*this, f); }
     BLSW_TEAM_DEV Reg conj(const Reg& a) const { return team_conj(j, a); }
     BLSW_TEAM_DEV Reg frob(const Reg& a, int power) const { return team_frob(j, a, power); }
     BLSW_TEAM_DEV void set_consts(const Fp& pkx, const Fp& pky) {

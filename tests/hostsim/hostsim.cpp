@@ -42,6 +42,8 @@ struct TeamHost {
         e.pos += T.n_witness;
         return out;
     }
+    Reg exec_hot(const TeamOp& T, const Reg& a, const Reg& b) { return exec(T, a, b); }
+    Reg exp_by_x(const Reg& f) { return team_exp_by_x_body(*this, f); }
     Reg conj(const Reg& a) const {
         Reg r;
         for (uint32_t j = 0; j < 6; j++) r[j] = team_conj(j, a[j]);

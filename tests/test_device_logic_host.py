@@ -194,3 +194,18 @@ def test_team_pairing_program(oracle):
         _check(oracle, np.zeros(12, dtype=np.uint64), bytes.fromhex(g["messages"][0]), np.zeros(24, dtype=np.uint64))
     finally:
         lib.hostsim_use_team(0)
+
+
+def test_team_tables_are_current(tmp_path):
+    """team_tables.cuh is generated (tools/gen_team_tables.py expands the tower formulas into op tables): the committed
+    header must be what the generator emits, and every op's witness count must be the single-lane code's."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "team_tables.cuh"
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_team_tables.py"), str(out)], capture_output=True, text=True, check=True)
+    assert out.read_text() == open(os.path.join(root, "bls-verify-gadget_amd", "csrc", "team_tables.cuh")).read()
+    counts = {l.split(":")[0]: int(l.split(" witnesses")[0].split()[-1]) for l in r.stderr.strip().splitlines()}
+    # fp12_mul_w 54, fp12_sqr_w 36, cyclotomic square 18, mul_by_014 30 (constant y) / 2 + 36 (variable y), inverse check 18+12+12
+    assert counts == {"MUL": 54, "SQR": 36, "CYC": 18, "ELLC": 30, "ELLV": 38, "INVCHK": 42}

@@ -12,8 +12,6 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-os.environ.setdefault("HSA_SCRATCH_SINGLE_LIMIT_ASYNC", str(8 << 30))
 
 
 def main():

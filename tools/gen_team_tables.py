@@ -305,6 +305,8 @@ def main():
             op.name, len(op.tasks), len(rounds), [len(r) for r in rounds], op.woff, max(sum(map(len, o.lists())) for o in op.out)))
     w("}  // namespace blsw")
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bls-verify-gadget_amd", "csrc", "team_tables.cuh")
+    if len(sys.argv) > 1:
+        path = sys.argv[1]
     with open(path, "w") as f:
         f.write("\n".join(out) + "\n")
     print("\n".join(summary), file=sys.stderr)
