@@ -52,7 +52,7 @@ struct Proj {
 
 // ProjectiveVar::double_in_place on variables: 3 squarings + 8 products, in this order
 template <class O>
-BLSW_FN Proj<O> proj_double_w(Emitter& e, const Proj<O>& p) {
+BLSW_HD Proj<O> proj_double_inl(Emitter& e, const Proj<O>& p) {
     typedef typename O::F F;
     F xx = O::sqr_w(e, p.x);
     F yy = O::sqr_w(e, p.y);
@@ -78,7 +78,7 @@ BLSW_FN Proj<O> proj_double_w(Emitter& e, const Proj<O>& p) {
 // 1 = z2 is the constant one (zz = z1 is a linear combination: 11 products);
 // 2 = both z are the constant one (zz constant: 11 products).
 template <class O, int ZMODE>
-BLSW_FN Proj<O> proj_add_w(Emitter& e, const Proj<O>& a, const Proj<O>& b) {
+BLSW_HD Proj<O> proj_add_inl(Emitter& e, const Proj<O>& a, const Proj<O>& b) {
     typedef typename O::F F;
     F xx = O::mul_w(e, a.x, b.x);
     F yy = O::mul_w(e, a.y, b.y);
@@ -111,6 +111,16 @@ BLSW_FN Proj<O> proj_add_w(Emitter& e, const Proj<O>& a, const Proj<O>& b) {
     F z = O::add(m4, m5);
     return {x, y, z};
 }
+// out-of-line entry points (single uses); the scalar-multiplication loop below inlines both steps: a call per step would
+// save and restore the callee-saved registers that hold the running point (scratch traffic that is written back to HBM)
+template <class O>
+BLSW_FN Proj<O> proj_double_w(Emitter& e, const Proj<O>& p) {
+    return proj_double_inl<O>(e, p);
+}
+template <class O, int ZMODE>
+BLSW_FN Proj<O> proj_add_w(Emitter& e, const Proj<O>& a, const Proj<O>& b) {
+    return proj_add_inl<O, ZMODE>(e, a, b);
+}
 // result = [k] ge with `result = zero; for b in BE bits: double; if b: += ge` (the first set bit costs nothing:
 // zero is a constant, so the first add returns ge itself)
 template <class O>
@@ -118,8 +128,8 @@ BLSW_FN Proj<O> proj_mul_bits_be_w(Emitter& e, const Proj<O>& ge, const uint32_t
     Proj<O> result = ge;
 #pragma unroll 1
     for (int i = nbits - 2; i >= 0; i--) {
-        result = proj_double_w<O>(e, result);
-        if ((words[i >> 5] >> (i & 31)) & 1) result = proj_add_w<O, 0>(e, result, ge);
+        result = proj_double_inl<O>(e, result);
+        if ((words[i >> 5] >> (i & 31)) & 1) result = proj_add_inl<O, 0>(e, result, ge);
     }
     return result;
 }
