@@ -327,10 +327,10 @@ BLSW_FN Proj<OpsFp2> chain_cofactor(Emitter e_add, Emitter e, const Proj<OpsFp2>
             Fp2 inv_add, inv_dbl;
             if (add) {
                 // the addition's and the doubling's slope denominators are both known here: one shared inversion
-                fp2_inv2(fp2_sub(mopt.x, acc.x), fp2_dbl(mopt.y), inv_add, inv_dbl);
+                fp2_inv2_inl(fp2_sub(mopt.x, acc.x), fp2_dbl(mopt.y), inv_add, inv_dbl);
                 acc = nz_add_unchecked_pre_inl(e, acc, mopt, inv_add);
             } else {
-                inv_dbl = fp2_inv(fp2_dbl(mopt.y));
+                inv_dbl = fp2_inv_inl(fp2_dbl(mopt.y));
             }
             mopt = nz_double_pre_inl(e, mopt, inv_dbl);
         }

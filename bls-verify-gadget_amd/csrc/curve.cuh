@@ -187,7 +187,7 @@ BLSW_FN Aff2 nz_add_unchecked_pre_w(Emitter& e, const Aff2& p, const Aff2& q, co
 // functions, each call saves and restores the callee-saved registers that hold the running points: measured as ~10 GB of
 // scratch write-back per 16 384 instances and a third of the kernel's time.
 BLSW_HD Fp2 fp2_div_pre_inl(Emitter& e, const Fp2& num, const Fp2& den, const Fp2& den_inv) {
-    Fp2 r = fp2_mul(num, den_inv);
+    Fp2 r = fp2_mul_inl(num, den_inv);
     e.put(r.c0);
     e.put(r.c1);
     fp_mul_w(e, r.c1, den.c1);

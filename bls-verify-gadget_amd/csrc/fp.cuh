@@ -404,21 +404,23 @@ BLSW_HD Fp2 fp2_dbl(const Fp2& a) { return {fp_dbl(a.c0), fp_dbl(a.c1)}; }
 BLSW_HD Fp2 fp2_conj(const Fp2& a) { return {a.c0, fp_neg(a.c1)}; }
 BLSW_HD Fp2 fp2_mul_xi(const Fp2& a) { return {fp_sub(a.c0, a.c1), fp_add(a.c0, a.c1)}; }  // * (1+u)
 // value-only products (used where the circuit has a constant operand: linear combination, no witness)
-BLSW_FN Fp2 fp2_mul(const Fp2& a, const Fp2& b) {
+BLSW_HD Fp2 fp2_mul_inl(const Fp2& a, const Fp2& b) {
     Fp v0 = fp_mul(a.c0, b.c0), v1 = fp_mul(a.c1, b.c1);
     Fp s = fp_mul(fp_add(a.c0, a.c1), fp_add(b.c0, b.c1));
     return {fp_sub(v0, v1), fp_sub(fp_sub(s, v0), v1)};
 }
+BLSW_FN Fp2 fp2_mul(const Fp2& a, const Fp2& b) { return fp2_mul_inl(a, b); }
 BLSW_FN Fp2 fp2_sqr(const Fp2& a) {
     Fp v = fp_mul(a.c0, a.c1);
     Fp t = fp_mul(fp_sub(a.c0, a.c1), fp_add(a.c0, a.c1));
     return {t, fp_dbl(v)};
 }
 BLSW_FN Fp2 fp2_mul_fp(const Fp2& a, const Fp& b) { return {fp_mul(a.c0, b), fp_mul(a.c1, b)}; }
-BLSW_FN Fp2 fp2_inv(const Fp2& a) {
+BLSW_HD Fp2 fp2_inv_inl(const Fp2& a) {
     Fp n = fp_add(fp_sqr(a.c0), fp_sqr(a.c1));
     Fp ni = fp_inv(n);
     return {fp_mul(a.c0, ni), fp_neg(fp_mul(a.c1, ni))};
 }
+BLSW_FN Fp2 fp2_inv(const Fp2& a) { return fp2_inv_inl(a); }
 
 }  // namespace blsw

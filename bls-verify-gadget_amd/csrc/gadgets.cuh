@@ -101,17 +101,18 @@ BLSW_FN Fp2 fp2_div_pre_w(Emitter& e, const Fp2& num, const Fp2& den, const Fp2&
 }
 // Montgomery's trick for two independent Fp2 inversions: one Fp inversion + 9 extra Fp products instead of two inversions.
 // Falls back to separate inversions when either input is zero (the hint of a zero is zero).
-BLSW_FN void fp2_inv2(const Fp2& a, const Fp2& b, Fp2& a_inv, Fp2& b_inv) {
+BLSW_HD void fp2_inv2_inl(const Fp2& a, const Fp2& b, Fp2& a_inv, Fp2& b_inv) {
     if (fp2_is_zero(a) || fp2_is_zero(b)) {
         a_inv = fp2_inv(a);
         b_inv = fp2_inv(b);
         return;
     }
-    Fp2 p = fp2_mul(a, b);
-    Fp2 pi = fp2_inv(p);
-    a_inv = fp2_mul(b, pi);
-    b_inv = fp2_mul(a, pi);
+    Fp2 p = fp2_mul_inl(a, b);
+    Fp2 pi = fp2_inv_inl(p);
+    a_inv = fp2_mul_inl(b, pi);
+    b_inv = fp2_mul_inl(a, pi);
 }
+BLSW_FN void fp2_inv2(const Fp2& a, const Fp2& b, Fp2& a_inv, Fp2& b_inv) { fp2_inv2_inl(a, b, a_inv, b_inv); }
 BLSW_FN bool fp2_is_eq_w(Emitter& e, const Fp2& self, const Fp2& other) {
     bool b0 = fp_is_eq_w(e, self.c0, other.c0);
     bool b1 = fp_is_eq_w(e, self.c1, other.c1);
