@@ -18,7 +18,7 @@ namespace {
 // All per-instance scratch is stored element-major: element e of instance I lives at index e*N + I, so that the
 // 64 lanes of a wave touch one contiguous 3 KiB window per element (48 B per lane).
 struct Workspace {
-    uint32_t* bits;  // [sha_words][N] u32 : SHA witness bitstream, word-major
+    uint32_t* bits;  // [N/64][sha_words][64] u32: SHA witness bitstream; a wave appends 256-byte rows to its own tile
     Fp* u;           // [4][N]   hash_to_field output u0.c0,u0.c1,u1.c0,u1.c1
     Fp* q;           // [12][N]  Q0 (x.c0,x.c1,y.c0,y.c1,z.c0,z.c1), Q1
     Fp* h;           // [6][N]   H(m) projective
@@ -52,7 +52,7 @@ Workspace carve(void* base, uint64_t N, const blsw_layout_t& L, bool with_stagin
         off = align_up(off + bytes, 256);
         return reinterpret_cast<char*>(base) + o;
     };
-    w.bits = reinterpret_cast<uint32_t*>(take(w.sha_words * N * 4));
+    w.bits = reinterpret_cast<uint32_t*>(take(w.sha_words * align_up(N, 64) * 4));
     w.u = reinterpret_cast<Fp*>(take(4 * N * sizeof(Fp)));
     w.q = reinterpret_cast<Fp*>(take(12 * N * sizeof(Fp)));
     w.h = reinterpret_cast<Fp*>(take(6 * N * sizeof(Fp)));
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(64) void k_sha(Group g, int want_bits, int write_u)
         for (int j = 0; j < 8; j++) em.put_bool((b >> j) & 1);
     }
     BitSink s;
-    s.init(want_bits ? g.ws.bits + I : nullptr, g.N);
+    s.init(want_bits ? g.ws.bits + (I >> 6) * g.ws.sha_words * 64 + (I & 63) : nullptr, 64);
     uint32_t uw[64];
     expand_message_w(s, msg, g.msg_len, false, uw);
     if (write_u)
@@ -196,12 +196,13 @@ __global__ __launch_bounds__(64) void k_sha_values(Group g) {
 #endif
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 template <int NT>
-__global__ __launch_bounds__(384) void k_sha_expand(const uint32_t* __restrict__ bits, uint64_t N, uint64_t first, uint32_t sha_bits,
+__global__ __launch_bounds__(384) void k_sha_expand(const uint32_t* __restrict__ bits, uint64_t sha_words, uint64_t first, uint32_t sha_bits,
                                                     uint32_t off_expand, uint64_t* __restrict__ d_witness, uint64_t stride) {
     constexpr uint32_t R1[12] = BLSW_R1_LIMBS;
     const uint64_t inst = blockIdx.y;
     uint4* out = reinterpret_cast<uint4*>(d_witness + (inst * stride + off_expand) * 6);
-    const uint32_t* b = bits + first + inst;
+    const uint64_t lane = first + inst;
+    const uint32_t* b = bits + (lane >> 6) * sha_words * 64 + (lane & 63);
     const uint32_t t = threadIdx.x, c = t % 3;
     const uint32_t e0 = blockIdx.x * (128 * BLSW_EXPAND_ITERS) + t / 3;
     uint4 rc;
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(384) void k_sha_expand(const uint32_t* __restrict__
     for (int k = 0; k < BLSW_EXPAND_ITERS; k++) {
         uint32_t e = e0 + 128 * k;
         if (e < sha_bits) {
-            uint32_t w = b[(uint64_t)(e >> 5) * N];
+            uint32_t w = b[(uint64_t)(e >> 5) * 64];
             uint32_t m = 0u - ((w >> (e & 31)) & 1u);
             uint4 v = make_uint4(rc.x & m, rc.y & m, rc.z & m, rc.w & m);
             if (NT == 2) {
@@ -703,7 +704,7 @@ static int launch_group(blsw_engine* e, hipStream_t user_stream) {
         const bool timed = e->n_timed < BLSW_MAX_TIMED;
         if (timed) hipEventRecord(e->ev_exp[2 * e->n_timed], e->place);
 #define BLSW_LAUNCH_EXPAND(MODE)                                                                                                                   \
-    hipLaunchKernelGGL(k_sha_expand<MODE>, grid, dim3(384), place_lds_bytes(), e->place, g.ws.bits, g.N, (uint64_t)s * e->n, e->L.sha_bits, \
+    hipLaunchKernelGGL(k_sha_expand<MODE>, grid, dim3(384), place_lds_bytes(), e->place, g.ws.bits, g.ws.sha_words, (uint64_t)s * e->n, e->L.sha_bits, \
                        e->L.off_expand, d.out, d.out_stride)
         switch (place_nt()) {
             case 0: BLSW_LAUNCH_EXPAND(0); break;
@@ -731,7 +732,7 @@ static int launch_group(blsw_engine* e, hipStream_t user_stream) {
 
 extern "C" {
 
-int blsw_version(void) { return 3; }
+int blsw_version(void) { return 4; }
 
 int blsw_layout(uint32_t msg_len, blsw_layout_t* out) {
     if (!out || msg_len > 65535) return BLSW_ERR_ARG;
@@ -969,7 +970,7 @@ int blsw_aggregate_verify_batch(const uint64_t* d_pks_xy, const uint8_t* d_bitma
     hipLaunchKernelGGL(k_sha, dim3(g1), dim3(64), 0, st, g, d_witness ? 1 : 0, 1);
     if (d_witness) {
         dim3 grid((g.L.sha_bits + 128 * BLSW_EXPAND_ITERS - 1) / (128 * BLSW_EXPAND_ITERS), (unsigned)n);
-        hipLaunchKernelGGL(k_sha_expand<0>, grid, dim3(384), 0, st, g.ws.bits, g.N, (uint64_t)0, g.L.sha_bits, g.L.off_expand, d_witness, witness_stride);
+        hipLaunchKernelGGL(k_sha_expand<0>, grid, dim3(384), 0, st, g.ws.bits, g.ws.sha_words, (uint64_t)0, g.L.sha_bits, g.L.off_expand, d_witness, witness_stride);
     }
     hipLaunchKernelGGL(k_map, dim3(g2), dim3(64), 0, st, g);
     hipLaunchKernelGGL(k_cofactor, dim3(g1), dim3(64), 0, st, g);
