@@ -49,7 +49,7 @@ def synth_inputs(pkg, n, seed, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=512)
+    ap.add_argument("--steps", type=int, default=1024)
     ap.add_argument("--warmup", type=int, default=48)
     ap.add_argument("--batch", type=int, default=1024, help="instances per GPU per step (configs[1]: 1024)")
     ap.add_argument("--coalesce", type=int, default=16, help="max submitted batches fused into one launch group")
@@ -67,10 +67,21 @@ def main():
     dist = None
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:  # launched by torch.distributed.run (also with one rank)
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=dev)
+        # RCCL prints a version banner on stdout when the communicator is created: keep stdout for the one JSON line
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=dev)
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
     pkg = importlib.import_module("bls-verify-gadget_amd")
     sharding = importlib.import_module("bls-verify-gadget_amd.sharding")
     pkg.lib()
@@ -126,6 +137,9 @@ def main():
         dt = float(t.item())
         sharding.all_gather_results(results[0], n * world)  # result shards only (multi-GPU)
 
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
     if rank != 0:
         return
     value = n * world * args.steps / dt

@@ -92,17 +92,21 @@ BLSW_HD void team_task(const TeamTask& t, Fp2* slots, const Emitter& e) {
         w.put(v1);
         w.put(s);
         r = {fp_sub(v0, v1), fp_sub(fp_sub(s, v0), v1)};
-    } else if (kind == TK_K2 || kind == TK_K2V) {  // Fp2 x (y, 0): a.c0*y, (a.c0+a.c1)*y
+    } else if (kind == TK_K2 || kind == TK_K2V || kind == TK_K2B) {
+        // two Fp products by the same y = b.c0, one instruction stream for the three kinds (they share rounds):
+        //   K2 / K2V  Fp2 x (y, 0): a.c0*y, (a.c0+a.c1)*y -> (v0, s - v0)      K2B  a.c0*y, a.c1*y -> (v0, s)
+        const bool sep = kind == TK_K2B;
+        Fp x1 = fp_add(a.c0, a.c1);
+#pragma unroll
+        for (int i = 0; i < 12; i++) x1.l[i] = sep ? a.c1.l[i] : x1.l[i];
         Fp v0 = fp_mul(a.c0, b.c0);
-        Fp s = fp_mul(fp_add(a.c0, a.c1), b.c0);
+        Fp s = fp_mul(x1, b.c0);
         w.put(v0);
         w.put(s);
-        r = {v0, fp_sub(s, v0)};
-    } else if (kind == TK_K2B) {  // two separate Fp products by the same y
-        r.c0 = fp_mul(a.c0, b.c0);
-        r.c1 = fp_mul(a.c1, b.c0);
-        w.put(r.c0);
-        w.put(r.c1);
+        Fp d = fp_sub(s, v0);
+#pragma unroll
+        for (int i = 0; i < 12; i++) d.l[i] = sep ? s.l[i] : d.l[i];
+        r = {v0, d};
     } else {  // TK_K1E: QuadExtVar::mul_equals over Fp, only a.c1*b.c1 is a witness
         w.put(fp_mul(a.c1, b.c1));
     }

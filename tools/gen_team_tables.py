@@ -113,10 +113,12 @@ class Op:
                         prod = next(ix for ix, u in enumerate(self.tasks) if u["dst"] == k)
                         lv = max(lv, level[prod] + 1)
             level[i] = lv
+        # kinds that run the same instruction stream share rounds: the two-product kinds (K2, K2V, K2B) and the Karatsuba kinds
+        classes = ((K2B, K2, K2V), (K3, K3V), (K1E,))
         rounds = []
         for lv in sorted(set(level.values())):
-            for kind in (K2B, K3, K3V, K2, K2V, K1E):
-                ids = [i for i in range(len(self.tasks)) if level[i] == lv and self.tasks[i]["kind"] == kind]
+            for cls in classes:
+                ids = [i for i in range(len(self.tasks)) if level[i] == lv and self.tasks[i]["kind"] in cls]
                 for c in range(0, len(ids), 6):
                     rounds.append(ids[c:c + 6])
         return rounds
