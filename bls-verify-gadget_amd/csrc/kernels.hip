@@ -243,14 +243,20 @@ __global__ __launch_bounds__(384) void k_sha_expand(const uint32_t* __restrict__
 // writes was measured slower (3.8 ms vs 1.8 ms per 1024 instances).
 __global__ __launch_bounds__(256) void k_place_field(const Fp* __restrict__ staging, const Fp* __restrict__ pair, uint64_t first, uint32_t off_expand,
                                                      uint32_t sha_bits, uint32_t staging_rows, uint32_t split_row, uint64_t* __restrict__ d_witness,
-                                                     uint64_t stride) {
-    const uint64_t inst = blockIdx.y;
+                                                     uint64_t stride, uint32_t n_inst) {
+    // XCD-aware block order: workgroups go round-robin to the 8 XCDs (each with its own L2). The 64 instances of a tile read
+    // neighbouring 48-byte pieces of the same staging lines, so all instances of one chunk of rows run back to back on ONE
+    // XCD: linear id L -> xcd = L % 8, chunk = xcd + 8 * ((L / 8) / n_inst), instance = (L / 8) % n_inst.
+    const uint32_t L = blockIdx.x, s_in_xcd = L >> 3;
+    const uint32_t chunk = (L & 7) + 8 * (s_in_xcd / n_inst);
+    const uint64_t inst = s_in_xcd % n_inst;
     const uint32_t nchunks = staging_rows * 3;
+    if (chunk * 2048u >= nchunks) return;
     const uint64_t lane = first + inst;
     const uint4* src = reinterpret_cast<const uint4*>(staging + (lane >> 6) * (uint64_t)split_row * 64 + (lane & 63));
     const uint4* src2 = reinterpret_cast<const uint4*>(pair + lane * (uint64_t)(staging_rows - split_row));
     uint4* out = reinterpret_cast<uint4*>(d_witness + inst * stride * 6);
-    uint32_t q0 = blockIdx.x * (256 * 8) + threadIdx.x;
+    uint32_t q0 = chunk * (256 * 8) + threadIdx.x;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         uint32_t q = q0 + k * 256;
@@ -720,9 +726,10 @@ static int launch_group(blsw_engine* e, hipStream_t user_stream) {
         }
         if (e->staged) {
             const uint32_t rows = e->L.n_witness - e->L.sha_bits;
-            dim3 grid2((rows * 3 + 2047) / 2048, (unsigned)e->n);
+            const unsigned chunks = (rows * 3 + 2047) / 2048;
+            dim3 grid2(8 * ((chunks + 7) / 8) * (unsigned)e->n);
             hipLaunchKernelGGL(k_place_field, grid2, dim3(256), 0, e->place, g.ws.staging, g.ws.pair, (uint64_t)s * e->n, e->L.off_expand, e->L.sha_bits, rows,
-                               g.ws.split_row, d.out, d.out_stride);
+                               g.ws.split_row, d.out, d.out_stride, (uint32_t)e->n);
         }
     }
     hipEventRecord(b.ev_done, e->place);
