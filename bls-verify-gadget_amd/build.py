@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libblsw.so")
 SOURCES = ["kernels.hip"]
-HEADERS = ["fp.cuh", "gadgets.cuh", "constants.cuh", "curve.cuh", "tower.cuh", "sha.cuh", "chains.cuh", "layout.h"]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith((".cuh", ".h")))
 
 
 def needs_build():

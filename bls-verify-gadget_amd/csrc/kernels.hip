@@ -189,7 +189,7 @@ __global__ __launch_bounds__(64) void k_sha_values(Group g) {
 // instruction of a wave covers 1 KiB contiguous. ~10 VALU instructions per 16 bytes stored; streaming (nontemporal)
 // stores: the tensor is not read again on the device. blockIdx.y = instance of the step.
 #ifndef BLSW_EXPAND_ITERS
-#define BLSW_EXPAND_ITERS 32
+#define BLSW_EXPAND_ITERS 8
 #endif
 #ifndef BLSW_EXPAND_UNROLL
 #define BLSW_EXPAND_UNROLL 8
@@ -239,8 +239,11 @@ __global__ __launch_bounds__(384) void k_sha_expand(const uint32_t* __restrict__
 // Engine mode: the field witnesses of one step are moved into place around the SHA segment. Rows below split_row are staged
 // in 64-instance tiles ([tile][row][64]: 48-byte gathers), the pairing rows instance-major (contiguous copies).
 // 16-byte chunk q of instance i covers elements [0, off_expand) and [off_expand + sha_bits, n_witness). Every block
-// writes 32 KiB contiguous of ONE instance's vector. An LDS-transposed variant with contiguous reads and 384-byte
+// writes 32 KiB contiguous of ONE instance's vector (16 and 64 KiB measure the same). An LDS-transposed variant with contiguous reads and 384-byte
 // writes was measured slower (3.8 ms vs 1.8 ms per 1024 instances).
+#ifndef BLSW_PLACE_ITERS
+#define BLSW_PLACE_ITERS 8
+#endif
 __global__ __launch_bounds__(256) void k_place_field(const Fp* __restrict__ staging, const Fp* __restrict__ pair, uint64_t first, uint32_t off_expand,
                                                      uint32_t sha_bits, uint32_t staging_rows, uint32_t split_row, uint64_t* __restrict__ d_witness,
                                                      uint64_t stride, uint32_t n_inst) {
@@ -251,14 +254,14 @@ __global__ __launch_bounds__(256) void k_place_field(const Fp* __restrict__ stag
     const uint32_t chunk = (L & 7) + 8 * (s_in_xcd / n_inst);
     const uint64_t inst = s_in_xcd % n_inst;
     const uint32_t nchunks = staging_rows * 3;
-    if (chunk * 2048u >= nchunks) return;
+    if (chunk * (256u * BLSW_PLACE_ITERS) >= nchunks) return;
     const uint64_t lane = first + inst;
     const uint4* src = reinterpret_cast<const uint4*>(staging + (lane >> 6) * (uint64_t)split_row * 64 + (lane & 63));
     const uint4* src2 = reinterpret_cast<const uint4*>(pair + lane * (uint64_t)(staging_rows - split_row));
     uint4* out = reinterpret_cast<uint4*>(d_witness + inst * stride * 6);
-    uint32_t q0 = chunk * (256 * 8) + threadIdx.x;
+    uint32_t q0 = chunk * (256 * BLSW_PLACE_ITERS) + threadIdx.x;
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
+    for (int k = 0; k < BLSW_PLACE_ITERS; k++) {
         uint32_t q = q0 + k * 256;
         if (q < nchunks) {
             uint32_t e = q / 3, c = q - e * 3;
@@ -726,7 +729,7 @@ static int launch_group(blsw_engine* e, hipStream_t user_stream) {
         }
         if (e->staged) {
             const uint32_t rows = e->L.n_witness - e->L.sha_bits;
-            const unsigned chunks = (rows * 3 + 2047) / 2048;
+            const unsigned chunks = (rows * 3 + 256 * BLSW_PLACE_ITERS - 1) / (256 * BLSW_PLACE_ITERS);
             dim3 grid2(8 * ((chunks + 7) / 8) * (unsigned)e->n);
             hipLaunchKernelGGL(k_place_field, grid2, dim3(256), 0, e->place, g.ws.staging, g.ws.pair, (uint64_t)s * e->n, e->L.off_expand, e->L.sha_bits, rows,
                                g.ws.split_row, d.out, d.out_stride, (uint32_t)e->n);
