@@ -288,3 +288,31 @@ def test_sign_batch_fixtures_and_synthetic_workload(pkg, oracle):
     opk, omsg, osig, oexp = synth.make_batch(oracle, 48, seed=0x5EED)
     assert (gpk.cpu().numpy().view(np.uint64) == opk).all() and (gsig.cpu().numpy().view(np.uint64) == osig).all()
     assert (gmsg.cpu().numpy() == omsg).all() and (gexp == oexp).all()
+
+
+def test_witness_digests_against_committed_goldens(pkg, oracle):
+    """The HIP path against tests/golden/witness_digests.json directly (no oracle call for the expected values): SHA-256 of
+    every witness vector and of its Miller-loop segment for the valid verify fixtures and the reference gadget case; inputs
+    are decoded from the compressed fixture bytes on the GPU."""
+    import hashlib
+
+    import torch
+
+    gold = json.load(open(os.path.join(GOLDEN, "witness_digests.json")))
+    names = list(gold["cases"])
+    dev = torch.device("cuda:0")
+    pk48 = torch.tensor(np.frombuffer(b"".join(bytes.fromhex(gold["cases"][k]["pubkey"]) for k in names), dtype=np.uint8).reshape(-1, 48).copy(), device=dev)
+    sig96 = torch.tensor(np.frombuffer(b"".join(bytes.fromhex(gold["cases"][k]["signature"]) for k in names), dtype=np.uint8).reshape(-1, 96).copy(), device=dev)
+    msg = torch.tensor(np.frombuffer(b"".join(bytes.fromhex(gold["cases"][k]["message"]) for k in names), dtype=np.uint8).reshape(-1, 32).copy(), device=dev)
+    pk_xy, sig_xy, st = pkg.decode_batch(pk48, sig96)
+    assert int(st.abs().sum().item()) == 0
+    g = pkg.BlsSignatureVerifyGadget(len(names), 32, device=dev)
+    res = g.verify(pkg.ParametersVar(), pkg.PublicKeyVar.new_witness(pk_xy), msg, pkg.SignatureVar.new_witness(sig_xy))
+    torch.cuda.synchronize()
+    w = g.witness.cpu().numpy().view(np.uint8).reshape(len(names), -1, 48)
+    lo, hi = gold["segments"][-3][1], gold["segments"][-3][2]
+    for i, k in enumerate(names):
+        c = gold["cases"][k]
+        assert w.shape[1] == c["n_witness"] and bool(res[i].item()) == c["result"]
+        assert hashlib.sha256(w[i].tobytes()).hexdigest() == c["sha256_all"], k
+        assert hashlib.sha256(w[i, lo:hi].tobytes()).hexdigest() == c["sha256_segments"]["miller"], k
