@@ -316,3 +316,34 @@ def test_witness_digests_against_committed_goldens(pkg, oracle):
         assert w.shape[1] == c["n_witness"] and bool(res[i].item()) == c["result"]
         assert hashlib.sha256(w[i].tobytes()).hexdigest() == c["sha256_all"], k
         assert hashlib.sha256(w[i, lo:hi].tobytes()).hexdigest() == c["sha256_segments"]["miller"], k
+
+
+def test_engine_ragged_tiles(pkg, oracle):
+    """Grouped engine with N = 2 x 70 lanes: staging tiles of 64 instances and pairing waves of 10 instances are both ragged
+    and straddled by the two batches; instances around every boundary are compared element by element with the oracle."""
+    import torch
+
+    n, steps = 70, 2
+    pk, msg, sig, expect = synth.make_batch(oracle, 64, tamper_every=5)
+    reps = (n * steps + 63) // 64
+    pk, msg, sig, expect = np.tile(pk, (reps, 1))[: n * steps], np.tile(msg, (reps, 1))[: n * steps], np.tile(sig, (reps, 1))[: n * steps], np.tile(expect, reps)[: n * steps]
+    dev = torch.device("cuda:0")
+    eng = pkg.WitnessEngine(n, 32, max_steps=2, device=dev)
+    outs, ress = [], []
+    for k in range(steps):
+        sl = slice(k * n, (k + 1) * n)
+        w, r = eng.new_witness_tensor(), torch.empty(n, dtype=torch.int32, device=dev)
+        eng.submit(torch.from_numpy(pk[sl].view(np.int64)).to(dev), torch.from_numpy(sig[sl].view(np.int64)).to(dev), torch.from_numpy(msg[sl]).to(dev), witness=w, result=r)
+        outs.append(w)
+        ress.append(r)
+    eng.flush()
+    torch.cuda.synchronize()
+    for k in range(steps):
+        sl = slice(k * n, (k + 1) * n)
+        got = ress[k].cpu().numpy().astype(bool)
+        assert np.array_equal(got, expect[sl])
+        w = outs[k].cpu().numpy().view(np.uint64)
+        # lanes 63|64 (tile edge in batch 0), 69|70 (batch edge), 127|128 (tile edge in batch 1 = local 57|58), last lane
+        idx = [0, 9, 10, 63, 64, 69] if k == 0 else [0, 57, 58, 59, 60, 69]
+        _compare(oracle, pk[sl], msg[sl], sig[sl], got, w, idx)
+    eng.close()
