@@ -191,12 +191,16 @@ __global__ __launch_bounds__(64) void k_sha_values(Group g) {
 #ifndef BLSW_EXPAND_ITERS
 #define BLSW_EXPAND_ITERS 8
 #endif
+#ifndef BLSW_EXPAND_THREADS
+#define BLSW_EXPAND_THREADS 384  // a multiple of 192: three 16-byte columns per element, whole waves
+#endif
+#define BLSW_EXPAND_EPI (BLSW_EXPAND_THREADS / 3)  // elements per block and iteration
 #ifndef BLSW_EXPAND_UNROLL
 #define BLSW_EXPAND_UNROLL 8
 #endif
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 template <int NT>
-__global__ __launch_bounds__(384) void k_sha_expand(const uint32_t* __restrict__ bits, uint64_t sha_words, uint64_t first, uint32_t sha_bits,
+__global__ __launch_bounds__(BLSW_EXPAND_THREADS) void k_sha_expand(const uint32_t* __restrict__ bits, uint64_t sha_words, uint64_t first, uint32_t sha_bits,
                                                     uint32_t off_expand, uint64_t* __restrict__ d_witness, uint64_t stride) {
     constexpr uint32_t R1[12] = BLSW_R1_LIMBS;
     const uint64_t inst = blockIdx.y;
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(384) void k_sha_expand(const uint32_t* __restrict__
     const uint64_t lane = first + inst;
     const uint32_t* b = bits + (lane >> 6) * sha_words * 64 + (lane & 63);
     const uint32_t t = threadIdx.x, c = t % 3;
-    const uint32_t e0 = blockIdx.x * (128 * BLSW_EXPAND_ITERS) + t / 3;
+    const uint32_t e0 = blockIdx.x * (BLSW_EXPAND_EPI * BLSW_EXPAND_ITERS) + t / 3;
     uint4 rc;
     rc.x = c == 0 ? R1[0] : (c == 1 ? R1[4] : R1[8]);
     rc.y = c == 0 ? R1[1] : (c == 1 ? R1[5] : R1[9]);
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(384) void k_sha_expand(const uint32_t* __restrict__
     rc.w = c == 0 ? R1[3] : (c == 1 ? R1[7] : R1[11]);
 #pragma unroll BLSW_EXPAND_UNROLL
     for (int k = 0; k < BLSW_EXPAND_ITERS; k++) {
-        uint32_t e = e0 + 128 * k;
+        uint32_t e = e0 + BLSW_EXPAND_EPI * k;
         if (e < sha_bits) {
             uint32_t w = b[(uint64_t)(e >> 5) * 64];
             uint32_t m = 0u - ((w >> (e & 31)) & 1u);
@@ -711,11 +715,11 @@ static int launch_group(blsw_engine* e, hipStream_t user_stream) {
     for (uint32_t s = 0; s < steps && any_out; s++) {
         const StepDesc& d = b.h_desc[s];
         if (!d.out) continue;
-        dim3 grid((e->L.sha_bits + 128 * BLSW_EXPAND_ITERS - 1) / (128 * BLSW_EXPAND_ITERS), (unsigned)e->n);
+        dim3 grid((e->L.sha_bits + BLSW_EXPAND_EPI * BLSW_EXPAND_ITERS - 1) / (BLSW_EXPAND_EPI * BLSW_EXPAND_ITERS), (unsigned)e->n);
         const bool timed = e->n_timed < BLSW_MAX_TIMED;
         if (timed) hipEventRecord(e->ev_exp[2 * e->n_timed], e->place);
 #define BLSW_LAUNCH_EXPAND(MODE)                                                                                                                   \
-    hipLaunchKernelGGL(k_sha_expand<MODE>, grid, dim3(384), place_lds_bytes(), e->place, g.ws.bits, g.ws.sha_words, (uint64_t)s * e->n, e->L.sha_bits, \
+    hipLaunchKernelGGL(k_sha_expand<MODE>, grid, dim3(BLSW_EXPAND_THREADS), place_lds_bytes(), e->place, g.ws.bits, g.ws.sha_words, (uint64_t)s * e->n, e->L.sha_bits, \
                        e->L.off_expand, d.out, d.out_stride)
         switch (place_nt()) {
             case 0: BLSW_LAUNCH_EXPAND(0); break;
@@ -981,8 +985,8 @@ int blsw_aggregate_verify_batch(const uint64_t* d_pks_xy, const uint8_t* d_bitma
     hipLaunchKernelGGL(k_prepare, dim3(g1), dim3(64), 0, st, g, 1);
     hipLaunchKernelGGL(k_sha, dim3(g1), dim3(64), 0, st, g, d_witness ? 1 : 0, 1);
     if (d_witness) {
-        dim3 grid((g.L.sha_bits + 128 * BLSW_EXPAND_ITERS - 1) / (128 * BLSW_EXPAND_ITERS), (unsigned)n);
-        hipLaunchKernelGGL(k_sha_expand<0>, grid, dim3(384), 0, st, g.ws.bits, g.ws.sha_words, (uint64_t)0, g.L.sha_bits, g.L.off_expand, d_witness, witness_stride);
+        dim3 grid((g.L.sha_bits + BLSW_EXPAND_EPI * BLSW_EXPAND_ITERS - 1) / (BLSW_EXPAND_EPI * BLSW_EXPAND_ITERS), (unsigned)n);
+        hipLaunchKernelGGL(k_sha_expand<0>, grid, dim3(BLSW_EXPAND_THREADS), 0, st, g.ws.bits, g.ws.sha_words, (uint64_t)0, g.L.sha_bits, g.L.off_expand, d_witness, witness_stride);
     }
     hipLaunchKernelGGL(k_map, dim3(g2), dim3(64), 0, st, g);
     hipLaunchKernelGGL(k_cofactor, dim3(g1), dim3(64), 0, st, g);
