@@ -207,8 +207,18 @@ __global__ __launch_bounds__(BLSW_EXPAND_THREADS) void k_sha_expand(const uint32
     uint4* out = reinterpret_cast<uint4*>(d_witness + (inst * stride + off_expand) * 6);
     const uint64_t lane = first + inst;
     const uint32_t* b = bits + (lane >> 6) * sha_words * 64 + (lane & 63);
-    const uint32_t t = threadIdx.x, c = t % 3;
-    const uint32_t e0 = blockIdx.x * (BLSW_EXPAND_EPI * BLSW_EXPAND_ITERS) + t / 3;
+    // The segment is a stream of 16-byte pieces (piece p = element p / 3, column p % 3) that starts at an arbitrary multiple
+    // of 16 bytes (instance vectors are 33 956 496 bytes apart). Pieces are assigned from the first 256-byte boundary on
+    // (P0 < 16 head pieces are written by block 0 as well), so every 1 KiB wave store covers whole 128-byte lines.
+    const uint32_t P0 = (16u - (uint32_t)((reinterpret_cast<uintptr_t>(out) >> 4) & 15u)) & 15u;
+    const uint32_t t = threadIdx.x, pt = P0 + t, c = pt % 3;
+    const uint32_t e0 = blockIdx.x * (BLSW_EXPAND_EPI * BLSW_EXPAND_ITERS) + pt / 3;
+    if (blockIdx.x == 0 && t < P0) {  // head pieces
+        const uint32_t he = t / 3, hc = t % 3;
+        uint32_t w = b[0];
+        uint32_t m = 0u - ((w >> he) & 1u);
+        out[(uint64_t)he * 3 + hc] = make_uint4(R1[4 * hc] & m, R1[4 * hc + 1] & m, R1[4 * hc + 2] & m, R1[4 * hc + 3] & m);
+    }
     uint4 rc;
     rc.x = c == 0 ? R1[0] : (c == 1 ? R1[4] : R1[8]);
     rc.y = c == 0 ? R1[1] : (c == 1 ? R1[5] : R1[9]);
