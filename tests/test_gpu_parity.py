@@ -347,3 +347,24 @@ def test_engine_ragged_tiles(pkg, oracle):
         idx = [0, 9, 10, 63, 64, 69] if k == 0 else [0, 57, 58, 59, 60, 69]
         _compare(oracle, pk[sl], msg[sl], sig[sl], got, w, idx)
     eng.close()
+
+
+def test_engine_results_only(pkg, oracle):
+    """Grouped engine without witness tensors (value-only emitters, no SHA bit pass, no placement): gadget results only."""
+    import torch
+
+    n, steps = 16, 3
+    pk, msg, sig, expect = synth.make_batch(oracle, n * steps, tamper_every=4)
+    dev = torch.device("cuda:0")
+    eng = pkg.WitnessEngine(n, 32, max_steps=2, device=dev)
+    ress = []
+    for k in range(steps):
+        sl = slice(k * n, (k + 1) * n)
+        r = torch.empty(n, dtype=torch.int32, device=dev)
+        eng.submit(torch.from_numpy(pk[sl].view(np.int64)).to(dev), torch.from_numpy(sig[sl].view(np.int64)).to(dev), torch.from_numpy(msg[sl]).to(dev), witness=None, result=r)
+        ress.append(r)
+    eng.flush()
+    torch.cuda.synchronize()
+    for k in range(steps):
+        assert np.array_equal(ress[k].cpu().numpy().astype(bool), expect[k * n:(k + 1) * n])
+    eng.close()
