@@ -55,6 +55,7 @@ def main():
     ap.add_argument("--coalesce", type=int, default=16, help="max submitted batches fused into one launch group")
     ap.add_argument("--buffers", type=int, default=3, help="launch groups in flight (each owns streams + a workspace slice)")
     ap.add_argument("--outputs", type=int, default=2, help="ring of output witness tensors (34 MB x batch each)")
+    ap.add_argument("--mem-frac", type=float, default=0.68, help="share of the free HBM the engine workspace and the output ring may take")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=32)
     args = ap.parse_args()
@@ -97,7 +98,7 @@ def main():
     coalesce = max(1, min(args.coalesce, args.steps))
     buffers = max(1, min(args.buffers, (args.steps + coalesce - 1) // coalesce))
     # leave >= 25 % of HBM to the runtime (per-queue scratch = stacks of the chain kernels)
-    while buffers > 1 and pkg.engine_workspace_bytes(n, 32, coalesce, buffers) + n_out * out_bytes > 0.68 * free_b:
+    while buffers > 1 and pkg.engine_workspace_bytes(n, 32, coalesce, buffers) + n_out * out_bytes > args.mem_frac * free_b:
         buffers -= 1
     eng = pkg.WitnessEngine(n, 32, max_steps=coalesce, device=dev, n_buffers=buffers)
     outs = [eng.new_witness_tensor() for _ in range(n_out)]
