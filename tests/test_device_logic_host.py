@@ -209,3 +209,37 @@ def test_team_tables_are_current(tmp_path):
     counts = {l.split(":")[0]: int(l.split(" witnesses")[0].split()[-1]) for l in r.stderr.strip().splitlines()}
     # fp12_mul_w 54, fp12_sqr_w 36, cyclotomic square 18, mul_by_014 30 (constant y) / 2 + 36 (variable y), inverse check 18+12+12
     assert counts == {"MUL": 54, "SQR": 36, "CYC": 18, "ELLC": 30, "ELLV": 38, "INVCHK": 42}
+
+
+def test_team_table_invariants():
+    """Structural checks of the generated op tables (tools/gen_team_tables.py): at most six tasks per round, at most four
+    rounds, every witness offset of an op used exactly once, product slots written once and read only in later rounds."""
+    import importlib.util
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen_team_tables", os.path.join(root, "tools", "gen_team_tables.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    for op in gen.build_ops():
+        rounds = op.schedule()
+        assert 1 <= len(rounds) <= 4 and all(1 <= len(r) <= 6 for r in rounds), op.name
+        assert sorted(i for r in rounds for i in r) == list(range(len(op.tasks))), op.name
+        covered = []
+        written = {}
+        for ri, r in enumerate(rounds):
+            for i in r:
+                t = op.tasks[i]
+                covered += list(range(t["woff"], t["woff"] + gen.KIND_WITNESSES[t["kind"]]))
+                for lc in (t["a"], t["b"]):
+                    lc.lists()  # raises if a combination does not fit a descriptor
+                    for slot in lc.d:
+                        assert 0 <= slot < gen.N_SLOTS
+                        if gen.P0 <= slot < gen.P0 + gen.N_P:
+                            assert written[slot] < ri, "%s: product slot %d read in the round that writes it" % (op.name, slot)
+                if t["dst"] != 0xFF:
+                    assert t["dst"] not in written or t["dst"] == gen.XH1
+                    written[t["dst"]] = ri
+        assert sorted(covered) == list(range(op.woff)), op.name
+        for o in op.out:
+            o.lists()
+            assert all(slot in written or slot < gen.P0 or slot >= gen.X0 for slot in o.d), op.name
