@@ -101,20 +101,8 @@ BLSW_FN Proj<OpsFp> chain_mapped_aggregate(Emitter e_count, Emitter e_agg, const
 }
 
 // ------------------------------------------------------------------------------------------------ G2 allocation
-BLSW_FN void chain_g2_alloc(Emitter e, const Fp2& sx, const Fp2& sy) {
-    constexpr uint32_t RM1[8] = BLSW_RM1_WORDS;
-    bool inf = fp2_is_zero(sx) && fp2_is_zero(sy);
-    Proj<OpsFp2> ge;
-    ge.x = inf ? fp2_zero() : sx;
-    ge.y = inf ? fp2_one() : sy;
-    ge.z = inf ? fp2_zero() : fp2_one();
-    e.put(ge.x.c0);
-    e.put(ge.x.c1);
-    e.put(ge.y.c0);
-    e.put(ge.y.c1);
-    e.put(ge.z.c0);
-    e.put(ge.z.c1);
-    (void)proj_mul_bits_be_w<OpsFp2>(e, ge, RM1, BLSW_RM1_NBITS);
+// the rest of the G2 allocation after the subgroup scalar multiplication: ge.enforce_equal(&ge) and the zero tests
+BLSW_FN void chain_g2_alloc_tail(Emitter e, const Proj<OpsFp2>& ge) {
     // ge.enforce_equal(&ge)   (sic: ark-r1cs-std 0.4.0)
     Fp2 l0 = fp2_mul_w(e, ge.x, ge.z);
     Fp2 r0 = fp2_mul_w(e, ge.x, ge.z);
@@ -129,6 +117,23 @@ BLSW_FN void chain_g2_alloc(Emitter e, const Fp2& sx, const Fp2& sy) {
     bool both_zero = za && zb;
     e.put_bool(both_zero);
     e.put_bool(both_zero || coords_eq);
+}
+
+BLSW_FN void chain_g2_alloc(Emitter e, const Fp2& sx, const Fp2& sy) {
+    constexpr uint32_t RM1[8] = BLSW_RM1_WORDS;
+    bool inf = fp2_is_zero(sx) && fp2_is_zero(sy);
+    Proj<OpsFp2> ge;
+    ge.x = inf ? fp2_zero() : sx;
+    ge.y = inf ? fp2_one() : sy;
+    ge.z = inf ? fp2_zero() : fp2_one();
+    e.put(ge.x.c0);
+    e.put(ge.x.c1);
+    e.put(ge.y.c0);
+    e.put(ge.y.c1);
+    e.put(ge.z.c0);
+    e.put(ge.z.c1);
+    (void)proj_mul_bits_be_w<OpsFp2>(e, ge, RM1, BLSW_RM1_NBITS);
+    chain_g2_alloc_tail(e, ge);
 }
 
 // ------------------------------------------------------------------------------------------------ map_to_curve

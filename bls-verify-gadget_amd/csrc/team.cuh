@@ -58,7 +58,8 @@ BLSW_HD uint32_t team_lin_idx(const TeamLin& L, uint32_t k) {
 BLSW_HD Fp2 team_gather(const TeamLin& L, const Fp2* slots) {
     Fp2 acc = fp2_zero();
     uint32_t k = 0;
-    const uint32_t n0 = L.n & 0xff, n1 = (L.n >> 8) & 0xff, n2 = (L.n >> 16) & 0xff, n3 = L.n >> 24;
+    const uint32_t n0 = L.n & 0x3f, n1 = (L.n >> 8) & 0xff, n2 = (L.n >> 16) & 0xff, n3 = L.n >> 24;
+    const uint32_t mscale = (L.n >> 6) & 3;  // the xi part times 1, 12 or 24 (3b of the twist: 12 xi)
     if (n0) {
         acc = team_ld(slots, team_lin_idx(L, 0));
         k = 1;
@@ -69,6 +70,11 @@ BLSW_HD Fp2 team_gather(const TeamLin& L, const Fp2* slots) {
         Fp2 m = fp2_zero();
         for (uint32_t e = k + n2; k < e; k++) m = fp2_add(m, team_ld(slots, team_lin_idx(L, k)));
         for (uint32_t e = k + n3; k < e; k++) m = fp2_sub(m, team_ld(slots, team_lin_idx(L, k)));
+        if (mscale) {
+            Fp2 m3 = fp2_add(fp2_dbl(m), m);
+            Fp2 m12 = fp2_dbl(fp2_dbl(m3));
+            m = mscale == 2 ? fp2_dbl(m12) : m12;
+        }
         acc = fp2_add(acc, fp2_mul_xi(m));
     }
     return acc;
@@ -85,13 +91,31 @@ BLSW_HD void team_task(const TeamTask& t, Fp2* slots, const Emitter& e) {
     // the witnesses of a task are contiguous in the instance's segment: computed first, then stored back to back
     // (144 contiguous bytes per lane and 864 per team and round reach L2 within one burst)
     Fp2 r = fp2_zero();
-    if (kind == TK_K3 || kind == TK_K3V) {  // Karatsuba: a0*b0, a1*b1, (a0+a1)*(b0+b1)
-        Fp v0 = fp_mul(a.c0, b.c0), v1 = fp_mul(a.c1, b.c1);
-        Fp s = fp_mul(fp_add(a.c0, a.c1), fp_add(b.c0, b.c1));
-        w.put(v0);
-        w.put(v1);
-        w.put(s);
-        r = {fp_sub(v0, v1), fp_sub(fp_sub(s, v0), v1)};
+    if (kind == TK_K3 || kind == TK_K3V || kind == TK_K2S) {
+        // one instruction stream for the kinds that share rounds:
+        //   K3 / K3V  Karatsuba: a0*b0, a1*b1, (a0+a1)*(b0+b1)           -> (p0 - p1, p2 - p0 - p1), 3 witnesses
+        //   K2S       Fp2 square: a0*a1, (a0-a1)*(a0+a1), (third unused) -> (p1, 2 p0),              2 witnesses
+        const bool sq = kind == TK_K2S;
+        const Fp sum = fp_add(a.c0, a.c1), dif = fp_sub(a.c0, a.c1), bsum = fp_add(b.c0, b.c1);
+        Fp y0, x1, y1;
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            y0.l[i] = sq ? a.c1.l[i] : b.c0.l[i];
+            x1.l[i] = sq ? dif.l[i] : a.c1.l[i];
+            y1.l[i] = sq ? sum.l[i] : b.c1.l[i];
+        }
+        Fp p0 = fp_mul(a.c0, y0), p1 = fp_mul(x1, y1);
+        Fp p2 = fp_mul(sum, bsum);
+        w.put(p0);
+        w.put(p1);
+        if (!sq) w.put(p2);
+        Fp2 rk = {fp_sub(p0, p1), fp_sub(fp_sub(p2, p0), p1)};
+        Fp2 rs = {p1, fp_dbl(p0)};
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            r.c0.l[i] = sq ? rs.c0.l[i] : rk.c0.l[i];
+            r.c1.l[i] = sq ? rs.c1.l[i] : rk.c1.l[i];
+        }
     } else if (kind == TK_K2 || kind == TK_K2V || kind == TK_K2B) {
         // two Fp products by the same y = b.c0, one instruction stream for the three kinds (they share rounds):
         //   K2 / K2V  Fp2 x (y, 0): a.c0*y, (a.c0+a.c1)*y -> (v0, s - v0)      K2B  a.c0*y, a.c1*y -> (v0, s)
@@ -231,6 +255,19 @@ BLSW_HD typename TEAM::Reg team_exp_by_x_body(TEAM& t, const typename TEAM::Reg&
 template <class TEAM>
 BLSW_HD typename TEAM::Reg team_exp_by_x(TEAM& t, const typename TEAM::Reg& f) {
     return t.exp_by_x(f);
+}
+// [k] ge for the bits of `words` (big-endian, the top bit is ge itself): the in-circuit subgroup check of G2 allocation
+// (curve.cuh::proj_mul_bits_be_w<OpsFp2>). Points are distributed over lanes 0..2 of a team (x, y, z).
+template <class TEAM>
+BLSW_HD typename TEAM::Reg team_g2_mul_bits(TEAM& t, const typename TEAM::Reg& ge, const uint32_t* words, int nbits) {
+    typename TEAM::Reg result = ge;
+#pragma unroll 1
+    for (int i = nbits - 2; i >= 0; i--) {
+        const int n_phases = ((words[i >> 5] >> (i & 31)) & 1) ? 2 : 1;
+#pragma unroll 1
+        for (int ph = 0; ph < n_phases; ph++) result = t.exec_hot(ph == 0 ? TEAM_OP_G2DBL : TEAM_OP_G2ADD, result, ge);
+    }
+    return result;
 }
 // final_exponentiation . is_one (chains.cuh::chain_final_exp_is_one); the cursor of `t` must be at off_final_exp
 template <class TEAM>

@@ -89,6 +89,28 @@ struct TeamHost {
     }
 };
 static int g_use_team = 0;
+// G2 allocation with the scalar multiplication of the subgroup check on the team program (lanes 0..2 own x, y, z)
+static void g2_alloc_segment(uint32_t* base, const blsw_layout_t& L, const Fp2& sx, const Fp2& sy) {
+    if (!g_use_team) {
+        chain_g2_alloc({base, L.off_sig_alloc}, sx, sy);
+        return;
+    }
+    constexpr uint32_t RM1[8] = BLSW_RM1_WORDS;
+    bool inf = fp2_is_zero(sx) && fp2_is_zero(sy);
+    TeamHost t;
+    t.e = {base, L.off_sig_alloc};
+    TeamHost::Reg ge = t.zero();
+    ge[0] = inf ? fp2_zero() : sx;
+    ge[1] = inf ? fp2_one() : sy;
+    ge[2] = inf ? fp2_zero() : fp2_one();
+    for (int j = 0; j < 3; j++) {
+        t.e.put(ge[j].c0);
+        t.e.put(ge[j].c1);
+    }
+    (void)team_g2_mul_bits(t, ge, RM1, BLSW_RM1_NBITS);
+    chain_g2_alloc_tail(t.e, {ge[0], ge[1], ge[2]});
+}
+
 static bool pairing_segment(uint32_t* base, const blsw_layout_t& L, const Fp& ax, const Fp& ay, Fp* cs, Fp* ch) {
     if (!g_use_team) {
         Fp12 fm = chain_miller({base, L.off_miller}, ax, ay, CoeffLinear{cs}, CoeffLinear{ch});
@@ -125,7 +147,7 @@ int hostsim_witness(const uint64_t* pk_xy, const uint8_t* msg, uint32_t msg_len,
     Fp pkx = load_fp(pk_xy), pky = load_fp(pk_xy + 6);
     G1ChainOut g1 = chain_g1_alloc({base, L.off_pk_alloc}, {base, L.off_pk_not_zero}, {base, L.off_prep_pk}, pkx, pky);
     Fp2 sx = {load_fp(sig_xy), load_fp(sig_xy + 6)}, sy = {load_fp(sig_xy + 12), load_fp(sig_xy + 18)};
-    chain_g2_alloc({base, L.off_sig_alloc}, sx, sy);
+    g2_alloc_segment(base, L, sx, sy);
     // expand_message: bitstream then expansion
     std::vector<uint32_t> bits((L.sha_bits + 31) / 32 + 1, 0);
     BitSink s;
@@ -170,7 +192,7 @@ int hostsim_witness_aggregate(const uint64_t* pks_xy, const uint8_t* bitmap, uin
     for (uint32_t i = 0; i < msg_len; i++)
         for (int j = 0; j < 8; j++) em.put_bool((msg[i] >> j) & 1);
     Fp2 sx = {load_fp(sig_xy), load_fp(sig_xy + 6)}, sy = {load_fp(sig_xy + 12), load_fp(sig_xy + 18)};
-    chain_g2_alloc({base, L.off_sig_alloc}, sx, sy);
+    g2_alloc_segment(base, L, sx, sy);
     HostKeys hk = {&keys};
     Proj<OpsFp> agg = chain_mapped_aggregate({base, L.off_count}, {base, L.off_agg}, hk, bitmap, K, count_out);
     G1ChainOut g1 = chain_g1_post({base, L.off_pk_not_zero}, {base, L.off_prep_pk}, agg);

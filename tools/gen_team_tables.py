@@ -17,9 +17,9 @@ IN0, IN1, P0, X0 = 0, 6, 12, 30
 N_P = 18
 XS0, XS1, XH0, XH1, XYC, XYV, XPX = range(X0, X0 + 7)
 N_SLOTS = X0 + 7
-K_NONE, K3, K3V, K2, K2V, K2B, K1E = range(7)
-KIND_NAMES = ["TK_NONE", "TK_K3", "TK_K3V", "TK_K2", "TK_K2V", "TK_K2B", "TK_K1E"]
-KIND_WITNESSES = {K3: 3, K3V: 0, K2: 2, K2V: 0, K2B: 2, K1E: 1}
+K_NONE, K3, K3V, K2, K2V, K2B, K1E, K2S = range(8)
+KIND_NAMES = ["TK_NONE", "TK_K3", "TK_K3V", "TK_K2", "TK_K2V", "TK_K2B", "TK_K1E", "TK_K2S"]
+KIND_WITNESSES = {K3: 3, K3V: 0, K2: 2, K2V: 0, K2B: 2, K1E: 1, K2S: 2}
 MAX_TERMS = 16
 
 
@@ -55,12 +55,21 @@ class LC:
                 raise ValueError("xi^2 is not representable: split the op")
         return LC({k: (0, a) for k, (a, b) in self.d.items()})
 
+    def mscale(self):
+        """common factor of the xi part that the device applies after summing: 12 (= 3b of y^2 = x^3 + 4 xi) or 24"""
+        import math
+        g = 0
+        for a, b in self.d.values():
+            g = math.gcd(g, abs(b))
+        return 24 if g and g % 24 == 0 else (12 if g and g % 12 == 0 else 1)
+
     def lists(self):
         lp, ln, mp, mn = [], [], [], []
+        sc = self.mscale()
         for k in sorted(self.d):
             a, b = self.d[k]
             (lp if a > 0 else ln).extend([k] * abs(a))
-            (mp if b > 0 else mn).extend([k] * abs(b))
+            (mp if b > 0 else mn).extend([k] * (abs(b) // sc))
         if len(lp) + len(ln) + len(mp) + len(mn) > MAX_TERMS:
             raise ValueError("linear combination too long: %d" % (len(lp) + len(ln) + len(mp) + len(mn)))
         return lp, ln, mp, mn
@@ -102,6 +111,9 @@ class Op:
     def muleq(self, a, b):
         self._task(K1E, a, b, want_result=False)
 
+    def sqr2(self, a):  # Fp2 square: a0*a1, (a0 - a1)(a0 + a1)
+        return self._task(K2S, a, ZERO)
+
     def schedule(self):
         """rounds of <= 6 tasks of one kind; a task that reads a product goes after the round that produced it"""
         level = {}
@@ -114,7 +126,7 @@ class Op:
                         lv = max(lv, level[prod] + 1)
             level[i] = lv
         # kinds that run the same instruction stream share rounds: the two-product kinds (K2, K2V, K2B) and the Karatsuba kinds
-        classes = ((K2B, K2, K2V), (K3, K3V), (K1E,))
+        classes = ((K2B, K2, K2V), (K3, K3V, K2S), (K1E,))
         rounds = []
         for lv in sorted(set(level.values())):
             for cls in classes:
@@ -243,6 +255,54 @@ def build_ops():
     c1 = op.mul2b(LC.slot(XH1), LC.slot(XPX))
     ops.append(finish(op, fp12_mul_by_014_w(op, a, LC.slot(XH0), c1, LC.slot(XYV), True)))
 
+    # ---- G2 points, homogeneous projective (x, y, z) on lanes 0..2 (curve.cuh: proj_double_w / proj_add_w<0> over Fp2;
+    # 3b = 12 xi). IN0 = p (slots 0..2), IN1 = q (slots 6..8).
+    px, py, pz = LC.slot(IN0 + 0), LC.slot(IN0 + 1), LC.slot(IN0 + 2)
+    qx, qy, qz = LC.slot(IN1 + 0), LC.slot(IN1 + 1), LC.slot(IN1 + 2)
+
+    def x12xi(v):
+        t = v.xi()
+        return LC({k: (a, 12 * b) for k, (a, b) in t.d.items()})
+
+    op = Op("G2DBL")
+    xx = op.sqr2(px)
+    yy = op.sqr2(py)
+    zz = op.sqr2(pz)
+    xy2 = op.mul3(px, py).dbl()
+    xz2 = op.mul3(px, pz).dbl()
+    bzz3 = x12xi(zz)
+    yy_m, yy_p = yy - bzz3, yy + bzz3
+    y_frag = op.mul3(yy_p, yy_m)
+    x_frag = op.mul3(yy_m, xy2)
+    bxz3 = x12xi(xz2)
+    xx3 = xx.dbl() + xx
+    tt = op.mul3(xx3, bxz3)
+    yz2 = op.mul3(py, pz).dbl()
+    t2 = op.mul3(bxz3, yz2)
+    zp = op.mul3(yz2, yy)
+    op.out = [x_frag - t2, y_frag + tt, zp.dbl().dbl(), ZERO, ZERO, ZERO]
+    ops.append(op)
+
+    op = Op("G2ADD")
+    xx = op.mul3(px, qx)
+    yy = op.mul3(py, qy)
+    zz = op.mul3(pz, qz)
+    xy_pairs = op.mul3(px + py, qx + qy) - (xx + yy)
+    xz_pairs = op.mul3(px + pz, qx + qz) - (xx + zz)
+    yz_pairs = op.mul3(py + pz, qy + qz) - (yy + zz)
+    bzz3 = x12xi(zz)
+    yy_m, yy_p = yy - bzz3, yy + bzz3
+    xx3 = xx.dbl() + xx
+    bxz3 = x12xi(xz_pairs)
+    m0 = op.mul3(yy_m, xy_pairs)
+    m1 = op.mul3(yz_pairs, bxz3)
+    m2 = op.mul3(yy_p, yy_m)
+    m3 = op.mul3(xx3, bxz3)
+    m4 = op.mul3(yy_p, yz_pairs)
+    m5 = op.mul3(xy_pairs, xx3)
+    op.out = [m0 - m1, m2 + m3, m4 + m5, ZERO, ZERO, ZERO]
+    ops.append(op)
+
     op = Op("INVCHK")  # mul_equals(self, inverse, one) of fp12_inv_w: IN0 = self, IN1 = inverse
     fp6_mul_w(op, a[1], b[1])
     fp6_mul_equals_w(op, a[0], b[0])
@@ -256,7 +316,7 @@ def c_lin(lc):
     lp, ln, mp, mn = lc.lists()
     idx = lp + ln + mp + mn
     idx += [0] * (MAX_TERMS - len(idx))
-    n = len(lp) | len(ln) << 8 | len(mp) << 16 | len(mn) << 24
+    n = len(lp) | len(ln) << 8 | len(mp) << 16 | len(mn) << 24 | {1: 0, 12: 1, 24: 2}[lc.mscale()] << 6
     words = [idx[4 * w] | idx[4 * w + 1] << 8 | idx[4 * w + 2] << 16 | idx[4 * w + 3] << 24 for w in range(4)]
     return "{0x%08xu, {%s}}" % (n, ", ".join("0x%08xu" % w for w in words))
 
