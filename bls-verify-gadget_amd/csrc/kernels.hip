@@ -43,6 +43,7 @@ static bool pairing_team_mode() {
     }
     return mode == 1;
 }
+inline blsw_layout_t staging_layout(const blsw_layout_t& L);
 Workspace carve(void* base, uint64_t N, const blsw_layout_t& L, bool with_staging) {
     Workspace w;
     w.sha_words = (L.sha_bits + 31) / 32 + 1;
@@ -59,7 +60,7 @@ Workspace carve(void* base, uint64_t N, const blsw_layout_t& L, bool with_stagin
     w.pkaff = reinterpret_cast<Fp*>(take(2 * N * sizeof(Fp)));
     w.coeff = reinterpret_cast<Fp*>(take(2ull * 272 * N * sizeof(Fp)));
     w.staging_rows = L.n_witness - L.sha_bits;
-    w.split_row = pairing_team_mode() ? L.off_miller - L.sha_bits : (uint32_t)w.staging_rows;
+    w.split_row = pairing_team_mode() ? staging_layout(L).off_miller : (uint32_t)w.staging_rows;
     w.pair_rows = (uint32_t)w.staging_rows - w.split_row;
     w.staging = with_staging ? reinterpret_cast<Fp*>(take((uint64_t)w.split_row * align_up(N, 64) * sizeof(Fp))) : nullptr;
     w.pair = with_staging && w.pair_rows ? reinterpret_cast<Fp*>(take((uint64_t)w.pair_rows * N * sizeof(Fp))) : nullptr;
@@ -91,11 +92,27 @@ struct Group {
     Workspace ws;
     int chain_prio;        // chain waves raise s_setprio
 };
+// G2 allocation on the six-lane machinery (BLSW_G2=team; needs the six-lane pairing mode): its segment is staged
+// instance-major like the pairing rows, so it moves to the end of the staging coordinates
+static bool g2_team_mode() {
+    static int mode = -1;
+    if (mode < 0) {
+        const char* s = getenv("BLSW_G2");
+        mode = (s && s[0] == 't' && pairing_team_mode()) ? 1 : 0;
+    }
+    return mode == 1;
+}
 inline blsw_layout_t staging_layout(const blsw_layout_t& L) {
     blsw_layout_t S = L;
     uint32_t* f = &S.off_msg;
     const uint32_t* g = &L.off_msg;
     for (int k = 0; k < 15; k++) f[k] = g[k] > L.off_expand ? g[k] - L.sha_bits : g[k];
+    if (g2_team_mode()) {
+        const uint32_t lo = L.off_sig_alloc, len = L.off_pk_not_zero - L.off_sig_alloc;
+        for (int k = 0; k < 15; k++)
+            if (f[k] > lo) f[k] -= len;
+        S.off_sig_alloc = L.n_witness - L.sha_bits - len;  // last rows of the staging coordinates
+    }
     return S;
 }
 
@@ -260,7 +277,7 @@ __global__ __launch_bounds__(BLSW_EXPAND_THREADS) void k_sha_expand(const uint32
 #endif
 __global__ __launch_bounds__(256) void k_place_field(const Fp* __restrict__ staging, const Fp* __restrict__ pair, uint64_t first, uint32_t off_expand,
                                                      uint32_t sha_bits, uint32_t staging_rows, uint32_t split_row, uint64_t* __restrict__ d_witness,
-                                                     uint64_t stride, uint32_t n_inst) {
+                                                     uint64_t stride, uint32_t n_inst, uint32_t moved_lo, uint32_t moved_len, uint32_t moved_at) {
     // XCD-aware block order: workgroups go round-robin to the 8 XCDs (each with its own L2). The 64 instances of a tile read
     // neighbouring 48-byte pieces of the same staging lines, so all instances of one chunk of rows run back to back on ONE
     // XCD: linear id L -> xcd = L % 8, chunk = xcd + 8 * ((L / 8) / n_inst), instance = (L / 8) % n_inst.
@@ -280,7 +297,11 @@ __global__ __launch_bounds__(256) void k_place_field(const Fp* __restrict__ stag
         if (q < nchunks) {
             uint32_t e = q / 3, c = q - e * 3;
             uint4 v = e < split_row ? src[(uint64_t)e * 64 * 3 + c] : src2[(uint64_t)(e - split_row) * 3 + c];
-            uint32_t dst_e = e < off_expand ? e : e + sha_bits;
+            // staging row -> witness index: the SHA segment is cut out; a segment staged at the end (moved_len rows that belong
+            // at moved_lo, staged from row moved_at on) goes back to its place
+            uint32_t t = e;
+            if (moved_len) t = e >= moved_at ? moved_lo + (e - moved_at) : (e >= moved_lo ? e + moved_len : e);
+            uint32_t dst_e = (moved_len && e >= moved_at) ? t : (t < off_expand ? t : t + sha_bits);
             out[(uint64_t)dst_e * 3 + c] = v;
         }
     }
@@ -465,6 +486,40 @@ __global__ __launch_bounds__(64) void k_pairing_team(Group g) {
     bool res = team_final_exp_is_one(t, f, e_one);
     int32_t* r = g.desc[id.s].result;
     if (active && j == 0 && r) r[id.i] = res ? 1 : 0;
+}
+// G2 allocation, six lanes per instance: the (r - 1) * sig chain of the subgroup check runs on the team machinery (points on
+// lanes 0..2), the allocation witnesses and the enforce_equal tail are single-lane work of lane 0
+__global__ __launch_bounds__(64) void k_g2_alloc_team(Group g) {
+    __shared__ Fp2 lds[BLSW_TEAMS_PER_WAVE * TS_NSLOTS];
+    if (g.chain_prio) __builtin_amdgcn_s_setprio(3);
+    constexpr uint32_t RM1[8] = BLSW_RM1_WORDS;
+    const uint32_t team = threadIdx.x / 6, j = threadIdx.x % 6;
+    const uint64_t I0 = (uint64_t)blockIdx.x * BLSW_TEAMS_PER_WAVE + team;
+    const bool active = team < BLSW_TEAMS_PER_WAVE && I0 < g.N;
+    const uint64_t I = active ? I0 : 0;
+    LaneId id = lane_id(g, I);
+    const Fp* p = reinterpret_cast<const Fp*>(g.desc[id.s].sig + (uint64_t)id.i * 24);
+    Fp2 sx = {ld_fp(p), ld_fp(p + 1)}, sy = {ld_fp(p + 2), ld_fp(p + 3)};
+    const bool inf = fp2_is_zero(sx) && fp2_is_zero(sy);
+    Proj<OpsFp2> ge = {inf ? fp2_zero() : sx, inf ? fp2_one() : sy, inf ? fp2_zero() : fp2_one()};
+    TeamLanes<CoeffStrided> t;
+    t.slots = lds + (active ? team : 0) * TS_NSLOTS;
+    t.j = j;
+    t.active = active;
+    t.coeff_h = {nullptr, 0};
+    t.coeff_sig = {nullptr, 0};
+    t.e = EMIT(g, id, off_sig_alloc);
+    if (!active) t.e.base = nullptr;
+    Fp2 mine = j == 0 ? ge.x : (j == 1 ? ge.y : (j == 2 ? ge.z : fp2_zero()));
+    if (j < 3) {  // the six allocation witnesses: x.c0, x.c1, y.c0, y.c1, z.c0, z.c1
+        Emitter w = t.e;
+        w.pos += 2 * j;
+        w.put(mine.c0);
+        w.put(mine.c1);
+    }
+    t.e.pos += 6;
+    (void)team_g2_mul_bits(t, mine, RM1, BLSW_RM1_NBITS);
+    if (active && j == 0) chain_g2_alloc_tail(t.e, ge);
 }
 static void launch_pairing(const Group& g, hipStream_t st) {
     if (!pairing_team_mode())
@@ -703,7 +758,10 @@ static int launch_group(blsw_engine* e, hipStream_t user_stream) {
     for (uint32_t s = 0; s < steps; s++) any_out = any_out || b.h_desc[s].out != nullptr;
     // aux0: group allocations
     hipLaunchKernelGGL(k_g1, dim3(g1), dim3(64), 0, b.st[1], g);
-    hipLaunchKernelGGL(k_g2_alloc, dim3(g1), dim3(64), 0, b.st[1], g);
+    if (g2_team_mode())
+        hipLaunchKernelGGL(k_g2_alloc_team, dim3((unsigned)((g.N + BLSW_TEAMS_PER_WAVE - 1) / BLSW_TEAMS_PER_WAVE)), dim3(64), 0, b.st[1], g);
+    else
+        hipLaunchKernelGGL(k_g2_alloc, dim3(g1), dim3(64), 0, b.st[1], g);
     hipEventRecord(b.ev_aux[0], b.st[1]);
     // aux1: prepare_g2(sig), then the SHA-256 witness bits
     hipLaunchKernelGGL(k_prepare, dim3(g1), dim3(64), 0, b.st[2], g, 1);
@@ -746,7 +804,8 @@ static int launch_group(blsw_engine* e, hipStream_t user_stream) {
             const unsigned chunks = (rows * 3 + 256 * BLSW_PLACE_ITERS - 1) / (256 * BLSW_PLACE_ITERS);
             dim3 grid2(8 * ((chunks + 7) / 8) * (unsigned)e->n);
             hipLaunchKernelGGL(k_place_field, grid2, dim3(256), 0, e->place, g.ws.staging, g.ws.pair, (uint64_t)s * e->n, e->L.off_expand, e->L.sha_bits, rows,
-                               g.ws.split_row, d.out, d.out_stride, (uint32_t)e->n);
+                               g.ws.split_row, d.out, d.out_stride, (uint32_t)e->n, e->L.off_sig_alloc,
+                               g2_team_mode() ? e->L.off_pk_not_zero - e->L.off_sig_alloc : 0u, e->LS.off_sig_alloc);
         }
     }
     hipEventRecord(b.ev_done, e->place);

@@ -368,3 +368,20 @@ def test_engine_results_only(pkg, oracle):
     for k in range(steps):
         assert np.array_equal(ress[k].cpu().numpy().astype(bool), expect[k * n:(k + 1) * n])
     eng.close()
+
+
+def test_g2_allocation_on_the_team_machinery():
+    """BLSW_G2=team (experimental, off by default): the G2 allocation's subgroup chain on the six-lane machinery and its
+    segment staged instance-major at the end of the staging coordinates. The mode is read once per process, so the direct,
+    grouped and ragged parity tests are re-run in ONE child process with the variable set."""
+    import subprocess
+    import sys
+
+    if os.environ.get("BLSW_G2") == "team":
+        pytest.skip("already inside the child run")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BLSW_G2="team")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-m", "gpu", "-x", "-q", "-k",
+                        "batch_bit_exact or engine_grouped or ragged or digests"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
