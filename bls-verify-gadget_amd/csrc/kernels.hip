@@ -490,7 +490,9 @@ __global__ __launch_bounds__(64) void k_pairing_team(Group g) {
 // G2 allocation, six lanes per instance: the (r - 1) * sig chain of the subgroup check runs on the team machinery (points on
 // lanes 0..2), the allocation witnesses and the enforce_equal tail are single-lane work of lane 0
 __global__ __launch_bounds__(64) void k_g2_alloc_team(Group g) {
-    __shared__ Fp2 lds[BLSW_TEAMS_PER_WAVE * TS_NSLOTS];
+    // the G2 op tables use the operand slots and 12 product slots only: 24 slots = 23 KB per wave, six waves per CU
+    constexpr uint32_t G2_SLOTS = TS_P + 12;
+    __shared__ Fp2 lds[BLSW_TEAMS_PER_WAVE * G2_SLOTS];
     if (g.chain_prio) __builtin_amdgcn_s_setprio(3);
     constexpr uint32_t RM1[8] = BLSW_RM1_WORDS;
     const uint32_t team = threadIdx.x / 6, j = threadIdx.x % 6;
@@ -503,7 +505,7 @@ __global__ __launch_bounds__(64) void k_g2_alloc_team(Group g) {
     const bool inf = fp2_is_zero(sx) && fp2_is_zero(sy);
     Proj<OpsFp2> ge = {inf ? fp2_zero() : sx, inf ? fp2_one() : sy, inf ? fp2_zero() : fp2_one()};
     TeamLanes<CoeffStrided> t;
-    t.slots = lds + (active ? team : 0) * TS_NSLOTS;
+    t.slots = lds + (active ? team : 0) * G2_SLOTS;
     t.j = j;
     t.active = active;
     t.coeff_h = {nullptr, 0};
