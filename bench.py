@@ -1,27 +1,30 @@
 #!/usr/bin/env python3
 """bench.py — BLS-verify witness instances/sec (full pairing circuit) on MI355X.
 
-One "step" = one pass of the hot path (blsw_witness_batch: every witness of the circuit of
-/root/reference/src/constraints.rs:335-366, for each instance) over one batch of 1 024 synthetic (pk, msg, sig)
-instances (BASELINE.json configs[1]). Inputs are resident in HBM before the timed region; every step writes a
-complete [1024][n_witness] witness tensor (34 MB per instance) into HBM.
+One "step" = one pass of the hot path (every witness of the circuit of /root/reference/src/constraints.rs:335-366, for
+each instance) over one batch of 1 024 synthetic (pk, msg, sig) instances (BASELINE.json configs[1]). Inputs are resident
+in HBM before the timed region; every step writes a complete [1024][n_witness] witness tensor (34 MB per instance).
 
 Steps are SUBMITTED to the engine, which fuses up to `--coalesce` pending batches into one group of launches (a single
-batch of 1024 instances is 16 wavefronts per chain kernel on a 1024-SIMD chip) and then writes every step's witness
-tensor, in submission order, into a ring of `--outputs` output tensors. EXACTLY K steps (K full witness tensors) are
-timed between barrier + synchronize on both sides.
+batch of 1024 instances is 16 wavefronts per chain kernel on a 1024-SIMD chip) and writes every step's witness tensor, in
+submission order, into a ring of `--outputs` output tensors. EXACTLY K steps (K full witness tensors) are timed between
+barrier + synchronize on both sides.
 
-Multi-GPU (launched by torch.distributed.run, one rank per GPU): instances are independent, each rank processes its
-own 1 024-instance shard per step (weak scaling, no data-path collective); only the result vectors are gathered.
+Multi-GPU: one process per GPU over RCCL. `python bench.py --gpus N` starts the N ranks itself (a child
+`python -m torch.distributed.run`, spawned before this process touches the GPU) and prints the child's one JSON line; under
+an external launcher (RANK / WORLD_SIZE in the environment) it is a rank and checks WORLD_SIZE == --gpus. Instances are
+independent: each rank processes its own 1 024-instance shard per step (weak scaling, NO data-path collective in `value`);
+the north-star's all-gather of witness shards is timed separately (`value_with_allgather`): micro-batches of every step's
+tensor are all-gathered over RCCL and consumed by the digest kernel before the ring slot is reused.
 """
 import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -34,19 +37,13 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s meas
 # inversion (Fermat pricing)
 MAD_PER_FPMUL = 300
 FPMUL_PER_INV = 570
+# what the kernels execute instead of a Fermat inversion: one safegcd inversion = 26.9 Fp-product times (blsw_microbench 2 / 1);
+# 636 of the 940 cofactor-chain inversions are shared with a neighbour (Montgomery's trick: +9 products each, -1 inversion)
+FPMUL_PER_INV_EXECUTED = 27
+TRAFFIC_FILES = ("r02_traffic.json", "r01_traffic.json")
 
 
-def synth_inputs(pkg, n, seed, dev):
-    """Synthetic valid instances, minted on the GPU by the product's own signer (blsw_sign_batch):
-    64 distinct signed instances are tiled to n (no kernel caches anything across lanes)."""
-    workload = importlib.import_module("bls-verify-gadget_amd.workload")
-    base = min(n, 64)
-    pk, msg, sig, expect = workload.make_batch(pkg, base, seed=seed, device=dev)
-    reps = (n + base - 1) // base
-    return pk.repeat(reps, 1)[:n].contiguous(), msg.repeat(reps, 1)[:n].contiguous(), sig.repeat(reps, 1)[:n].contiguous(), np.tile(expect, reps)[:n].copy()
-
-
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1024)
@@ -57,18 +54,149 @@ def main():
     ap.add_argument("--outputs", type=int, default=2, help="ring of output witness tensors (34 MB x batch each)")
     ap.add_argument("--mem-frac", type=float, default=0.68, help="share of the free HBM the engine workspace and the output ring may take")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=32)
-    args = ap.parse_args()
+    ap.add_argument("--cpu-sample", type=int, default=256, help="instances of the batch timed on the host (all cores, and one thread)")
+    ap.add_argument("--allgather-steps", type=int, default=4, help="steps of the generation + all-gather leg (0 = skip; runs when a process group exists)")
+    ap.add_argument("--allgather-chunk", type=int, default=16, help="instances per rank in one all-gathered micro-batch")
+    return ap.parse_args()
 
+
+def spawn_ranks(args):
+    """--gpus N outside a launcher: start N ranks as a CHILD torch.distributed.run (this process has not touched the GPU and
+    never will) and relay the one JSON line rank 0 prints."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    if lines:
+        print(lines[-1])
+    else:
+        sys.stderr.write(p.stdout)
+    sys.exit(p.returncode if p.returncode or lines else 1)
+
+
+def balanced_coalesce(steps, max_group):
+    """Equal launch groups: 20 steps with groups of at most 16 run as 10 + 10 rather than 16 + 4."""
+    groups = (steps + max_group - 1) // max_group
+    return max(1, (steps + groups - 1) // groups)
+
+
+def cpu_baseline(args, d_pk, d_msg, d_sig, n):
+    """The C++ restatement of the reference path (oracle/) on the host cores: all cores and one thread, on the first
+    `--cpu-sample` instances of the batch. Built -O3 -march=native on THIS machine when a compiler is present."""
+    import numpy as np
+
+    from tests import oracle_lib  # the CPU restatement: used for this baseline leg only
+
+    build = "portable (-O3 -march=x86-64-v3 -madx)"
+    oracle = None
+    try:
+        import ctypes
+
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "native"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        oracle = oracle_lib.Oracle(ctypes.CDLL(os.path.join(ROOT, "oracle", "_native", "liboracle.so")))
+        build = "-O3 -march=native, built on this host"
+    except Exception:
+        oracle = oracle_lib.load()
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    m = min(args.cpu_sample, n)
+    h_pk, h_msg, h_sig = d_pk[:m].cpu().numpy().view(np.uint64), d_msg[:m].cpu().numpy(), d_sig[:m].cpu().numpy().view(np.uint64)
+    t1 = time.perf_counter()
+    oracle.witness_batch(h_pk, h_msg, h_sig, threads=cores, want_digests=False)
+    all_dt = time.perf_counter() - t1
+    m1 = min(m, max(8, int(30.0 / max(all_dt * cores / m, 1e-9))))  # the same sample on one thread, capped at ~30 s of work
+    t1 = time.perf_counter()
+    oracle.witness_batch(h_pk[:m1], h_msg[:m1], h_sig[:m1], threads=1, want_digests=False)
+    one_dt = time.perf_counter() - t1
+    return {"value": m / all_dt, "unit": "instances/s", "cores": cores, "kind": "port", "value_1thread": m1 / one_dt,
+            "sample": "first %d instances of the bench batch through the C++ restatement of the reference path (oracle/, %s), %d threads: %.2f s; "
+                      "first %d instances on one thread: %.2f s" % (m, build, cores, all_dt, m1, one_dt)}
+
+
+def allgather_leg(args, pkg, sharding, dist, dev, inputs, lay, world):
+    """Generation + RCCL all-gather of the witness shards (north_star): every step's tensor is all-gathered in
+    micro-batches of `--allgather-chunk` instances per rank and each gathered micro-batch is consumed by the digest kernel
+    before the next one; a ring slot is released to the engine when its last micro-batch has been consumed."""
+    import torch
+
+    n, ring = args.batch, 2
+    steps = min(args.allgather_steps, args.steps)
+    d_pk, d_msg, d_sig = inputs
+    eng = pkg.WitnessEngine(n, 32, max_steps=ring, device=dev, n_buffers=2)
+    outs = [eng.new_witness_tensor() for _ in range(ring)]
+    results = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(ring)]
+    chunk = max(1, min(args.allgather_chunk, n))
+    gathered = torch.empty((world * chunk, lay["n_witness"], 6), dtype=torch.int64, device=dev)
+    dig = torch.empty((world * chunk, 2), dtype=torch.int64, device=dev)
+    acc = torch.zeros(2, dtype=torch.int64, device=dev)
+    consumer = torch.cuda.Stream(device=dev)
+    state = {"next": 0}
+
+    def drain():
+        while state["next"] < eng.launched():
+            s = state["next"]
+            eng.wait_step(s, consumer)
+            with torch.cuda.stream(consumer):
+                for c0 in range(0, n, chunk):
+                    part = outs[s % ring][c0:c0 + chunk]
+                    if part.shape[0] == chunk:
+                        g = sharding.all_gather_witness_chunk(part, out=gathered)
+                    else:
+                        g = sharding.all_gather_witness_chunk(part)
+                    d = pkg.witness_digest(g, out=dig[: g.shape[0]], stream=consumer)
+                    acc.add_(d.sum(dim=0))
+            eng.output_consumed(outs[s % ring], consumer)
+            state["next"] += 1
+
+    def run(k_steps):
+        for k in range(k_steps):
+            eng.submit(d_pk, d_sig, d_msg, witness=outs[k % ring], result=results[k % ring])
+            drain()
+        eng.flush()
+        drain()
+        consumer.synchronize()
+        torch.cuda.synchronize()
+
+    run(ring)  # warm-up: communicator, buffers
+    state["next"] = eng.launched()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(steps)
+    dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    eng.close()
+    return float(t.item()), steps, chunk
+
+
+def main():
+    args = parse_args()
+    under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not under_launcher:
+        spawn_ranks(args)  # does not return
+    import numpy as np
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
     dist = None
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:  # launched by torch.distributed.run (also with one rank)
+    if under_launcher:  # launched by torch.distributed.run (also with one rank)
         import torch.distributed as dist
 
         # RCCL prints a version banner on stdout when the communicator is created: keep stdout for the one JSON line
@@ -83,19 +211,23 @@ def main():
             sys.stdout.flush()
             os.dup2(saved, 1)
             os.close(saved)
+        assert dist.get_world_size() == args.gpus
     pkg = importlib.import_module("bls-verify-gadget_amd")
     sharding = importlib.import_module("bls-verify-gadget_amd.sharding")
+    workload = importlib.import_module("bls-verify-gadget_amd.workload")
     pkg.lib()
 
     n = args.batch
-    d_pk, d_msg, d_sig, expect = synth_inputs(pkg, n, 0x5EED + rank, dev)
+    # n DISTINCT instances (16 keys, n uniform messages, every 16th tampered), this rank's block of the
+    # global batch, minted on the GPU by the product's own signer (blsw_sign_batch)
+    d_pk, d_msg, d_sig, expect = workload.make_batch(pkg, n, seed=0x5EED, device=dev, start=rank * n)
     lay = pkg.layout(32)
     # engine: up to `--coalesce` submitted batches are fused into one launch group (fills the SIMDs); witness tensors
     # are written per step, in order, into a ring of `--outputs` output tensors (a consumer would drain them in order)
     out_bytes = n * lay["n_witness"] * 48
     free_b, _ = torch.cuda.mem_get_info(dev)
     n_out = max(1, min(args.outputs, args.steps + args.warmup))
-    coalesce = max(1, min(args.coalesce, args.steps))
+    coalesce = balanced_coalesce(args.steps, max(1, args.coalesce))
     buffers = max(1, min(args.buffers, (args.steps + coalesce - 1) // coalesce))
     # leave >= 25 % of HBM to the runtime (per-queue scratch = stacks of the chain kernels)
     while buffers > 1 and pkg.engine_workspace_bytes(n, 32, coalesce, buffers) + n_out * out_bytes > args.mem_frac * free_b:
@@ -127,17 +259,24 @@ def main():
     dt = time.perf_counter() - t0
 
     # live measurement of the dominant-by-bytes kernel (k_sha_expand): HIP events recorded around it on the stream it
-    # ran on, for every launch of the timed region
-    exp_count, exp_avg = eng.expand_stats()
-    exp_ms = [exp_avg]
+    # ran on, for every launch of the timed region (at most 1024)
+    exp_count, exp_avg_ms = eng.expand_stats()
     res = torch.stack(results)
     ok = bool((res.cpu().numpy().astype(bool) == expect[None, :]).all())
+    gathered_ok = None
     if dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        sharding.all_gather_results(results[0], n * world)  # result shards only (multi-GPU)
+        allres = sharding.all_gather_results(results[0], n * world)  # result shards only (multi-GPU)
+        gathered_ok = bool(allres.numel() == n * world)
+    eng.close()
+    del eng, outs
+    torch.cuda.empty_cache()
 
+    ag = None
+    if dist and args.allgather_steps > 0:
+        ag = allgather_leg(args, pkg, sharding, dist, dev, (d_pk, d_msg, d_sig), lay, world)
     if dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -145,20 +284,23 @@ def main():
         return
     value = n * world * args.steps / dt
     expand_bytes = n * lay["sha_bits"] * 48  # bytes one k_sha_expand launch must write
-    exp_avg_ms = float(np.mean(exp_ms))
-    achieved = expand_bytes / (exp_avg_ms * 1e-3) / 1e9
+    achieved = expand_bytes / (exp_avg_ms * 1e-3) / 1e9 if exp_avg_ms else 0.0
     bytes_per_instance = 48 * (lay["n_witness"] + lay["n_instance_vars"]) + 320
     opc = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_opcount.json")))
-    # HBM bytes per k_sha_expand launch from the PMC passes committed under profiles/ (rocprofv3 refuses to be combined
+    # HBM bytes per k_sha_expand launch from the PMC passes committed under profiles/ (rocprofv3 --pmc cannot be combined
     # with the timed run); only quoted for the workload it was collected on
-    traffic = None
-    try:
-        tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["k_sha_expand"]
-        if tr["instances_per_launch"] == n and lay["msg_len"] == 32:
-            traffic = (tr["write_kib"] + tr["fetch_kib"]) * 1024.0
-    except (OSError, KeyError, ValueError):
-        pass
+    traffic, traffic_source = None, None
+    for name in TRAFFIC_FILES:
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", name)))["k_sha_expand"]
+            if tr["instances_per_launch"] == n and lay["msg_len"] == 32:
+                traffic = (tr["write_kib"] + tr["fetch_kib"]) * 1024.0
+                traffic_source = "profiles/%s (rocprofv3 --pmc WRITE_SIZE and FETCH_SIZE passes of this command, per launch, bytes; FETCH_SIZE doubled as the gfx950 guide prescribes)" % name
+                break
+        except (OSError, KeyError, ValueError):
+            continue
     mad_per_instance = (opc["fp_mul"] + opc["fp_inv"] * FPMUL_PER_INV) * MAD_PER_FPMUL
+    executed_fpmul = opc["fp_mul"] + opc["fp_inv"] * FPMUL_PER_INV_EXECUTED
     mad_peak = pkg.microbench(0, iters=8192, blocks=8192)
     fpmul_peak = pkg.microbench(1, iters=512, blocks=8192)
     out = {
@@ -174,30 +316,30 @@ def main():
         "vs_baseline": None,
         "dtype": "u32 (12 x 32-bit limb Montgomery integers mod the 381-bit BLS12-381 prime; SHA-256 words)",
         "data": "synthetic",
-        "config": {"workload": "configs[1]: batch of 1024 independent BLS-verify instances per GPU per step, 32-byte messages, full witness vectors written",
-                   "instances_per_gpu_per_step": n, "batches_fused_per_launch_group": coalesce, "groups_in_flight": buffers, "output_ring": n_out, "n_witness": lay["n_witness"], "results_ok": ok},
+        "config": {"workload": "configs[1]: batch of 1024 independent BLS-verify instances per GPU per step (1024 distinct messages, 16 keys, every 16th tampered), 32-byte messages, full witness vectors written",
+                   "instances_per_gpu_per_step": n, "batches_fused_per_launch_group": coalesce, "groups_in_flight": buffers, "output_ring": n_out, "n_witness": lay["n_witness"], "results_ok": ok,
+                   "result_shards_gathered": gathered_ok},
         "roofline": {"bound": "hbm", "kernel": "k_sha_expand", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                     "traffic": traffic, "traffic_source": "profiles/r01_pmc_hbm_traffic_final.txt (WRITE_SIZE + FETCH_SIZE per launch, bytes)", "algorithmic_bytes_per_launch": expand_bytes, "avg_launch_ms": exp_avg_ms, "launches_timed": exp_count},
+                     "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": expand_bytes, "avg_launch_ms": exp_avg_ms, "launches_timed": exp_count},
         "roofline_whole_path": {"bound": "hbm", "algorithmic_bytes_per_instance": bytes_per_instance,
                                 "achieved": value / world * bytes_per_instance / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                 "frac": value / world * bytes_per_instance / 1e9 / HBM_PEAK_GBPS},
         "roofline_valu": {"bound": "valu-int32-mad", "algorithmic_mad_per_instance": mad_per_instance, "measured_peak_mad_per_s": mad_peak,
                           "measured_peak_fpmul_per_s": fpmul_peak, "achieved_mad_per_s": value / world * mad_per_instance,
                           "frac": value / world * mad_per_instance / mad_peak},
+        # utilisation, not Fermat-priced throughput: Fp products the kernels actually execute per instance (products of the
+        # op counter + 27 product-times per safegcd inversion) over the measured Fp-product rate of the chip
+        "roofline_valu_executed": {"bound": "valu-fp-mul", "executed_fpmul_per_instance": executed_fpmul, "achieved_fpmul_per_s": value / world * executed_fpmul,
+                                   "measured_peak_fpmul_per_s": fpmul_peak, "frac": value / world * executed_fpmul / fpmul_peak},
     }
+    if ag:
+        ag_dt, ag_steps, ag_chunk = ag
+        out["value_with_allgather"] = n * world * ag_steps / ag_dt
+        out["allgather"] = {"steps": ag_steps, "seconds": ag_dt, "micro_batch_instances_per_rank": ag_chunk, "ring": 2,
+                            "consumer": "blsw_witness_digest over each gathered micro-batch",
+                            "bytes_received_per_gpu_per_step": (world - 1) * n * lay["n_witness"] * 48}
     if not args.no_cpu_baseline:
-        cores = os.cpu_count() or 1
-        threads = min(cores, 16)
-        m = min(args.cpu_sample, n)
-        from tests import oracle_lib  # the CPU restatement: used for this baseline leg only
-
-        oracle = oracle_lib.load()
-        h_pk, h_msg, h_sig = d_pk[:m].cpu().numpy().view(np.uint64), d_msg[:m].cpu().numpy(), d_sig[:m].cpu().numpy().view(np.uint64)
-        t1 = time.perf_counter()
-        oracle.witness_batch(h_pk, h_msg, h_sig, threads=threads, want_digests=False)
-        cdt = time.perf_counter() - t1
-        out["cpu_baseline"] = {"value": m / cdt, "unit": "instances/s", "cores": threads, "kind": "port",
-                               "sample": "%d instances of the same batch through the C++ restatement of the reference path (oracle/), %d threads" % (m, threads)}
+        out["cpu_baseline"] = cpu_baseline(args, d_pk, d_msg, d_sig, n)
     print(json.dumps(out))
 
 

@@ -17,12 +17,17 @@ LIB_PATH = os.path.join(HERE, "libblsw.so")
 FP_BYTES = 48
 _LAYOUT_FIELDS = (
     "msg_len n_instance_vars n_witness sha_bits off_msg off_pk_alloc off_sig_alloc off_pk_not_zero off_expand off_map0 off_map1 "
-    "off_add off_cofactor off_prep_h off_prep_pk off_prep_sig off_miller off_final_exp off_is_one n_keys off_keys off_bitmap off_count off_agg"
+    "off_add off_cofactor off_prep_h off_prep_pk off_prep_sig off_miller off_final_exp off_is_one n_keys off_keys off_bitmap off_count off_agg "
+    "n_pairs stride_msg stride_pk_alloc stride_pk_not_zero stride_hash stride_prep_h stride_prep_pk"
 ).split()
 
 
 class blsw_layout_t(ctypes.Structure):
     _fields_ = [(n, ctypes.c_uint32) for n in _LAYOUT_FIELDS]
+
+
+class blsw_engine_options_t(ctypes.Structure):
+    _fields_ = [("device", ctypes.c_int32)] + [(n, ctypes.c_uint32) for n in "pairing_mode g2_mode expand_store prio_mode place_lds".split()]
 
 
 class BlswError(RuntimeError):
@@ -54,6 +59,16 @@ def lib():
         L.blsw_layout.argtypes = [u32, ctypes.POINTER(blsw_layout_t)]
         L.blsw_engine_workspace_bytes.argtypes = [u64, u32, u32, u32, ctypes.POINTER(u64)]
         L.blsw_engine_create.argtypes = [ctypes.POINTER(vp), u64, u32, u32, u32, vp, u64]
+        L.blsw_engine_create_ex.argtypes = [ctypes.POINTER(vp), u64, u32, u32, u32, ctypes.POINTER(blsw_engine_options_t), vp, u64]
+        L.blsw_engine_options_default.argtypes = [ctypes.POINTER(blsw_engine_options_t)]
+        L.blsw_engine_submitted.argtypes = [vp, ctypes.POINTER(u64)]
+        L.blsw_engine_launched.argtypes = [vp, ctypes.POINTER(u64)]
+        L.blsw_engine_wait_step.argtypes = [vp, u64, vp]
+        L.blsw_engine_output_consumed.argtypes = [vp, vp, vp]
+        L.blsw_witness_digest.argtypes = [vp, u64, u64, u32, vp, vp]
+        L.blsw_layout_multi.argtypes = [u32, u32, ctypes.POINTER(blsw_layout_t)]
+        L.blsw_verify_multi_workspace_bytes.argtypes = [u64, u32, u32, ctypes.POINTER(u64)]
+        L.blsw_verify_multi_batch.argtypes = [vp, vp, u32, u32, vp, u64, vp, u64, vp, vp, u64, vp]
         L.blsw_engine_destroy.argtypes = [vp]
         L.blsw_engine_submit.argtypes = [vp, vp, vp, vp, vp, u64, vp, vp]
         L.blsw_engine_flush.argtypes = [vp, vp]
@@ -70,9 +85,11 @@ def lib():
     return _lib
 
 
-EXPORTED_SYMBOLS = ["blsw_version", "blsw_layout", "blsw_engine_workspace_bytes", "blsw_engine_create", "blsw_engine_destroy", "blsw_engine_submit",
-                    "blsw_engine_flush", "blsw_engine_expand_stats", "blsw_hash_to_g2_workspace_bytes", "blsw_hash_to_g2_batch", "blsw_decode_batch", "blsw_layout_aggregate", "blsw_aggregate_workspace_bytes",
-                    "blsw_aggregate_verify_batch", "blsw_sign_batch", "blsw_microbench"]
+EXPORTED_SYMBOLS = ["blsw_version", "blsw_layout", "blsw_engine_options_default", "blsw_engine_workspace_bytes", "blsw_engine_create", "blsw_engine_create_ex",
+                    "blsw_engine_destroy", "blsw_engine_submit", "blsw_engine_flush", "blsw_engine_submitted", "blsw_engine_launched", "blsw_engine_wait_step",
+                    "blsw_engine_output_consumed", "blsw_engine_expand_stats", "blsw_witness_digest", "blsw_hash_to_g2_workspace_bytes", "blsw_hash_to_g2_batch",
+                    "blsw_decode_batch", "blsw_layout_aggregate", "blsw_aggregate_workspace_bytes", "blsw_aggregate_verify_batch", "blsw_layout_multi",
+                    "blsw_verify_multi_workspace_bytes", "blsw_verify_multi_batch", "blsw_sign_batch", "blsw_microbench"]
 
 
 def layout(msg_len=32):
@@ -100,10 +117,28 @@ def _require_cuda():
     return torch
 
 
-class WitnessEngine:
-    """Thin wrapper of blsw_engine_*: submit batches, flush, read results. max_steps batches are fused per launch group."""
+def engine_options(**overrides):
+    """blsw_engine_options_default (BLSW_* environment overrides applied there) with keyword overrides:
+    device, pairing_mode ("team"/"lane" or 0/1), g2_mode ("lane"/"team" or 0/1), expand_store, prio_mode, place_lds."""
+    o = blsw_engine_options_t()
+    rc = lib().blsw_engine_options_default(ctypes.byref(o))
+    if rc:
+        raise BlswError("blsw_engine_options_default failed: %d" % rc)
+    names = {"pairing_mode": {"team": 0, "lane": 1}, "g2_mode": {"lane": 0, "team": 1}}
+    for k, v in overrides.items():
+        if v is None:
+            continue
+        if not hasattr(o, k):
+            raise BlswError("unknown engine option %r" % k)
+        setattr(o, k, names.get(k, {}).get(v, v))
+    return o
 
-    def __init__(self, n, msg_len=32, max_steps=1, device=None, n_buffers=None):
+
+class WitnessEngine:
+    """Thin wrapper of blsw_engine_*: submit batches, flush, read results. max_steps batches are fused per launch group.
+    Streaming consumers use the step numbers returned by submit(): wait_step(seq) / output_consumed(tensor)."""
+
+    def __init__(self, n, msg_len=32, max_steps=1, device=None, n_buffers=None, **options):
         torch = _require_cuda()
         self.torch = torch
         self.n, self.msg_len, self.max_steps = int(n), int(msg_len), int(max_steps)
@@ -113,10 +148,13 @@ class WitnessEngine:
         self.n_witness = self.layout["n_witness"]
         self.workspace = torch.empty(engine_workspace_bytes(self.n, msg_len, self.max_steps, self.n_buffers), dtype=torch.uint8, device=self.device)
         self._e = ctypes.c_void_p()
-        with torch.cuda.device(self.device):
-            rc = lib().blsw_engine_create(ctypes.byref(self._e), self.n, self.msg_len, self.max_steps, self.n_buffers, self.workspace.data_ptr(), self.workspace.numel())
+        opt = engine_options(**options)
+        opt.device = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        rc = lib().blsw_engine_create_ex(ctypes.byref(self._e), self.n, self.msg_len, self.max_steps, self.n_buffers, ctypes.byref(opt), self.workspace.data_ptr(),
+                                         self.workspace.numel())
         if rc:
-            raise BlswError("blsw_engine_create failed: %d" % rc)
+            self._e = None
+            raise BlswError("blsw_engine_create_ex failed: %d" % rc)
         self._keep = []
 
     def close(self):
@@ -133,27 +171,58 @@ class WitnessEngine:
     def new_witness_tensor(self):
         return self.torch.empty((self.n, self.n_witness, 6), dtype=self.torch.int64, device=self.device)
 
+    def _stream(self, stream):
+        return (stream if stream is not None else self.torch.cuda.current_stream(self.device)).cuda_stream
+
     def submit(self, pk_xy, sig_xy, msg, witness=None, result=None, stream=None):
-        torch = self.torch
+        """-> step number (0, 1, 2, ... in submission order)"""
         assert pk_xy.is_cuda and sig_xy.is_cuda and msg.is_cuda
         assert pk_xy.shape == (self.n, 12) and sig_xy.shape == (self.n, 24) and msg.shape == (self.n, self.msg_len)
         assert pk_xy.is_contiguous() and sig_xy.is_contiguous() and msg.is_contiguous()
         if witness is not None:
             assert witness.is_contiguous() and witness.shape[0] == self.n and witness.shape[1] >= self.n_witness
-        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        if result is not None:
+            assert result.is_contiguous() and result.numel() >= self.n
+        seq = self.submitted()
         rc = lib().blsw_engine_submit(self._e, pk_xy.data_ptr(), sig_xy.data_ptr(), msg.data_ptr() if self.msg_len else None,
                                       witness.data_ptr() if witness is not None else None, witness.shape[1] if witness is not None else 0,
-                                      result.data_ptr() if result is not None else None, s.cuda_stream)
+                                      result.data_ptr() if result is not None else None, self._stream(stream))
         if rc:
             raise BlswError("blsw_engine_submit failed: %d" % rc)
         self._keep.append((pk_xy, sig_xy, msg, witness, result))
+        self._keep = self._keep[-(self.n_buffers + 1) * self.max_steps:]
+        return seq
 
     def flush(self, stream=None):
-        s = stream if stream is not None else self.torch.cuda.current_stream(self.device)
-        rc = lib().blsw_engine_flush(self._e, s.cuda_stream)
+        rc = lib().blsw_engine_flush(self._e, self._stream(stream))
         if rc:
             raise BlswError("blsw_engine_flush failed: %d" % rc)
-        self._keep = self._keep[-(self.n_buffers + 1) * self.max_steps:]
+
+    def _counter(self, fn):
+        v = ctypes.c_uint64(0)
+        rc = fn(self._e, ctypes.byref(v))
+        if rc:
+            raise BlswError("engine counter failed: %d" % rc)
+        return v.value
+
+    def submitted(self):
+        return self._counter(lib().blsw_engine_submitted)
+
+    def launched(self):
+        return self._counter(lib().blsw_engine_launched)
+
+    def wait_step(self, seq, stream=None):
+        """Makes `stream` (default: the current stream) wait for step `seq`'s witness tensor and results (seq < launched())."""
+        rc = lib().blsw_engine_wait_step(self._e, seq, self._stream(stream))
+        if rc:
+            raise BlswError("blsw_engine_wait_step failed: %d" % rc)
+
+    def output_consumed(self, witness, stream=None):
+        """The consumer is done with `witness` once `stream` reaches this point: the next step submitted with the same tensor
+        does not overwrite it earlier."""
+        rc = lib().blsw_engine_output_consumed(self._e, witness.data_ptr(), self._stream(stream))
+        if rc:
+            raise BlswError("blsw_engine_output_consumed failed: %d" % rc)
 
     def expand_stats(self):
         """(number of k_sha_expand launches since the last call, their average duration in ms); synchronises with them."""
@@ -196,8 +265,8 @@ class SignatureVar:
 class BlsSignatureVerifyGadget:
     """Batched counterpart of constraints.rs:79-128. One call = n independent circuits (direct mode engine, one batch)."""
 
-    def __init__(self, n, msg_len=32, device=None, want_witness=True, max_steps=1):
-        self.engine = WitnessEngine(n, msg_len, max_steps=max_steps, device=device)
+    def __init__(self, n, msg_len=32, device=None, want_witness=True, max_steps=1, **options):
+        self.engine = WitnessEngine(n, msg_len, max_steps=max_steps, device=device, **options)
         torch = self.engine.torch
         self.torch = torch
         self.n, self.msg_len, self.device = self.engine.n, self.engine.msg_len, self.engine.device
@@ -259,7 +328,7 @@ def aggregate_verify(parameters, public_keys, bitmap, message, signature, want_w
     bitmap [n, K] uint8 (0/1), message [n, msg_len] uint8, signature.xy [n, 24]. Returns (result int32 [n], count int32 [n], witness)."""
     torch = _require_cuda()
     assert isinstance(parameters, ParametersVar)
-    pks, sig = public_keys.xy, signature.xy
+    pks, sig, bitmap, message = public_keys.xy.contiguous(), signature.xy.contiguous(), bitmap.contiguous(), message.contiguous()
     n, K = pks.shape[0], pks.shape[1]
     assert K >= 1 and bitmap.shape == (n, K)  # constraints.rs:160-162: equal lengths, at least one key
     msg_len = message.shape[1]
@@ -271,13 +340,85 @@ def aggregate_verify(parameters, public_keys, bitmap, message, signature, want_w
     res = torch.empty(n, dtype=torch.int32, device=dev)
     cnt = torch.empty(n, dtype=torch.int32, device=dev)
     wit = torch.empty((n, lay["n_witness"], 6), dtype=torch.int64, device=dev) if want_witness else None
-    rc = lib().blsw_aggregate_verify_batch(pks.contiguous().data_ptr(), bitmap.contiguous().data_ptr(), K, sig.data_ptr(), message.data_ptr(), msg_len, n,
+    assert sig.shape == (n, 24) and message.shape[0] == n
+    rc = lib().blsw_aggregate_verify_batch(pks.data_ptr(), bitmap.data_ptr(), K, sig.data_ptr(), message.data_ptr(), msg_len, n,
                                            wit.data_ptr() if wit is not None else None, lay["n_witness"], res.data_ptr(), cnt.data_ptr(), ws.data_ptr(),
                                            ws.numel(), torch.cuda.current_stream(dev).cuda_stream)
     if rc:
         raise BlswError("blsw_aggregate_verify_batch failed: %d" % rc)
     torch.cuda.synchronize(dev)
     return res, cnt, wit
+
+
+def layout_multi(msg_len, n_pairs):
+    L = blsw_layout_t()
+    rc = lib().blsw_layout_multi(msg_len, n_pairs, ctypes.byref(L))
+    if rc:
+        raise BlswError("blsw_layout_multi failed: %d" % rc)
+    return {n: getattr(L, n) for n in _LAYOUT_FIELDS}
+
+
+def verify_multi(parameters, public_keys, messages, signature, want_witness=True):
+    """N+1-pair product of pairings: one signature over K (pk_j, msg_j) pairs per instance, i.e. constraints.rs:90-128 with
+    product_of_pairings over slices of K + 1 prepared points. public_keys.xy [n, K, 12] int64, messages [n, K, msg_len] uint8,
+    signature.xy [n, 24]. Returns (result int32 [n], witness [n, n_witness, 6] int64 or None)."""
+    torch = _require_cuda()
+    assert isinstance(parameters, ParametersVar)
+    pks, sig, messages = public_keys.xy.contiguous(), signature.xy.contiguous(), messages.contiguous()
+    n, K = pks.shape[0], pks.shape[1]
+    assert K >= 1 and messages.shape[:2] == (n, K) and sig.shape == (n, 24) and pks.shape == (n, K, 12)
+    msg_len = messages.shape[2]
+    lay = layout_multi(msg_len, K)
+    wb = ctypes.c_uint64(0)
+    rc = lib().blsw_verify_multi_workspace_bytes(n, msg_len, K, ctypes.byref(wb))
+    if rc:
+        raise BlswError("blsw_verify_multi_workspace_bytes failed: %d" % rc)
+    dev = pks.device
+    ws = torch.empty(wb.value, dtype=torch.uint8, device=dev)
+    res = torch.empty(n, dtype=torch.int32, device=dev)
+    wit = torch.empty((n, lay["n_witness"], 6), dtype=torch.int64, device=dev) if want_witness else None
+    rc = lib().blsw_verify_multi_batch(pks.data_ptr(), messages.data_ptr() if msg_len else None, msg_len, K, sig.data_ptr(), n, wit.data_ptr() if wit is not None else None,
+                                       lay["n_witness"], res.data_ptr(), ws.data_ptr(), ws.numel(), torch.cuda.current_stream(dev).cuda_stream)
+    if rc:
+        raise BlswError("blsw_verify_multi_batch failed: %d" % rc)
+    torch.cuda.synchronize(dev)
+    return res, wit
+
+
+DIGEST_C = (0x9E3779B97F4A7C15, 0xC2B2AE3D27D4EB4F)
+
+
+def witness_digest(witness, n_witness=None, out=None, stream=None):
+    """blsw_witness_digest: [n, stride, 6] int64 cuda tensor -> [n, 2] int64 (two u64 sums, see include/blsw.h)."""
+    torch = _require_cuda()
+    assert witness.is_cuda and witness.is_contiguous() and witness.dim() == 3 and witness.shape[2] == 6
+    n, stride = witness.shape[0], witness.shape[1]
+    if out is None:
+        out = torch.empty((n, 2), dtype=torch.int64, device=witness.device)
+    s = stream if stream is not None else torch.cuda.current_stream(witness.device)
+    rc = lib().blsw_witness_digest(witness.data_ptr(), stride, n, n_witness if n_witness is not None else stride, out.data_ptr(), s.cuda_stream)
+    if rc:
+        raise BlswError("blsw_witness_digest failed: %d" % rc)
+    return out
+
+
+def witness_digest_reference(words):
+    """The same digest in numpy (host-side definition used by consumers / tests): `words` = the instance's u64 words."""
+    import numpy as np
+
+    w = np.ascontiguousarray(words, dtype=np.uint64).reshape(-1)
+    k = np.arange(1, w.size + 1, dtype=np.uint64)
+    out = []
+    with np.errstate(over="ignore"):
+        for c in DIGEST_C:
+            z = w + k * np.uint64(c)
+            z ^= z >> np.uint64(30)
+            z *= np.uint64(0xBF58476D1CE4E5B9)
+            z ^= z >> np.uint64(27)
+            z *= np.uint64(0x94D049BB133111EB)
+            z ^= z >> np.uint64(31)
+            out.append(int(z.sum(dtype=np.uint64)))
+    return out
 
 
 def microbench(which, iters=4096, blocks=4096):

@@ -478,6 +478,29 @@ BLSW_FN Fp12 chain_miller(Emitter e, const Fp& pkx, const Fp& pky, const C& coef
     }
     return fp12_conj(f);
 }
+// miller_loop over K + 1 pairs, single-lane statement of team_miller_multi: P::pk(j, x, y) = prepare_g1(pk_j),
+// P::coeff_h(j) = line coefficients of prepare_g2(H(m_j))
+template <class C, class P>
+BLSW_FN Fp12 chain_miller_multi(Emitter e, uint32_t K, const P& pairs, const C& coeff_sig) {
+    Fp12 f = fp12_one();
+    uint32_t k = 0;
+#pragma unroll 1
+    for (int i = 62; i >= 0; i--) {
+        const int reps = ((BLSW_X_ABS >> i) & 1) ? 2 : 1;
+        for (int rep = 0; rep < reps; rep++) {
+            bool first = (i == 62 && rep == 0);
+            if (rep == 0 && i != 62) f = fp12_sqr_w(e, f);
+            f = ell_const_p_w(e, f, coeff_sig, k, first);
+            for (uint32_t j = 0; j < K; j++) {
+                Fp px, py;
+                pairs.pk(j, px, py);
+                f = ell_var_p_w(e, f, pairs.coeff_h(j), k, px, py);
+            }
+            k++;
+        }
+    }
+    return fp12_conj(f);
+}
 // final_exponentiation . is_one
 BLSW_FN bool chain_final_exp_is_one(Emitter e_fe, Emitter e_one, const Fp12& f) {
     // final exponentiation

@@ -23,7 +23,9 @@ struct Workspace {
     Fp* q;           // [12][N]  Q0 (x.c0,x.c1,y.c0,y.c1,z.c0,z.c1), Q1
     Fp* h;           // [6][N]   H(m) projective
     Fp* pkaff;       // [2][N]   prepare_g1(pk)
-    Fp* coeff;       // [2][272][N]  line coefficients: 0 = H(m), 1 = sig
+    Fp* coeff_h;     // [272][N]      line coefficients of prepare_g2(H(m))
+    Fp* coeff_sig;   // [272][n_sig]  line coefficients of prepare_g2(sig)
+    uint64_t n_sig;  // = N for the single-key circuit; = instances (not pairs) for the N+1-pair product
     Fp* staging;     // [N/64][split_row][64] field witnesses (engine mode), or nullptr (direct mode): each wave of 64
                      // instances owns one contiguous tile and appends 3 KiB rows to it (sequential HBM writes per wave)
     uint64_t staging_rows;
@@ -34,18 +36,30 @@ struct Workspace {
     uint64_t total_bytes;
 };
 inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
-// pairing segment: six lanes per instance (default) or the single-lane chain (BLSW_PAIRING=lane, kept for A/B runs)
-static bool pairing_team_mode() {
-    static int mode = -1;
-    if (mode < 0) {
-        const char* s = getenv("BLSW_PAIRING");
-        mode = (s && s[0] == 'l') ? 0 : 1;
+// kernel variants, fixed per engine at creation (blsw_engine_options_t)
+struct Modes {
+    bool pairing_team;  // pairing segment: six lanes per instance (default) or the single-lane chain (kept for A/B runs)
+    bool g2_team;       // G2 allocation on the six-lane machinery: its segment is staged instance-major like the pairing rows,
+                        // so it moves to the end of the staging coordinates
+};
+constexpr Modes DEFAULT_MODES = {true, false};
+inline blsw_layout_t staging_layout(const blsw_layout_t& L, const Modes& m) {
+    blsw_layout_t S = L;
+    uint32_t* f = &S.off_msg;
+    const uint32_t* g = &L.off_msg;
+    for (int k = 0; k < 15; k++) f[k] = g[k] > L.off_expand ? g[k] - L.sha_bits : g[k];
+    if (m.g2_team) {
+        const uint32_t lo = L.off_sig_alloc, len = L.off_pk_not_zero - L.off_sig_alloc;
+        for (int k = 0; k < 15; k++)
+            if (f[k] > lo) f[k] -= len;
+        S.off_sig_alloc = L.n_witness - L.sha_bits - len;  // last rows of the staging coordinates
     }
-    return mode == 1;
+    return S;
 }
-inline blsw_layout_t staging_layout(const blsw_layout_t& L);
-Workspace carve(void* base, uint64_t N, const blsw_layout_t& L, bool with_staging) {
+// N lanes of per-(pk, msg) work, n_sig lanes of per-signature work (n_sig = N except for the N+1-pair product)
+Workspace carve(void* base, uint64_t N, const blsw_layout_t& L, bool with_staging, const Modes& m, uint64_t n_sig = 0) {
     Workspace w;
+    if (n_sig == 0) n_sig = N;
     w.sha_words = (L.sha_bits + 31) / 32 + 1;
     uint64_t off = 0;
     auto take = [&](uint64_t bytes) {
@@ -58,9 +72,11 @@ Workspace carve(void* base, uint64_t N, const blsw_layout_t& L, bool with_stagin
     w.q = reinterpret_cast<Fp*>(take(12 * N * sizeof(Fp)));
     w.h = reinterpret_cast<Fp*>(take(6 * N * sizeof(Fp)));
     w.pkaff = reinterpret_cast<Fp*>(take(2 * N * sizeof(Fp)));
-    w.coeff = reinterpret_cast<Fp*>(take(2ull * 272 * N * sizeof(Fp)));
+    w.coeff_h = reinterpret_cast<Fp*>(take(272ull * N * sizeof(Fp)));
+    w.coeff_sig = reinterpret_cast<Fp*>(take(272ull * n_sig * sizeof(Fp)));
+    w.n_sig = n_sig;
     w.staging_rows = L.n_witness - L.sha_bits;
-    w.split_row = pairing_team_mode() ? staging_layout(L).off_miller : (uint32_t)w.staging_rows;
+    w.split_row = m.pairing_team ? staging_layout(L, m).off_miller : (uint32_t)w.staging_rows;
     w.pair_rows = (uint32_t)w.staging_rows - w.split_row;
     w.staging = with_staging ? reinterpret_cast<Fp*>(take((uint64_t)w.split_row * align_up(N, 64) * sizeof(Fp))) : nullptr;
     w.pair = with_staging && w.pair_rows ? reinterpret_cast<Fp*>(take((uint64_t)w.pair_rows * N * sizeof(Fp))) : nullptr;
@@ -81,10 +97,12 @@ struct StepDesc {
     const uint8_t* bitmap;  // [n][n_keys]
     uint32_t* count;        // [n]
 };
-// a group of `steps` batches of n instances each, processed by one set of launches (N = steps * n lanes per chain)
+// a group of `steps` batches of n instances each, processed by one set of launches (N = steps * n * K lanes per chain;
+// K = (pk, msg) pairs per instance: 1 except for the N+1-pair product)
 struct Group {
     uint64_t N;
-    uint32_t n;
+    uint32_t n;   // instances per step
+    uint32_t K;   // pairs per instance
     uint32_t msg_len;
     const StepDesc* desc;  // device array [steps]
     blsw_layout_t L;       // offsets in the witness vector
@@ -92,29 +110,6 @@ struct Group {
     Workspace ws;
     int chain_prio;        // chain waves raise s_setprio
 };
-// G2 allocation on the six-lane machinery (BLSW_G2=team; needs the six-lane pairing mode): its segment is staged
-// instance-major like the pairing rows, so it moves to the end of the staging coordinates
-static bool g2_team_mode() {
-    static int mode = -1;
-    if (mode < 0) {
-        const char* s = getenv("BLSW_G2");
-        mode = (s && s[0] == 't' && pairing_team_mode()) ? 1 : 0;
-    }
-    return mode == 1;
-}
-inline blsw_layout_t staging_layout(const blsw_layout_t& L) {
-    blsw_layout_t S = L;
-    uint32_t* f = &S.off_msg;
-    const uint32_t* g = &L.off_msg;
-    for (int k = 0; k < 15; k++) f[k] = g[k] > L.off_expand ? g[k] - L.sha_bits : g[k];
-    if (g2_team_mode()) {
-        const uint32_t lo = L.off_sig_alloc, len = L.off_pk_not_zero - L.off_sig_alloc;
-        for (int k = 0; k < 15; k++)
-            if (f[k] > lo) f[k] -= len;
-        S.off_sig_alloc = L.n_witness - L.sha_bits - len;  // last rows of the staging coordinates
-    }
-    return S;
-}
 
 __device__ __forceinline__ Fp ld_fp(const Fp* p) {
     const uint4* s = reinterpret_cast<const uint4*>(p);
@@ -133,16 +128,19 @@ __device__ __forceinline__ void st_fp(Fp* p, const Fp& v) {
 }
 __device__ __forceinline__ Fp2 ld_fp2(const Fp* p, uint64_t n) { return {ld_fp(p), ld_fp(p + n)}; }
 
-// lane -> (step, instance-in-step)
+// lane -> (step, instance-in-step, pair). Inputs of per-pair work are indexed by f (flat [n][K]), outputs by (i, j).
 struct LaneId {
     uint64_t I;
-    uint32_t s, i;
+    uint32_t s, i, j, f;
 };
 __device__ __forceinline__ LaneId lane_id(const Group& g, uint64_t I) {
     LaneId r;
     r.I = I;
-    r.s = (uint32_t)(I / g.n);
-    r.i = (uint32_t)(I - (uint64_t)r.s * g.n);
+    const uint32_t nk = g.n * g.K;
+    r.s = (uint32_t)(I / nk);
+    r.f = (uint32_t)(I - (uint64_t)r.s * nk);
+    r.i = g.K == 1 ? r.f : r.f / g.K;
+    r.j = g.K == 1 ? 0u : r.f - r.i * g.K;
     return r;
 }
 // witness cursor for a segment: staging row (engine mode), the instance's dense vector (direct mode), or value-only
@@ -167,6 +165,8 @@ __device__ __forceinline__ Emitter emitter(const Group& g, const LaneId& id, uin
     return e;
 }
 #define EMIT(g, id, field) emitter(g, id, (g).L.field, (g).LS.field)
+// segment that exists once per pair: pair j's copy starts j * stride further (staged groups always have K = 1)
+#define EMITJ(g, id, field, stride) emitter(g, id, (g).L.field + (id).j * (g).L.stride, (g).LS.field + (id).j * (g).L.stride)
 
 // ---------------------------------------------------------------- kernels (one instance per lane)
 // SHA-256 witness bits of expand_message (+ the message bits themselves)
@@ -175,9 +175,9 @@ __global__ __launch_bounds__(64) void k_sha(Group g, int want_bits, int write_u)
     uint64_t I = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (I >= g.N) return;
     LaneId id = lane_id(g, I);
-    const uint8_t* msg = g.desc[id.s].msg + (uint64_t)id.i * g.msg_len;
+    const uint8_t* msg = g.desc[id.s].msg + (uint64_t)id.f * g.msg_len;
     // UInt8::new_witness_vec(msg): 8 booleans per byte, little-endian
-    Emitter em = EMIT(g, id, off_msg);
+    Emitter em = EMITJ(g, id, off_msg, stride_msg);
     for (uint32_t k = 0; k < g.msg_len; k++) {
         uint32_t b = msg[k];
         for (int j = 0; j < 8; j++) em.put_bool((b >> j) & 1);
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(64) void k_sha_values(Group g) {
     if (I >= g.N) return;
     LaneId id = lane_id(g, I);
     uint32_t uw[64];
-    expand_message_values(g.desc[id.s].msg + (uint64_t)id.i * g.msg_len, g.msg_len, uw);
+    expand_message_values(g.desc[id.s].msg + (uint64_t)id.f * g.msg_len, g.msg_len, uw);
     for (int j = 0; j < 4; j++) st_fp(g.ws.u + (uint64_t)j * g.N + I, hash_to_field_elem(uw + 16 * j));
 }
 
@@ -218,11 +218,13 @@ __global__ __launch_bounds__(64) void k_sha_values(Group g) {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 template <int NT>
 __global__ __launch_bounds__(BLSW_EXPAND_THREADS) void k_sha_expand(const uint32_t* __restrict__ bits, uint64_t sha_words, uint64_t first, uint32_t sha_bits,
-                                                    uint32_t off_expand, uint64_t* __restrict__ d_witness, uint64_t stride) {
+                                                    uint32_t off_expand, uint64_t* __restrict__ d_witness, uint64_t stride, uint32_t K, uint32_t stride_hash) {
     constexpr uint32_t R1[12] = BLSW_R1_LIMBS;
-    const uint64_t inst = blockIdx.y;
-    uint4* out = reinterpret_cast<uint4*>(d_witness + (inst * stride + off_expand) * 6);
-    const uint64_t lane = first + inst;
+    // blockIdx.y = flat (instance, pair) index of the step; K = 1 for the single-key circuit
+    const uint64_t inst = K == 1 ? blockIdx.y : blockIdx.y / K;
+    const uint32_t pair = K == 1 ? 0u : blockIdx.y - (uint32_t)inst * K;
+    uint4* out = reinterpret_cast<uint4*>(d_witness + (inst * stride + off_expand + (uint64_t)pair * stride_hash) * 6);
+    const uint64_t lane = first + blockIdx.y;
     const uint32_t* b = bits + (lane >> 6) * sha_words * 64 + (lane & 63);
     // The segment is a stream of 16-byte pieces (piece p = element p / 3, column p % 3) that starts at an arbitrary multiple
     // of 16 bytes (instance vectors are 33 956 496 bytes apart). Pieces are assigned from the first 256-byte boundary on
@@ -312,8 +314,9 @@ __global__ __launch_bounds__(64) void k_g1(Group g) {
     uint64_t I = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (I >= g.N) return;
     LaneId id = lane_id(g, I);
-    const Fp* p = reinterpret_cast<const Fp*>(g.desc[id.s].pk + (uint64_t)id.i * 12);
-    G1ChainOut o = chain_g1_alloc(EMIT(g, id, off_pk_alloc), EMIT(g, id, off_pk_not_zero), EMIT(g, id, off_prep_pk), ld_fp(p), ld_fp(p + 1));
+    const Fp* p = reinterpret_cast<const Fp*>(g.desc[id.s].pk + (uint64_t)id.f * 12);
+    G1ChainOut o = chain_g1_alloc(EMITJ(g, id, off_pk_alloc, stride_pk_alloc), EMITJ(g, id, off_pk_not_zero, stride_pk_not_zero),
+                                  EMITJ(g, id, off_prep_pk, stride_prep_pk), ld_fp(p), ld_fp(p + 1));
     st_fp(g.ws.pkaff + I, o.ax);
     st_fp(g.ws.pkaff + g.N + I, o.ay);
 }
@@ -381,7 +384,7 @@ __global__ __launch_bounds__(64) void k_map(Group g) {
     LaneId id = lane_id(g, I);
     const uint64_t N = g.N;
     Fp2 u = ld_fp2(g.ws.u + (uint64_t)(2 * which) * N + I, N);
-    Proj<OpsFp2> q = chain_map_to_curve(which ? EMIT(g, id, off_map1) : EMIT(g, id, off_map0), u);
+    Proj<OpsFp2> q = chain_map_to_curve(which ? EMITJ(g, id, off_map1, stride_hash) : EMITJ(g, id, off_map0, stride_hash), u);
     Fp* o = g.ws.q + (uint64_t)(6 * which) * N + I;
     st_fp(o, q.x.c0);
     st_fp(o + N, q.x.c1);
@@ -405,7 +408,7 @@ __global__ __launch_bounds__(64) void k_cofactor(Group g) {
     LaneId id = lane_id(g, I);
     const uint64_t N = g.N;
     Proj<OpsFp2> q0 = ld_proj2(g.ws.q + I, N), q1 = ld_proj2(g.ws.q + 6 * N + I, N);
-    Proj<OpsFp2> h = chain_cofactor(EMIT(g, id, off_add), EMIT(g, id, off_cofactor), q0, q1);
+    Proj<OpsFp2> h = chain_cofactor(EMITJ(g, id, off_add, stride_hash), EMITJ(g, id, off_cofactor, stride_hash), q0, q1);
     Fp* o = g.ws.h + I;
     st_fp(o, h.x.c0);
     st_fp(o + N, h.x.c1);
@@ -440,8 +443,8 @@ __global__ __launch_bounds__(64) void k_prepare(Group g, int which) {
         q.y = inf ? fp2_one() : sy;
         q.z = inf ? fp2_zero() : fp2_one();
     }
-    CoeffStrided out = {g.ws.coeff + (uint64_t)which * 272 * N + I, N};
-    chain_prepare_g2(which == 0 ? EMIT(g, id, off_prep_h) : EMIT(g, id, off_prep_sig), q, out);
+    CoeffStrided out = which == 0 ? CoeffStrided{g.ws.coeff_h + I, N} : CoeffStrided{g.ws.coeff_sig + I, g.ws.n_sig};
+    chain_prepare_g2(which == 0 ? EMITJ(g, id, off_prep_h, stride_prep_h) : EMIT(g, id, off_prep_sig), q, out);
 }
 
 // Miller loop + final exponentiation + is_one
@@ -452,8 +455,8 @@ __global__ __launch_bounds__(64) void k_pairing(Group g) {
     LaneId id = lane_id(g, I);
     const uint64_t N = g.N;
     Fp pkx = ld_fp(g.ws.pkaff + I), pky = ld_fp(g.ws.pkaff + N + I);
-    CoeffStrided ch = {g.ws.coeff + I, N};
-    CoeffStrided cs = {g.ws.coeff + 272ull * N + I, N};
+    CoeffStrided ch = {g.ws.coeff_h + I, N};
+    CoeffStrided cs = {g.ws.coeff_sig + I, g.ws.n_sig};
     Fp12 f = chain_miller(EMIT(g, id, off_miller), pkx, pky, cs, ch);
     bool res = chain_final_exp_is_one(EMIT(g, id, off_final_exp), EMIT(g, id, off_is_one), f);
     int32_t* r = g.desc[id.s].result;
@@ -475,8 +478,8 @@ __global__ __launch_bounds__(64) void k_pairing_team(Group g) {
     t.slots = lds + (active ? team : 0) * TS_NSLOTS;
     t.j = j;
     t.active = active;
-    t.coeff_h = {g.ws.coeff + I, N};
-    t.coeff_sig = {g.ws.coeff + 272ull * N + I, N};
+    t.coeff_h = {g.ws.coeff_h + I, N};
+    t.coeff_sig = {g.ws.coeff_sig + I, g.ws.n_sig};
     t.e = EMIT(g, id, off_miller);
     if (!active) t.e.base = nullptr;
     t.set_consts(ld_fp(g.ws.pkaff + I), ld_fp(g.ws.pkaff + N + I));
@@ -523,11 +526,98 @@ __global__ __launch_bounds__(64) void k_g2_alloc_team(Group g) {
     (void)team_g2_mul_bits(t, mine, RM1, BLSW_RM1_NBITS);
     if (active && j == 0) chain_g2_alloc_tail(t.e, ge);
 }
-static void launch_pairing(const Group& g, hipStream_t st) {
-    if (!pairing_team_mode())
+// N+1-pair product (blsw_verify_multi_batch): one team per instance, K pairs per instance. `gs` is the per-signature view
+// (N = instances), the per-pair values (prepare_g1(pk_j), line coefficients of H(m_j)) live at flat index I * K + j of the
+// per-pair launch of n_h = N * K lanes.
+struct TeamLanesMulti : TeamLanes<CoeffStrided> {
+    const Fp* coeff_h_all;
+    const Fp* pkaff;
+    uint64_t n_h, flat0;
+    BLSW_TEAM_DEV void load_coeff_sig(uint32_t k) {
+        if (active) team_load_coeff_sig_lane(j, slots, coeff_sig, k);
+        team_sync();
+    }
+    BLSW_TEAM_DEV void load_pair(uint32_t jp, uint32_t k) {
+        if (active) {
+            const uint64_t t = flat0 + jp;
+            Fp px = fp_zero(), py = fp_zero();
+            if (j == 5) px = ld_fp(pkaff + t);
+            if (j == 4) py = ld_fp(pkaff + n_h + t);
+            team_load_pair_lane(j, slots, CoeffStrided{const_cast<Fp*>(coeff_h_all) + t, n_h}, k, px, py);
+        }
+        team_sync();
+    }
+};
+__global__ __launch_bounds__(64) void k_pairing_team_multi(Group gs, uint32_t K, uint64_t n_h) {
+    __shared__ Fp2 lds[BLSW_TEAMS_PER_WAVE * TS_NSLOTS];
+    const uint32_t team = threadIdx.x / 6, j = threadIdx.x % 6;
+    const uint64_t I0 = (uint64_t)blockIdx.x * BLSW_TEAMS_PER_WAVE + team;
+    const bool active = team < BLSW_TEAMS_PER_WAVE && I0 < gs.N;
+    const uint64_t I = active ? I0 : 0;
+    LaneId id = lane_id(gs, I);
+    TeamLanesMulti t;
+    t.slots = lds + (active ? team : 0) * TS_NSLOTS;
+    t.j = j;
+    t.active = active;
+    t.coeff_h = {nullptr, 0};
+    t.coeff_sig = {gs.ws.coeff_sig + I, gs.ws.n_sig};
+    t.coeff_h_all = gs.ws.coeff_h;
+    t.pkaff = gs.ws.pkaff;
+    t.n_h = n_h;
+    t.flat0 = I * K;
+    t.e = EMIT(gs, id, off_miller);
+    if (!active) t.e.base = nullptr;
+    if (active && j == 0) team_st(t.slots, TS_XYC, {K_G1_GEN_NEG_Y(), fp_zero()});
+    team_sync();
+    Fp2 f = team_miller_multi(t, K);
+    Emitter e_one = EMIT(gs, id, off_is_one);
+    if (!active) e_one.base = nullptr;
+    bool res = team_final_exp_is_one(t, f, e_one);
+    int32_t* r = gs.desc[id.s].result;
+    if (active && j == 0 && r) r[id.i] = res ? 1 : 0;
+}
+static void launch_pairing(const Group& g, const Modes& m, hipStream_t st) {
+    if (!m.pairing_team)
         hipLaunchKernelGGL(k_pairing, dim3((unsigned)((g.N + 63) / 64)), dim3(64), 0, st, g);
     else
         hipLaunchKernelGGL(k_pairing_team, dim3((unsigned)((g.N + BLSW_TEAMS_PER_WAVE - 1) / BLSW_TEAMS_PER_WAVE)), dim3(64), 0, st, g);
+}
+
+// Digest of witness vectors (blsw_witness_digest): d[c] = sum_k mix64(w_k + (k + 1) * C_c) over the instance's u64 words.
+// grid (chunks, n); 256 threads, each 16 bytes per iteration; block partial sums -> two atomics per block.
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z ^= z >> 30;
+    z *= 0xbf58476d1ce4e5b9ull;
+    z ^= z >> 27;
+    z *= 0x94d049bb133111ebull;
+    z ^= z >> 31;
+    return z;
+}
+#define BLSW_DIGEST_ITERS 16
+__global__ __launch_bounds__(256) void k_digest(const uint64_t* __restrict__ w, uint64_t stride, uint64_t n_words, uint64_t* __restrict__ digest) {
+    const uint64_t inst = blockIdx.y;
+    const ulonglong2* src = reinterpret_cast<const ulonglong2*>(w + inst * stride * 6);
+    const uint64_t n_pairs = n_words / 2;  // n_witness * 6 is even
+    uint64_t q = ((uint64_t)blockIdx.x * BLSW_DIGEST_ITERS) * 256 + threadIdx.x;
+    uint64_t d0 = 0, d1 = 0;
+#pragma unroll 4
+    for (int it = 0; it < BLSW_DIGEST_ITERS; it++, q += 256) {
+        if (q < n_pairs) {
+            ulonglong2 v = src[q];
+            const uint64_t k = 2 * q + 1;  // (index of v.x) + 1
+            d0 += mix64(v.x + k * 0x9E3779B97F4A7C15ull) + mix64(v.y + (k + 1) * 0x9E3779B97F4A7C15ull);
+            d1 += mix64(v.x + k * 0xC2B2AE3D27D4EB4Full) + mix64(v.y + (k + 1) * 0xC2B2AE3D27D4EB4Full);
+        }
+    }
+    // wave reduction, then one atomic pair per wave
+    for (int off = 32; off > 0; off >>= 1) {
+        d0 += __shfl_down(d0, off, 64);
+        d1 += __shfl_down(d1, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(digest + inst * 2), (unsigned long long)d0);
+        atomicAdd(reinterpret_cast<unsigned long long*>(digest + inst * 2 + 1), (unsigned long long)d1);
+    }
 }
 
 // input decode: lanes [0, n) decompress pk (48 B), lanes [n, 2n) decompress sig (96 B); status[i][0] / status[i][1]
@@ -670,156 +760,219 @@ inline int hip_ok(hipError_t e, const char* what) {
     return BLSW_OK;
 }
 
+// RAII: every ABI entry point of an engine runs on the engine's device and restores the caller's
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int dev) {
+        if (dev < 0) return;
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (switched) hipSetDevice(prev);
+    }
+};
+
 }  // namespace
 
 // Execution engine. Batches ("steps") are SUBMITTED with their input/output pointers and processed in GROUPS of up
 // to max_steps batches by one set of launches (N = steps * n lanes per chain kernel), which is what fills the chip:
 // one batch of 1024 instances is only 16 waves per chain. Per group:
-//   main : sha_values -> map -> cofactor -> prepare(H) ............ -> pairing
+//   sha  : SHA witness bits                                          (needs only msg)        -> ev_sha
+//   main : sha_values -> map -> cofactor -> prepare(H) ............ -> pairing               -> ev_chains
 //   aux0 : g1_alloc, g2_alloc                                        (needs only pk / sig)
-//   aux1 : prepare(sig), sha witness bits                            (need only sig / msg)
-// Field witnesses go to an element-major staging area (coalesced stores); then, per step and in submission order,
-// the `place` stream writes the step's complete witness tensor: k_sha_expand (bit -> Fp, ~31 MB per instance, the
-// HBM-bound kernel) and k_place_field (staging -> its place around the SHA segment). Two group buffers ping-pong,
-// so the next group's chains overlap the previous group's placement.
+//   aux1 : prepare(sig)                                              (needs only sig)
+// Field witnesses go to a staging area (coalesced stores). The witness tensors are written per step, in submission
+// order, by two engine-wide streams: `expand` runs k_sha_expand (bit -> Fp, 31 MB of the 34 MB per instance, the
+// HBM-bound kernel) as soon as the group's SHA bits exist — it never waits for the curve / pairing chains, so a short
+// job does not pay the chains' latency in front of its HBM stream — and `place` runs k_place_field (staging -> its
+// place around the SHA segment) once the group's chains are done and the step's expansion has been issued.
+// n_buffers group buffers rotate, so the next groups' chains overlap the previous groups' placement.
 #define BLSW_MAX_BUFFERS 32
 #define BLSW_MAX_TIMED 1024
+#define BLSW_MAX_CONSUMED 64
 struct GroupBuf {
-    void* base;
-    Workspace ws;
-    StepDesc* h_desc;  // pinned host
-    StepDesc* d_desc;
-    hipStream_t st[3];  // main, aux0, aux1
-    hipEvent_t ev_start, ev_aux[3], ev_chains, ev_done;
-    bool used;
+    void* base = nullptr;
+    StepDesc* h_desc = nullptr;  // pinned host
+    StepDesc* d_desc = nullptr;
+    hipStream_t st[4] = {nullptr, nullptr, nullptr, nullptr};  // main, aux0, aux1, sha
+    hipEvent_t ev_start = nullptr, ev_aux[2] = {nullptr, nullptr}, ev_sha = nullptr, ev_chains = nullptr, ev_done = nullptr;
+    hipEvent_t* ev_in = nullptr;    // [max_steps] inputs of step s valid (recorded on the submitting stream)
+    hipEvent_t* ev_x = nullptr;     // [max_steps] expansion of step s issued and finished
+    hipEvent_t* ev_step = nullptr;  // [max_steps] step s complete (witness tensor + results)
+    uint64_t first_seq = 0;
+    uint32_t steps = 0;
+    bool used = false;
 };
 struct blsw_engine {
-    uint64_t n;
-    uint32_t msg_len, max_steps;
+    uint64_t n = 0;
+    uint32_t msg_len = 0, max_steps = 0;
     blsw_layout_t L, LS;
+    Modes modes = DEFAULT_MODES;
+    blsw_engine_options_t opt;
+    int device = -1;
     GroupBuf buf[BLSW_MAX_BUFFERS];
-    int nbuf;
-    int cur;
-    uint32_t pending;
-    hipStream_t place;
-    hipEvent_t ev_in;
+    int nbuf = 0;
+    int cur = 0;
+    uint32_t pending = 0;
+    uint64_t submitted = 0, launched = 0;
+    hipStream_t expand = nullptr, place = nullptr;
     // HIP event pairs around every k_sha_expand launch since the last stats reset (live roofline measurement)
-    hipEvent_t* ev_exp;  // 2 * BLSW_MAX_TIMED events
-    uint32_t n_timed;
-    bool staged;  // false: direct mode (max_steps == 1, no staging; witnesses written in place by the chains)
+    hipEvent_t* ev_exp = nullptr;  // 2 * BLSW_MAX_TIMED events
+    uint32_t n_timed = 0;
+    // consumer releases: output tensor pointer -> event after which it may be overwritten
+    const uint64_t* consumed_ptr[BLSW_MAX_CONSUMED];
+    hipEvent_t consumed_ev[BLSW_MAX_CONSUMED];
+    bool consumed_live[BLSW_MAX_CONSUMED];
+    bool staged = false;  // false: direct mode (max_steps == 1, no staging; witnesses written in place by the chains)
 };
 
-static unsigned place_lds_bytes() {
-    static int v = -1;
-    if (v < 0) {
-        const char* s = getenv("BLSW_PLACE_LDS");
-        v = s ? atoi(s) : 0;  // optional occupancy limiter for the placement kernel (bytes of dynamic LDS per workgroup)
+static void engine_free(blsw_engine* e) {
+    if (!e) return;
+    for (int k = 0; k < BLSW_MAX_BUFFERS; k++) {
+        GroupBuf& b = e->buf[k];
+        if (b.h_desc) hipHostFree(b.h_desc);
+        if (b.d_desc) hipFree(b.d_desc);
+        for (int i = 0; i < 4; i++)
+            if (b.st[i]) hipStreamDestroy(b.st[i]);
+        hipEvent_t single[] = {b.ev_start, b.ev_aux[0], b.ev_aux[1], b.ev_sha, b.ev_chains, b.ev_done};
+        for (hipEvent_t ev : single)
+            if (ev) hipEventDestroy(ev);
+        hipEvent_t* arrays[] = {b.ev_in, b.ev_x, b.ev_step};
+        for (hipEvent_t* arr : arrays) {
+            if (!arr) continue;
+            for (uint32_t s = 0; s < e->max_steps; s++)
+                if (arr[s]) hipEventDestroy(arr[s]);
+            delete[] arr;
+        }
     }
-    return (unsigned)v;
-}
-static int prio_mode() {  // 0: chains high / placement low; 1: placement high / chains low (default); 2: all equal
-    static int v = -1;
-    if (v < 0) {
-        const char* s = getenv("BLSW_PRIO_MODE");
-        v = s ? atoi(s) : 1;
+    if (e->expand) hipStreamDestroy(e->expand);
+    if (e->place) hipStreamDestroy(e->place);
+    if (e->ev_exp) {
+        for (int i = 0; i < 2 * BLSW_MAX_TIMED; i++)
+            if (e->ev_exp[i]) hipEventDestroy(e->ev_exp[i]);
+        delete[] e->ev_exp;
     }
-    return v;
+    for (int i = 0; i < BLSW_MAX_CONSUMED; i++)
+        if (e->consumed_ev[i]) hipEventDestroy(e->consumed_ev[i]);
+    delete e;
 }
-static int place_nt() {
-    static int v = -1;
-    if (v < 0) {
-        // 0 plain stores (default), 1 nontemporal, 2 sc1, 3 sc0 sc1. Nontemporal stores were the better choice while the chain
-        // kernels kept 10 KB stacks in L2 (+10 %); with the stack traffic cut, plain stores win by 8-10 %
-        const char* s = getenv("BLSW_EXPAND_NT");
-        v = s ? atoi(s) : 0;
-    }
-    return v;
-}
-static int launch_group(blsw_engine* e, hipStream_t user_stream) {
+
+static int launch_group(blsw_engine* e) {
     GroupBuf& b = e->buf[e->cur];
     const uint32_t steps = e->pending;
     if (steps == 0) return BLSW_OK;
     Group g;
     g.N = (uint64_t)steps * e->n;
     g.n = (uint32_t)e->n;
+    g.K = 1;
     g.msg_len = e->msg_len;
     g.desc = b.d_desc;
     g.L = e->L;
     g.LS = e->LS;
-    g.ws = carve(b.base, g.N, e->L, e->staged);
-    g.chain_prio = prio_mode() == 0;
+    g.ws = carve(b.base, g.N, e->L, e->staged, e->modes);
+    g.chain_prio = e->opt.prio_mode == 0;
     const unsigned g1 = (unsigned)((g.N + 63) / 64), g2 = (unsigned)((2 * g.N + 63) / 64);
+    const unsigned gt = (unsigned)((g.N + BLSW_TEAMS_PER_WAVE - 1) / BLSW_TEAMS_PER_WAVE);
     hipStream_t st = b.st[0];
-    // inputs are ready once the submitting stream reaches this point
-    hipEventRecord(e->ev_in, user_stream);
-    hipStreamWaitEvent(st, e->ev_in, 0);
-    hipMemcpyAsync(b.d_desc, b.h_desc, sizeof(StepDesc) * steps, hipMemcpyHostToDevice, st);
-    hipEventRecord(b.ev_start, st);
-    for (int i = 0; i < 2; i++) hipStreamWaitEvent(b.st[1 + i], b.ev_start, 0);
+    // inputs of every step are ready once its submitting stream reached the point of the submit
+    for (uint32_t s = 0; s < steps; s++) hipStreamWaitEvent(st, b.ev_in[s], 0);
     bool any_out = false;
     for (uint32_t s = 0; s < steps; s++) any_out = any_out || b.h_desc[s].out != nullptr;
-    // aux0: group allocations
-    hipLaunchKernelGGL(k_g1, dim3(g1), dim3(64), 0, b.st[1], g);
-    if (g2_team_mode())
-        hipLaunchKernelGGL(k_g2_alloc_team, dim3((unsigned)((g.N + BLSW_TEAMS_PER_WAVE - 1) / BLSW_TEAMS_PER_WAVE)), dim3(64), 0, b.st[1], g);
-    else
-        hipLaunchKernelGGL(k_g2_alloc, dim3(g1), dim3(64), 0, b.st[1], g);
-    hipEventRecord(b.ev_aux[0], b.st[1]);
-    // aux1: prepare_g2(sig), then the SHA-256 witness bits
-    hipLaunchKernelGGL(k_prepare, dim3(g1), dim3(64), 0, b.st[2], g, 1);
-    hipEventRecord(b.ev_aux[1], b.st[2]);
-    if (any_out) hipLaunchKernelGGL(k_sha, dim3(g1), dim3(64), 0, b.st[2], g, 1, 0);
-    hipEventRecord(b.ev_aux[2], b.st[2]);
-    // main: the hash-to-G2 critical path, then the pairing
+    // direct mode: the chains themselves write into the output tensors, so they wait for the consumer's release
+    if (!e->staged)
+        for (uint32_t s = 0; s < steps; s++)
+            for (int c = 0; c < BLSW_MAX_CONSUMED; c++)
+                if (e->consumed_live[c] && e->consumed_ptr[c] == b.h_desc[s].out) hipStreamWaitEvent(st, e->consumed_ev[c], 0);
+    hipMemcpyAsync(b.d_desc, b.h_desc, sizeof(StepDesc) * steps, hipMemcpyHostToDevice, st);
+    hipEventRecord(b.ev_start, st);
+    for (int i = 1; i < 4; i++) hipStreamWaitEvent(b.st[i], b.ev_start, 0);
+    // sha: the witness bits of the in-circuit SHA-256 (first: the expansion stream is waiting for them)
+    if (any_out) hipLaunchKernelGGL(k_sha, dim3(g1), dim3(64), 0, b.st[3], g, 1, 0);
+    hipEventRecord(b.ev_sha, b.st[3]);
+    // main, first part: the hash-to-G2 critical path
     hipLaunchKernelGGL(k_sha_values, dim3(g1), dim3(64), 0, st, g);
     hipLaunchKernelGGL(k_map, dim3(g2), dim3(64), 0, st, g);
     hipLaunchKernelGGL(k_cofactor, dim3(g1), dim3(64), 0, st, g);
     hipLaunchKernelGGL(k_prepare, dim3(g1), dim3(64), 0, st, g, 0);
+    // aux0: group allocations
+    hipLaunchKernelGGL(k_g1, dim3(g1), dim3(64), 0, b.st[1], g);
+    if (e->modes.g2_team)
+        hipLaunchKernelGGL(k_g2_alloc_team, dim3(gt), dim3(64), 0, b.st[1], g);
+    else
+        hipLaunchKernelGGL(k_g2_alloc, dim3(g1), dim3(64), 0, b.st[1], g);
+    hipEventRecord(b.ev_aux[0], b.st[1]);
+    // aux1: prepare_g2(sig)
+    hipLaunchKernelGGL(k_prepare, dim3(g1), dim3(64), 0, b.st[2], g, 1);
+    hipEventRecord(b.ev_aux[1], b.st[2]);
+    // main, second part: the pairing
     hipStreamWaitEvent(st, b.ev_aux[0], 0);
     hipStreamWaitEvent(st, b.ev_aux[1], 0);
-    launch_pairing(g, st);
-    hipStreamWaitEvent(st, b.ev_aux[2], 0);
+    launch_pairing(g, e->modes, st);
+    hipStreamWaitEvent(st, b.ev_sha, 0);
     hipEventRecord(b.ev_chains, st);
-    // placement, per step, in submission order
-    hipStreamWaitEvent(e->place, b.ev_chains, 0);
-    for (uint32_t s = 0; s < steps && any_out; s++) {
+    // expansion of the SHA segments, per step, in submission order: waits for the SHA bits only
+    hipStreamWaitEvent(e->expand, b.ev_sha, 0);
+    for (uint32_t s = 0; s < steps; s++) {
         const StepDesc& d = b.h_desc[s];
-        if (!d.out) continue;
-        dim3 grid((e->L.sha_bits + BLSW_EXPAND_EPI * BLSW_EXPAND_ITERS - 1) / (BLSW_EXPAND_EPI * BLSW_EXPAND_ITERS), (unsigned)e->n);
-        const bool timed = e->n_timed < BLSW_MAX_TIMED;
-        if (timed) hipEventRecord(e->ev_exp[2 * e->n_timed], e->place);
-#define BLSW_LAUNCH_EXPAND(MODE)                                                                                                                   \
-    hipLaunchKernelGGL(k_sha_expand<MODE>, grid, dim3(BLSW_EXPAND_THREADS), place_lds_bytes(), e->place, g.ws.bits, g.ws.sha_words, (uint64_t)s * e->n, e->L.sha_bits, \
-                       e->L.off_expand, d.out, d.out_stride)
-        switch (place_nt()) {
-            case 0: BLSW_LAUNCH_EXPAND(0); break;
-            case 2: BLSW_LAUNCH_EXPAND(2); break;
-            case 3: BLSW_LAUNCH_EXPAND(3); break;
-            default: BLSW_LAUNCH_EXPAND(1); break;
+        if (d.out) {
+            for (int c = 0; c < BLSW_MAX_CONSUMED; c++)
+                if (e->consumed_live[c] && e->consumed_ptr[c] == d.out) {
+                    hipStreamWaitEvent(e->expand, e->consumed_ev[c], 0);
+                    e->consumed_live[c] = false;
+                }
+            dim3 grid((e->L.sha_bits + BLSW_EXPAND_EPI * BLSW_EXPAND_ITERS - 1) / (BLSW_EXPAND_EPI * BLSW_EXPAND_ITERS), (unsigned)e->n);
+            const bool timed = e->n_timed < BLSW_MAX_TIMED;
+            if (timed) hipEventRecord(e->ev_exp[2 * e->n_timed], e->expand);
+#define BLSW_LAUNCH_EXPAND(MODE)                                                                                                                         \
+    hipLaunchKernelGGL(k_sha_expand<MODE>, grid, dim3(BLSW_EXPAND_THREADS), e->opt.place_lds, e->expand, g.ws.bits, g.ws.sha_words, (uint64_t)s * e->n, \
+                       e->L.sha_bits, e->L.off_expand, d.out, d.out_stride, 1u, 0u)
+            switch (e->opt.expand_store) {
+                case 0: BLSW_LAUNCH_EXPAND(0); break;
+                case 2: BLSW_LAUNCH_EXPAND(2); break;
+                case 3: BLSW_LAUNCH_EXPAND(3); break;
+                default: BLSW_LAUNCH_EXPAND(1); break;
+            }
+            if (timed) {
+                hipEventRecord(e->ev_exp[2 * e->n_timed + 1], e->expand);
+                e->n_timed++;
+            }
         }
-        if (timed) {
-            hipEventRecord(e->ev_exp[2 * e->n_timed + 1], e->place);
-            e->n_timed++;
-        }
-        if (e->staged) {
+        hipEventRecord(b.ev_x[s], e->expand);
+    }
+    // field segments, per step, once the group's chains are done; a step is complete after both kernels
+    hipStreamWaitEvent(e->place, b.ev_chains, 0);
+    for (uint32_t s = 0; s < steps; s++) {
+        const StepDesc& d = b.h_desc[s];
+        hipStreamWaitEvent(e->place, b.ev_x[s], 0);
+        if (d.out && e->staged) {
             const uint32_t rows = e->L.n_witness - e->L.sha_bits;
             const unsigned chunks = (rows * 3 + 256 * BLSW_PLACE_ITERS - 1) / (256 * BLSW_PLACE_ITERS);
             dim3 grid2(8 * ((chunks + 7) / 8) * (unsigned)e->n);
             hipLaunchKernelGGL(k_place_field, grid2, dim3(256), 0, e->place, g.ws.staging, g.ws.pair, (uint64_t)s * e->n, e->L.off_expand, e->L.sha_bits, rows,
                                g.ws.split_row, d.out, d.out_stride, (uint32_t)e->n, e->L.off_sig_alloc,
-                               g2_team_mode() ? e->L.off_pk_not_zero - e->L.off_sig_alloc : 0u, e->LS.off_sig_alloc);
+                               e->modes.g2_team ? e->L.off_pk_not_zero - e->L.off_sig_alloc : 0u, e->LS.off_sig_alloc);
         }
+        hipEventRecord(b.ev_step[s], e->place);
     }
     hipEventRecord(b.ev_done, e->place);
     b.used = true;
+    b.first_seq = e->launched;
+    b.steps = steps;
+    e->launched += steps;
     e->pending = 0;
     e->cur = (e->cur + 1) % e->nbuf;
     return hip_ok(hipGetLastError(), "launch");
 }
 
+static uint32_t env_u32(const char* name, uint32_t dflt) {
+    const char* s = getenv(name);
+    return s && *s ? (uint32_t)strtoul(s, nullptr, 10) : dflt;
+}
+
 extern "C" {
 
-int blsw_version(void) { return 4; }
+int blsw_version(void) { return BLSW_ABI_VERSION; }
 
 int blsw_layout(uint32_t msg_len, blsw_layout_t* out) {
     if (!out || msg_len > 65535) return BLSW_ERR_ARG;
@@ -827,75 +980,135 @@ int blsw_layout(uint32_t msg_len, blsw_layout_t* out) {
     return BLSW_OK;
 }
 
+int blsw_engine_options_default(blsw_engine_options_t* o) {
+    if (!o) return BLSW_ERR_ARG;
+    const char* p = getenv("BLSW_PAIRING");
+    const char* g2 = getenv("BLSW_G2");
+    o->device = -1;
+    o->pairing_mode = (p && p[0] == 'l') ? 1u : 0u;
+    o->g2_mode = (g2 && g2[0] == 't' && o->pairing_mode == 0) ? 1u : 0u;
+    o->expand_store = env_u32("BLSW_EXPAND_NT", 0);  // plain stores: nontemporal ones cost 8-10 % since the chains' stack traffic was cut
+    o->prio_mode = env_u32("BLSW_PRIO_MODE", 1);
+    o->place_lds = env_u32("BLSW_PLACE_LDS", 0);
+    return BLSW_OK;
+}
+
 int blsw_engine_workspace_bytes(uint64_t n, uint32_t msg_len, uint32_t max_steps, uint32_t n_buffers, uint64_t* bytes) {
-    if (!bytes || n == 0 || max_steps == 0 || n_buffers == 0 || n_buffers > BLSW_MAX_BUFFERS) return BLSW_ERR_ARG;
+    if (!bytes || n == 0 || max_steps == 0 || n_buffers == 0 || n_buffers > BLSW_MAX_BUFFERS || msg_len > 65535) return BLSW_ERR_ARG;
     blsw_layout_t L;
     make_layout(msg_len, &L);
-    Workspace w = carve(nullptr, n * max_steps, L, max_steps > 1 || n_buffers > 1);
-    *bytes = (uint64_t)n_buffers * align_up(w.total_bytes, 4096);
+    const bool staged = max_steps > 1 || n_buffers > 1;
+    // the same workspace serves every kernel variant: the largest carve of the three mode combinations
+    uint64_t need = 0;
+    const Modes all[3] = {{true, false}, {true, true}, {false, false}};
+    for (const Modes& m : all) {
+        uint64_t t = carve(nullptr, n * max_steps, L, staged, m).total_bytes;
+        need = t > need ? t : need;
+    }
+    *bytes = (uint64_t)n_buffers * align_up(need, 4096);
+    return BLSW_OK;
+}
+
+int blsw_engine_create_ex(blsw_engine_t** out, uint64_t n, uint32_t msg_len, uint32_t max_steps, uint32_t n_buffers, const blsw_engine_options_t* options,
+                          void* d_workspace, uint64_t workspace_bytes) {
+    if (!out || n == 0 || n > 0x7fffffffu || max_steps == 0 || !d_workspace || n_buffers == 0 || n_buffers > BLSW_MAX_BUFFERS || !options || msg_len > 65535)
+        return BLSW_ERR_ARG;
+    if (options->pairing_mode > 1 || options->g2_mode > 1 || (options->g2_mode == 1 && options->pairing_mode != 0) || options->expand_store > 3 ||
+        options->prio_mode > 2)
+        return BLSW_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return BLSW_ERR_NO_DEVICE;
+    int dev = options->device;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return BLSW_ERR_NO_DEVICE;
+    if (dev >= ndev) return BLSW_ERR_ARG;
+    DeviceGuard guard(dev);
+    uint64_t need = 0;
+    if (blsw_engine_workspace_bytes(n, msg_len, max_steps, n_buffers, &need)) return BLSW_ERR_ARG;
+    if (workspace_bytes < need) return BLSW_ERR_WORKSPACE;
+    // Scratch guard. ROCr backs a queue's scratch for full-device occupancy: stack bytes per lane x 64 lanes x wave slots
+    // (CUs x 32), per queue that runs the kernel. The single-lane pairing kernel (9.7 KB of stack) on four or more group
+    // buffers made the runtime abort with HSA_STATUS_ERROR_OUT_OF_RESOURCES; refuse instead.
+    if (options->pairing_mode == 1) {
+        hipFuncAttributes fa;
+        int cus = 256;
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        uint64_t stack = 10240;
+        if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_pairing)) == hipSuccess && fa.localSizeBytes) stack = fa.localSizeBytes;
+        const uint64_t projected = stack * 64ull * (uint64_t)cus * 32ull * n_buffers;
+        if (projected > (16ull << 30)) {
+            fprintf(stderr, "[blsw] pairing_mode 1 with %u group buffers needs about %.1f GB of per-queue scratch: refused (use pairing_mode 0 or n_buffers <= 3)\n",
+                    n_buffers, projected / 1e9);
+            return BLSW_ERR_SCRATCH;
+        }
+    }
+    blsw_engine* e = new blsw_engine();
+    e->n = n;
+    e->msg_len = msg_len;
+    e->max_steps = max_steps;
+    e->opt = *options;
+    e->opt.device = dev;
+    e->device = dev;
+    e->modes = {options->pairing_mode == 0, options->g2_mode == 1};
+    e->staged = max_steps > 1 || n_buffers > 1;
+    make_layout(msg_len, &e->L);
+    e->LS = staging_layout(e->L, e->modes);
+    for (int i = 0; i < BLSW_MAX_CONSUMED; i++) {
+        e->consumed_ptr[i] = nullptr;
+        e->consumed_ev[i] = nullptr;
+        e->consumed_live[i] = false;
+    }
+    e->nbuf = (int)n_buffers;
+    int rc = BLSW_OK;
+    auto chk = [&](hipError_t err, const char* what) {
+        if (rc == BLSW_OK && hip_ok(err, what)) rc = BLSW_ERR_HIP;
+        return rc == BLSW_OK;
+    };
+    e->ev_exp = new hipEvent_t[2 * BLSW_MAX_TIMED]();
+    for (int i = 0; i < 2 * BLSW_MAX_TIMED && rc == BLSW_OK; i++) chk(hipEventCreate(&e->ev_exp[i]), "event create");
+    int prio_lo = 0, prio_hi = 0;
+    chk(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi), "priority range");  // (least, greatest): numerically lower = higher priority
+    const int chain_prio = e->opt.prio_mode == 1 ? prio_lo : prio_hi, place_prio = e->opt.prio_mode == 0 ? prio_lo : prio_hi;
+    for (int k = 0; k < e->nbuf && rc == BLSW_OK; k++) {
+        GroupBuf& b = e->buf[k];
+        b.base = reinterpret_cast<char*>(d_workspace) + (uint64_t)k * (need / e->nbuf);
+        chk(hipHostMalloc(reinterpret_cast<void**>(&b.h_desc), sizeof(StepDesc) * max_steps, hipHostMallocDefault), "host alloc");
+        chk(hipMalloc(reinterpret_cast<void**>(&b.d_desc), sizeof(StepDesc) * max_steps), "desc alloc");
+        // the SHA-bit stream feeds the HBM-bound expansion: it takes the placement priority
+        for (int i = 0; i < 4; i++) chk(hipStreamCreateWithPriority(&b.st[i], hipStreamNonBlocking, i == 3 ? place_prio : chain_prio), "stream create");
+        hipEvent_t* single[] = {&b.ev_start, &b.ev_aux[0], &b.ev_aux[1], &b.ev_sha, &b.ev_chains, &b.ev_done};
+        for (hipEvent_t* ev : single) chk(hipEventCreateWithFlags(ev, hipEventDisableTiming), "event create");
+        b.ev_in = new hipEvent_t[max_steps]();
+        b.ev_x = new hipEvent_t[max_steps]();
+        b.ev_step = new hipEvent_t[max_steps]();
+        for (uint32_t s = 0; s < max_steps && rc == BLSW_OK; s++) {
+            chk(hipEventCreateWithFlags(&b.ev_in[s], hipEventDisableTiming), "event create");
+            chk(hipEventCreateWithFlags(&b.ev_x[s], hipEventDisableTiming), "event create");
+            chk(hipEventCreateWithFlags(&b.ev_step[s], hipEventDisableTiming), "event create");
+        }
+    }
+    chk(hipStreamCreateWithPriority(&e->expand, hipStreamNonBlocking, place_prio), "stream create");
+    chk(hipStreamCreateWithPriority(&e->place, hipStreamNonBlocking, place_prio), "stream create");
+    if (rc != BLSW_OK) {
+        engine_free(e);
+        return rc;
+    }
+    *out = e;
     return BLSW_OK;
 }
 
 int blsw_engine_create(blsw_engine_t** out, uint64_t n, uint32_t msg_len, uint32_t max_steps, uint32_t n_buffers, void* d_workspace,
                        uint64_t workspace_bytes) {
-    if (!out || n == 0 || max_steps == 0 || !d_workspace || n_buffers == 0 || n_buffers > BLSW_MAX_BUFFERS) return BLSW_ERR_ARG;
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return BLSW_ERR_NO_DEVICE;
-    uint64_t need = 0;
-    blsw_engine_workspace_bytes(n, msg_len, max_steps, n_buffers, &need);
-    if (workspace_bytes < need) return BLSW_ERR_WORKSPACE;
-    blsw_engine* e = new blsw_engine();
-    e->n = n;
-    e->msg_len = msg_len;
-    e->max_steps = max_steps;
-    e->staged = max_steps > 1 || n_buffers > 1;
-    make_layout(msg_len, &e->L);
-    e->LS = staging_layout(e->L);
-    e->cur = 0;
-    e->pending = 0;
-    e->n_timed = 0;
-    e->ev_exp = new hipEvent_t[2 * BLSW_MAX_TIMED];
-    for (int i = 0; i < 2 * BLSW_MAX_TIMED; i++) hipEventCreate(&e->ev_exp[i]);
-    e->nbuf = (int)n_buffers;
-    int prio_lo = 0, prio_hi = 0;
-    hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);  // (least, greatest): numerically lower = higher priority
-    for (int k = 0; k < e->nbuf; k++) {
-        GroupBuf& b = e->buf[k];
-        b.base = reinterpret_cast<char*>(d_workspace) + (uint64_t)k * (need / e->nbuf);
-        b.used = false;
-        if (hip_ok(hipHostMalloc(reinterpret_cast<void**>(&b.h_desc), sizeof(StepDesc) * max_steps, hipHostMallocDefault), "host alloc")) return BLSW_ERR_HIP;
-        if (hip_ok(hipMalloc(reinterpret_cast<void**>(&b.d_desc), sizeof(StepDesc) * max_steps), "desc alloc")) return BLSW_ERR_HIP;
-        for (int i = 0; i < 3; i++)
-            if (hip_ok(hipStreamCreateWithPriority(&b.st[i], hipStreamNonBlocking, prio_mode() == 1 ? prio_lo : prio_hi), "stream create")) return BLSW_ERR_HIP;
-        for (int i = 0; i < 3; i++) hipEventCreateWithFlags(&b.ev_aux[i], hipEventDisableTiming);
-        hipEventCreateWithFlags(&b.ev_start, hipEventDisableTiming);
-        hipEventCreateWithFlags(&b.ev_chains, hipEventDisableTiming);
-        hipEventCreateWithFlags(&b.ev_done, hipEventDisableTiming);
-    }
-    if (hip_ok(hipStreamCreateWithPriority(&e->place, hipStreamNonBlocking, prio_mode() == 0 ? prio_lo : prio_hi), "stream create")) return BLSW_ERR_HIP;
-    hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming);
-    *out = e;
-    return hip_ok(hipGetLastError(), "engine create");
+    blsw_engine_options_t o;
+    blsw_engine_options_default(&o);
+    return blsw_engine_create_ex(out, n, msg_len, max_steps, n_buffers, &o, d_workspace, workspace_bytes);
 }
 
 int blsw_engine_destroy(blsw_engine_t* e) {
     if (!e) return BLSW_ERR_ARG;
+    DeviceGuard guard(e->device);
     hipDeviceSynchronize();
-    for (int k = 0; k < e->nbuf; k++) {
-        GroupBuf& b = e->buf[k];
-        hipHostFree(b.h_desc);
-        hipFree(b.d_desc);
-        for (int i = 0; i < 3; i++) hipStreamDestroy(b.st[i]);
-        for (int i = 0; i < 3; i++) hipEventDestroy(b.ev_aux[i]);
-        hipEventDestroy(b.ev_start);
-        hipEventDestroy(b.ev_chains);
-        hipEventDestroy(b.ev_done);
-    }
-    hipStreamDestroy(e->place);
-    for (int i = 0; i < 2 * BLSW_MAX_TIMED; i++) hipEventDestroy(e->ev_exp[i]);
-    delete[] e->ev_exp;
-    hipEventDestroy(e->ev_in);
-    delete e;
+    engine_free(e);
     return BLSW_OK;
 }
 
@@ -903,12 +1116,14 @@ int blsw_engine_submit(blsw_engine_t* e, const uint64_t* d_pk_xy, const uint64_t
                        uint64_t witness_stride, int32_t* d_result, void* stream_) {
     if (!e || !d_pk_xy || !d_sig_xy || (!d_msg && e->msg_len)) return BLSW_ERR_ARG;
     if (d_witness && witness_stride < e->L.n_witness) return BLSW_ERR_ARG;
+    DeviceGuard guard(e->device);
     GroupBuf& b = e->buf[e->cur];
     if (e->pending == 0 && b.used) {
         // the buffer's previous group must have been fully placed before its staging is overwritten
         if (hip_ok(hipEventSynchronize(b.ev_done), "event sync")) return BLSW_ERR_HIP;
         b.used = false;
     }
+    if (hip_ok(hipEventRecord(b.ev_in[e->pending], reinterpret_cast<hipStream_t>(stream_)), "event record")) return BLSW_ERR_HIP;
     StepDesc& d = b.h_desc[e->pending];
     d.pk = d_pk_xy;
     d.sig = d_sig_xy;
@@ -920,25 +1135,65 @@ int blsw_engine_submit(blsw_engine_t* e, const uint64_t* d_pk_xy, const uint64_t
     d.bitmap = nullptr;
     d.count = nullptr;
     e->pending++;
-    if (e->pending == e->max_steps) return launch_group(e, reinterpret_cast<hipStream_t>(stream_));
+    e->submitted++;
+    if (e->pending == e->max_steps) return launch_group(e);
     return BLSW_OK;
 }
 
 // launches whatever is pending and makes `stream` wait for every group issued so far
 int blsw_engine_flush(blsw_engine_t* e, void* stream_) {
     if (!e) return BLSW_ERR_ARG;
+    DeviceGuard guard(e->device);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream_);
-    int rc = launch_group(e, st);
+    int rc = launch_group(e);
     if (rc) return rc;
     for (int k = 0; k < e->nbuf; k++)
         if (e->buf[k].used) hipStreamWaitEvent(st, e->buf[k].ev_done, 0);
     return hip_ok(hipGetLastError(), "flush");
 }
 
+int blsw_engine_submitted(blsw_engine_t* e, uint64_t* seq) {
+    if (!e || !seq) return BLSW_ERR_ARG;
+    *seq = e->submitted;
+    return BLSW_OK;
+}
+int blsw_engine_launched(blsw_engine_t* e, uint64_t* seq) {
+    if (!e || !seq) return BLSW_ERR_ARG;
+    *seq = e->launched;
+    return BLSW_OK;
+}
+// Step `seq` must have been issued (seq < launched) and its group buffer not yet recycled (at most n_buffers groups back:
+// older steps completed before their buffer was reused, so there is nothing to wait for).
+int blsw_engine_wait_step(blsw_engine_t* e, uint64_t seq, void* stream_) {
+    if (!e || seq >= e->launched) return BLSW_ERR_ARG;
+    DeviceGuard guard(e->device);
+    for (int k = 0; k < e->nbuf; k++) {
+        GroupBuf& b = e->buf[k];
+        if (b.used && seq >= b.first_seq && seq < b.first_seq + b.steps)
+            return hip_ok(hipStreamWaitEvent(reinterpret_cast<hipStream_t>(stream_), b.ev_step[seq - b.first_seq], 0), "wait step");
+    }
+    return BLSW_OK;
+}
+int blsw_engine_output_consumed(blsw_engine_t* e, const uint64_t* d_witness, void* stream_) {
+    if (!e || !d_witness) return BLSW_ERR_ARG;
+    DeviceGuard guard(e->device);
+    int slot = -1;
+    for (int c = 0; c < BLSW_MAX_CONSUMED; c++)
+        if (e->consumed_ptr[c] == d_witness) slot = c;
+    for (int c = 0; c < BLSW_MAX_CONSUMED && slot < 0; c++)
+        if (!e->consumed_live[c]) slot = c;
+    if (slot < 0) return BLSW_ERR_ARG;  // more than BLSW_MAX_CONSUMED distinct tensors with an outstanding release
+    if (!e->consumed_ev[slot] && hip_ok(hipEventCreateWithFlags(&e->consumed_ev[slot], hipEventDisableTiming), "event create")) return BLSW_ERR_HIP;
+    e->consumed_ptr[slot] = d_witness;
+    e->consumed_live[slot] = true;
+    return hip_ok(hipEventRecord(e->consumed_ev[slot], reinterpret_cast<hipStream_t>(stream_)), "event record");
+}
+
 // Average duration (ms) of the k_sha_expand launches issued since the last call (HIP events recorded on the stream the
 // kernel ran on); blocks until they have finished, then resets the statistics. count may be 0.
 int blsw_engine_expand_stats(blsw_engine_t* e, uint32_t* count, float* avg_ms) {
     if (!e || !count || !avg_ms) return BLSW_ERR_ARG;
+    DeviceGuard guard(e->device);
     double sum = 0;
     for (uint32_t i = 0; i < e->n_timed; i++) {
         if (hip_ok(hipEventSynchronize(e->ev_exp[2 * i + 1]), "event sync")) return BLSW_ERR_HIP;
@@ -952,25 +1207,48 @@ int blsw_engine_expand_stats(blsw_engine_t* e, uint32_t* count, float* avg_ms) {
     return BLSW_OK;
 }
 
-int blsw_hash_to_g2_batch(const uint8_t* d_msg, uint32_t msg_len, uint64_t n, uint64_t* d_out_affine, void* d_workspace, uint64_t workspace_bytes,
-                          void* stream_) {
-    if ((!d_msg && msg_len) || n == 0 || !d_workspace || !d_out_affine) return BLSW_ERR_ARG;
+int blsw_witness_digest(const uint64_t* d_witness, uint64_t witness_stride, uint64_t n, uint32_t n_witness, uint64_t* d_digest, void* stream_) {
+    if (!d_witness || !d_digest || n == 0 || n > 65535 || n_witness == 0 || witness_stride < n_witness) return BLSW_ERR_ARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream_);
+    if (hip_ok(hipMemsetAsync(d_digest, 0, n * 2 * sizeof(uint64_t), st), "memset")) return BLSW_ERR_HIP;
+    const uint64_t n_words = (uint64_t)n_witness * 6, per_block = 2ull * 256 * BLSW_DIGEST_ITERS;
+    dim3 grid((unsigned)((n_words + per_block - 1) / per_block), (unsigned)n);
+    hipLaunchKernelGGL(k_digest, grid, dim3(256), 0, st, d_witness, witness_stride, n_words, d_digest);
+    return hip_ok(hipGetLastError(), "launch");
+}
+
+// one-step descriptor at the head of a caller workspace (direct-mode entry points); `h` is copied before returning
+static int put_desc(StepDesc* d_desc, const StepDesc& h, hipStream_t st) {
+    if (hip_ok(hipMemcpyAsync(d_desc, &h, sizeof(h), hipMemcpyHostToDevice, st), "memcpy")) return BLSW_ERR_HIP;
+    return hip_ok(hipStreamSynchronize(st), "sync");  // `h` is a stack object
+}
+static Group direct_group(uint64_t n, uint32_t K, uint32_t msg_len, const blsw_layout_t& L, StepDesc* d_desc, const Workspace& ws) {
     Group g;
-    make_layout(msg_len, &g.L);
-    g.LS = staging_layout(g.L);
-    // the step descriptor lives at the head of the workspace
-    StepDesc* d_desc = reinterpret_cast<StepDesc*>(d_workspace);
-    g.ws = carve(reinterpret_cast<char*>(d_workspace) + 256, n, g.L, false);
-    if (g.ws.total_bytes + 256 > workspace_bytes) return BLSW_ERR_WORKSPACE;
-    g.N = n;
+    g.N = n * K;
     g.n = (uint32_t)n;
+    g.K = K;
     g.msg_len = msg_len;
     g.desc = d_desc;
+    g.L = L;
+    g.LS = L;
+    g.ws = ws;
     g.chain_prio = 0;
+    return g;
+}
+
+int blsw_hash_to_g2_batch(const uint8_t* d_msg, uint32_t msg_len, uint64_t n, uint64_t* d_out_affine, void* d_workspace, uint64_t workspace_bytes,
+                          void* stream_) {
+    if ((!d_msg && msg_len) || n == 0 || n > 0x7fffffffu || !d_workspace || !d_out_affine || msg_len > 65535) return BLSW_ERR_ARG;
+    blsw_layout_t L;
+    make_layout(msg_len, &L);
+    // the step descriptor lives at the head of the workspace
+    StepDesc* d_desc = reinterpret_cast<StepDesc*>(d_workspace);
+    Workspace ws = carve(reinterpret_cast<char*>(d_workspace) + 256, n, L, false, DEFAULT_MODES);
+    if (ws.total_bytes + 256 > workspace_bytes) return BLSW_ERR_WORKSPACE;
+    Group g = direct_group(n, 1, msg_len, L, d_desc, ws);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream_);
     StepDesc h = {nullptr, nullptr, d_msg, nullptr, 0, nullptr, nullptr, nullptr, nullptr};
-    hipMemcpyAsync(d_desc, &h, sizeof(h), hipMemcpyHostToDevice, st);
-    hipStreamSynchronize(st);  // `h` is a stack object
+    if (int rc = put_desc(d_desc, h, st)) return rc;
     const unsigned g1 = (unsigned)((n + 63) / 64), g2 = (unsigned)((2 * n + 63) / 64);
     hipLaunchKernelGGL(k_sha_values, dim3(g1), dim3(64), 0, st, g);
     hipLaunchKernelGGL(k_map, dim3(g2), dim3(64), 0, st, g);
@@ -981,22 +1259,16 @@ int blsw_hash_to_g2_batch(const uint8_t* d_msg, uint32_t msg_len, uint64_t n, ui
 // BLS::sign + PublicKey::from(&sk) for a batch (bls.rs:411-425, 183-195). Workspace: blsw_hash_to_g2_workspace_bytes.
 int blsw_sign_batch(const uint8_t* d_sk32_le, const uint8_t* d_msg, uint32_t msg_len, uint64_t n, uint8_t* d_sig96, uint64_t* d_sig_xy, uint8_t* d_pk48,
                     uint64_t* d_pk_xy, int32_t* d_status, void* d_workspace, uint64_t workspace_bytes, void* stream_) {
-    if (!d_sk32_le || (!d_msg && msg_len) || n == 0 || !d_workspace || !d_status) return BLSW_ERR_ARG;
-    Group g;
-    make_layout(msg_len, &g.L);
-    g.LS = staging_layout(g.L);
+    if (!d_sk32_le || (!d_msg && msg_len) || n == 0 || n > 0x7fffffffu || !d_workspace || !d_status || msg_len > 65535) return BLSW_ERR_ARG;
+    blsw_layout_t L;
+    make_layout(msg_len, &L);
     StepDesc* d_desc = reinterpret_cast<StepDesc*>(d_workspace);
-    g.ws = carve(reinterpret_cast<char*>(d_workspace) + 256, n, g.L, false);
-    if (g.ws.total_bytes + 256 > workspace_bytes) return BLSW_ERR_WORKSPACE;
-    g.N = n;
-    g.n = (uint32_t)n;
-    g.msg_len = msg_len;
-    g.desc = d_desc;
-    g.chain_prio = 0;
+    Workspace ws = carve(reinterpret_cast<char*>(d_workspace) + 256, n, L, false, DEFAULT_MODES);
+    if (ws.total_bytes + 256 > workspace_bytes) return BLSW_ERR_WORKSPACE;
+    Group g = direct_group(n, 1, msg_len, L, d_desc, ws);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream_);
     StepDesc h = {nullptr, nullptr, d_msg, nullptr, 0, nullptr, nullptr, nullptr, nullptr};
-    hipMemcpyAsync(d_desc, &h, sizeof(h), hipMemcpyHostToDevice, st);
-    hipStreamSynchronize(st);  // `h` is a stack object
+    if (int rc = put_desc(d_desc, h, st)) return rc;
     const unsigned g1 = (unsigned)((n + 63) / 64), g2 = (unsigned)((2 * n + 63) / 64);
     hipLaunchKernelGGL(k_sha_values, dim3(g1), dim3(64), 0, st, g);
     hipLaunchKernelGGL(k_map, dim3(g2), dim3(64), 0, st, g);
@@ -1016,10 +1288,10 @@ static uint64_t agg_workspace(uint64_t n, const blsw_layout_t& L, uint64_t* off_
     *off_keyproj = o;
     o = align_up(o + 3ull * n * L.n_keys * sizeof(Fp), 256);
     *off_ws = o;
-    return o + carve(nullptr, n, L, false).total_bytes;
+    return o + carve(nullptr, n, L, false, DEFAULT_MODES).total_bytes;
 }
 int blsw_aggregate_workspace_bytes(uint64_t n, uint32_t msg_len, uint32_t n_keys, uint64_t* bytes) {
-    if (!bytes || n == 0 || n_keys == 0) return BLSW_ERR_ARG;
+    if (!bytes || n == 0 || n_keys == 0 || msg_len > 65535) return BLSW_ERR_ARG;
     blsw_layout_t L;
     make_layout(msg_len, &L, n_keys);
     uint64_t a, b, c;
@@ -1029,26 +1301,19 @@ int blsw_aggregate_workspace_bytes(uint64_t n, uint32_t msg_len, uint32_t n_keys
 int blsw_aggregate_verify_batch(const uint64_t* d_pks_xy, const uint8_t* d_bitmap, uint32_t n_keys, const uint64_t* d_sig_xy, const uint8_t* d_msg,
                                 uint32_t msg_len, uint64_t n, uint64_t* d_witness, uint64_t witness_stride, int32_t* d_result, uint32_t* d_count,
                                 void* d_workspace, uint64_t workspace_bytes, void* stream_) {
-    if (!d_pks_xy || !d_bitmap || n_keys == 0 || !d_sig_xy || (!d_msg && msg_len) || n == 0 || !d_workspace) return BLSW_ERR_ARG;
-    Group g;
-    make_layout(msg_len, &g.L, n_keys);
-    g.LS = g.L;
-    if (d_witness && witness_stride < g.L.n_witness) return BLSW_ERR_ARG;
+    if (!d_pks_xy || !d_bitmap || n_keys == 0 || !d_sig_xy || (!d_msg && msg_len) || n == 0 || n > 65535 || !d_workspace || msg_len > 65535) return BLSW_ERR_ARG;
+    blsw_layout_t L;
+    make_layout(msg_len, &L, n_keys);
+    if (d_witness && witness_stride < L.n_witness) return BLSW_ERR_ARG;
     uint64_t off_desc, off_keyproj, off_ws;
-    if (agg_workspace(n, g.L, &off_desc, &off_keyproj, &off_ws) > workspace_bytes) return BLSW_ERR_WORKSPACE;
+    if (agg_workspace(n, L, &off_desc, &off_keyproj, &off_ws) > workspace_bytes) return BLSW_ERR_WORKSPACE;
     char* base = reinterpret_cast<char*>(d_workspace);
     StepDesc* d_desc = reinterpret_cast<StepDesc*>(base + off_desc);
     Fp* keyproj = reinterpret_cast<Fp*>(base + off_keyproj);
-    g.ws = carve(base + off_ws, n, g.L, false);
-    g.N = n;
-    g.n = (uint32_t)n;
-    g.msg_len = msg_len;
-    g.desc = d_desc;
-    g.chain_prio = 0;
+    Group g = direct_group(n, 1, msg_len, L, d_desc, carve(base + off_ws, n, L, false, DEFAULT_MODES));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream_);
     StepDesc h = {nullptr, d_sig_xy, d_msg, d_witness, witness_stride, d_result, d_pks_xy, d_bitmap, d_count};
-    hipMemcpyAsync(d_desc, &h, sizeof(h), hipMemcpyHostToDevice, st);
-    hipStreamSynchronize(st);  // `h` is a stack object
+    if (int rc = put_desc(d_desc, h, st)) return rc;
     const unsigned g1 = (unsigned)((n + 63) / 64), g2 = (unsigned)((2 * n + 63) / 64), gk = (unsigned)((n * n_keys + 63) / 64);
     hipLaunchKernelGGL(k_agg_keys, dim3(gk), dim3(64), 0, st, g, keyproj);
     hipLaunchKernelGGL(k_agg_sum, dim3(g1), dim3(64), 0, st, g, (const Fp*)keyproj);
@@ -1057,40 +1322,93 @@ int blsw_aggregate_verify_batch(const uint64_t* d_pks_xy, const uint8_t* d_bitma
     hipLaunchKernelGGL(k_sha, dim3(g1), dim3(64), 0, st, g, d_witness ? 1 : 0, 1);
     if (d_witness) {
         dim3 grid((g.L.sha_bits + BLSW_EXPAND_EPI * BLSW_EXPAND_ITERS - 1) / (BLSW_EXPAND_EPI * BLSW_EXPAND_ITERS), (unsigned)n);
-        hipLaunchKernelGGL(k_sha_expand<0>, grid, dim3(BLSW_EXPAND_THREADS), 0, st, g.ws.bits, g.ws.sha_words, (uint64_t)0, g.L.sha_bits, g.L.off_expand, d_witness, witness_stride);
+        hipLaunchKernelGGL(k_sha_expand<0>, grid, dim3(BLSW_EXPAND_THREADS), 0, st, g.ws.bits, g.ws.sha_words, (uint64_t)0, g.L.sha_bits, g.L.off_expand, d_witness,
+                           witness_stride, 1u, 0u);
     }
     hipLaunchKernelGGL(k_map, dim3(g2), dim3(64), 0, st, g);
     hipLaunchKernelGGL(k_cofactor, dim3(g1), dim3(64), 0, st, g);
     hipLaunchKernelGGL(k_prepare, dim3(g1), dim3(64), 0, st, g, 0);
-    launch_pairing(g, st);
+    launch_pairing(g, DEFAULT_MODES, st);
     return hip_ok(hipGetLastError(), "launch");
 }
+
+// ---- N+1-pair product of pairings (one signature over n_pairs (pk, msg) pairs)
+int blsw_layout_multi(uint32_t msg_len, uint32_t n_pairs, blsw_layout_t* out) {
+    if (!out || msg_len > 65535 || n_pairs == 0 || n_pairs > 4096) return BLSW_ERR_ARG;
+    make_layout(msg_len, out, 0, n_pairs);
+    // the witness vector must stay addressable with 32-bit element offsets
+    const uint64_t total = (uint64_t)out->off_prep_h - out->off_expand;  // n_pairs * stride_hash
+    if (total / n_pairs != out->stride_hash) return BLSW_ERR_ARG;
+    return BLSW_OK;
+}
+int blsw_verify_multi_workspace_bytes(uint64_t n, uint32_t msg_len, uint32_t n_pairs, uint64_t* bytes) {
+    blsw_layout_t L;
+    if (!bytes || n == 0 || blsw_layout_multi(msg_len, n_pairs, &L)) return BLSW_ERR_ARG;
+    *bytes = 256 + carve(nullptr, n * n_pairs, L, false, DEFAULT_MODES, n).total_bytes;
+    return BLSW_OK;
+}
+int blsw_verify_multi_batch(const uint64_t* d_pks_xy, const uint8_t* d_msgs, uint32_t msg_len, uint32_t n_pairs, const uint64_t* d_sig_xy, uint64_t n,
+                            uint64_t* d_witness, uint64_t witness_stride, int32_t* d_result, void* d_workspace, uint64_t workspace_bytes, void* stream_) {
+    blsw_layout_t L;
+    if (!d_pks_xy || (!d_msgs && msg_len) || !d_sig_xy || n == 0 || !d_workspace || blsw_layout_multi(msg_len, n_pairs, &L)) return BLSW_ERR_ARG;
+    const uint64_t NP = n * n_pairs;  // per-pair lanes
+    if (NP > 65535 * 16ull || n > 65535) return BLSW_ERR_ARG;
+    if (d_witness && witness_stride < L.n_witness) return BLSW_ERR_ARG;
+    StepDesc* d_desc = reinterpret_cast<StepDesc*>(d_workspace);
+    Workspace ws = carve(reinterpret_cast<char*>(d_workspace) + 256, NP, L, false, DEFAULT_MODES, n);
+    if (ws.total_bytes + 256 > workspace_bytes) return BLSW_ERR_WORKSPACE;
+    Group gp = direct_group(n, n_pairs, msg_len, L, d_desc, ws);  // per-pair work: N = n * n_pairs lanes
+    Group gs = direct_group(n, 1, msg_len, L, d_desc, ws);        // per-signature work: N = n lanes
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream_);
+    StepDesc h = {d_pks_xy, d_sig_xy, d_msgs, d_witness, witness_stride, d_result, nullptr, nullptr, nullptr};
+    if (int rc = put_desc(d_desc, h, st)) return rc;
+    const unsigned p1 = (unsigned)((NP + 63) / 64), p2 = (unsigned)((2 * NP + 63) / 64), s1 = (unsigned)((n + 63) / 64);
+    hipLaunchKernelGGL(k_g1, dim3(p1), dim3(64), 0, st, gp);
+    hipLaunchKernelGGL(k_g2_alloc, dim3(s1), dim3(64), 0, st, gs);
+    hipLaunchKernelGGL(k_prepare, dim3(s1), dim3(64), 0, st, gs, 1);
+    hipLaunchKernelGGL(k_sha, dim3(p1), dim3(64), 0, st, gp, d_witness ? 1 : 0, 1);
+    if (d_witness) {
+        // blockIdx.y = flat (instance, pair); grid.y <= 65535: several launches for larger batches
+        const unsigned bx = (L.sha_bits + BLSW_EXPAND_EPI * BLSW_EXPAND_ITERS - 1) / (BLSW_EXPAND_EPI * BLSW_EXPAND_ITERS);
+        for (uint64_t first = 0; first < NP; first += (65535 / n_pairs) * (uint64_t)n_pairs) {
+            const uint64_t cnt = NP - first < (65535 / n_pairs) * (uint64_t)n_pairs ? NP - first : (65535 / n_pairs) * (uint64_t)n_pairs;
+            hipLaunchKernelGGL(k_sha_expand<0>, dim3(bx, (unsigned)cnt), dim3(BLSW_EXPAND_THREADS), 0, st, ws.bits, ws.sha_words, first, L.sha_bits, L.off_expand,
+                               d_witness + (first / n_pairs) * witness_stride * 6, witness_stride, n_pairs, L.stride_hash);
+        }
+    }
+    hipLaunchKernelGGL(k_map, dim3(p2), dim3(64), 0, st, gp);
+    hipLaunchKernelGGL(k_cofactor, dim3(p1), dim3(64), 0, st, gp);
+    hipLaunchKernelGGL(k_prepare, dim3(p1), dim3(64), 0, st, gp, 0);
+    hipLaunchKernelGGL(k_pairing_team_multi, dim3((unsigned)((n + BLSW_TEAMS_PER_WAVE - 1) / BLSW_TEAMS_PER_WAVE)), dim3(64), 0, st, gs, n_pairs, NP);
+    return hip_ok(hipGetLastError(), "launch");
+}
+
 int blsw_decode_batch(const uint8_t* d_pk48, const uint8_t* d_sig96, uint64_t n, uint64_t* d_pk_xy, uint64_t* d_sig_xy, int32_t* d_status, void* stream_) {
-    if (!d_pk48 || !d_sig96 || !d_pk_xy || !d_sig_xy || !d_status || n == 0) return BLSW_ERR_ARG;
+    if (!d_pk48 || !d_sig96 || !d_pk_xy || !d_sig_xy || !d_status || n == 0 || n > 0x3fffffffu) return BLSW_ERR_ARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream_);
     hipLaunchKernelGGL(k_decode, dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, st, d_pk48, d_sig96, n, d_pk_xy, d_sig_xy, d_status);
     return hip_ok(hipGetLastError(), "launch");
 }
 int blsw_hash_to_g2_workspace_bytes(uint64_t n, uint32_t msg_len, uint64_t* bytes) {
-    if (!bytes || n == 0) return BLSW_ERR_ARG;
+    if (!bytes || n == 0 || msg_len > 65535) return BLSW_ERR_ARG;
     blsw_layout_t L;
     make_layout(msg_len, &L);
-    *bytes = carve(nullptr, n, L, false).total_bytes + 256;
+    *bytes = carve(nullptr, n, L, false, DEFAULT_MODES).total_bytes + 256;
     return BLSW_OK;
 }
 
-// which = 0: v_mad_u64_u32 issue rate (result in multiply-adds/s); which = 1: fp_mul rate (Fp products/s). Synchronous.
+// which = 0: v_mad_u64_u32 issue rate (multiply-adds/s); 1: fp_mul (Fp products/s); 2: fp_inv (inversions/s); 3: Fp products/s inside
+// witness-emitting Fp2 mul + sqr. Synchronous, on the current device.
 int blsw_microbench(int which, uint32_t iters, uint32_t blocks, double* ops_per_s) {
-    if (!ops_per_s || iters == 0 || blocks == 0) return BLSW_ERR_ARG;
+    if (!ops_per_s || iters == 0 || blocks == 0 || which < 0 || which > 3) return BLSW_ERR_ARG;
     uint32_t* d = nullptr;
-    if (hip_ok(hipMalloc(&d, 4), "malloc")) return BLSW_ERR_HIP;
-    hipEvent_t e0, e1;
-    hipEventCreate(&e0);
-    hipEventCreate(&e1);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = hip_ok(hipMalloc(&d, 4), "malloc");
+    if (!rc) rc = hip_ok(hipEventCreate(&e0), "event create");
+    if (!rc) rc = hip_ok(hipEventCreate(&e1), "event create");
     const int threads = which == 0 ? 256 : 64;
     const double per_iter[4] = {8.0, 2.0, 1.0, 5.0};  // MADs, fp products, fp inversions, fp products (one Fp2 mul + one Fp2 sqr)
-    if (which < 0 || which > 3) return BLSW_ERR_ARG;
-    for (int rep = 0; rep < 2; rep++) {  // first pass warms up
+    for (int rep = 0; rep < 2 && !rc; rep++) {        // first pass warms up
         hipEventRecord(e0, 0);
         if (which == 0)
             hipLaunchKernelGGL(k_bench_mad, dim3(blocks), dim3(threads), 0, 0, iters, d);
@@ -1101,15 +1419,16 @@ int blsw_microbench(int which, uint32_t iters, uint32_t blocks, double* ops_per_
         else
             hipLaunchKernelGGL(k_bench_fp2mulw, dim3(blocks), dim3(threads), 0, 0, iters, d);
         hipEventRecord(e1, 0);
-        hipEventSynchronize(e1);
+        rc = hip_ok(hipEventSynchronize(e1), "event sync");
     }
-    float ms = 0;
-    hipEventElapsedTime(&ms, e0, e1);
-    double per_lane = per_iter[which] * iters;
-    *ops_per_s = per_lane * blocks * threads / (ms * 1e-3);
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
-    hipFree(d);
-    return hip_ok(hipGetLastError(), "microbench");
+    if (!rc) {
+        float ms = 0;
+        rc = hip_ok(hipEventElapsedTime(&ms, e0, e1), "event elapsed");
+        if (!rc) *ops_per_s = per_iter[which] * iters * blocks * threads / (ms * 1e-3);
+    }
+    if (e0) hipEventDestroy(e0);
+    if (e1) hipEventDestroy(e1);
+    if (d) hipFree(d);
+    return rc;
 }
 }

@@ -23,7 +23,11 @@ enum : uint32_t {
     SEG_IS_ONE = 35,
 };
 
-inline void make_layout(uint32_t msg_len, blsw_layout_t* L, uint32_t n_keys = 0) {
+// n_keys > 0: the aggregate_verify circuit (constraints.rs:378-441). n_pairs > 1: the N+1-pair product (one signature over
+// n_pairs (pk, msg) pairs; every statement of constraints.rs:97-125 becomes a loop over the pairs, allocation order
+// msgs, params, pks, sig as in constraints.rs:335-366). n_pairs == 1 is exactly the single-key circuit.
+inline uint32_t seg_miller(uint32_t n_pairs) { return 62 * 36 + 68 * 30 - 30 + 68 * 38 * n_pairs; }
+inline void make_layout(uint32_t msg_len, blsw_layout_t* L, uint32_t n_keys = 0, uint32_t n_pairs = 1) {
     std::vector<uint8_t> msg(msg_len ? msg_len : 1, 0);
     BitSink s;
     s.init(nullptr, 0);
@@ -41,10 +45,18 @@ inline void make_layout(uint32_t msg_len, blsw_layout_t* L, uint32_t n_keys = 0)
         L->off_bitmap = o;
         o += n_keys;
     }
+    const uint32_t K = n_keys ? 1 : (n_pairs ? n_pairs : 1);
+    L->n_pairs = K;
+    L->stride_msg = 8 * msg_len;
+    L->stride_pk_alloc = SEG_PK_ALLOC;
+    L->stride_pk_not_zero = SEG_PK_NOT_ZERO;
+    L->stride_hash = L->sha_bits + 2 * SEG_MAP + SEG_ADD + SEG_COFACTOR;
+    L->stride_prep_h = SEG_PREP_G2;
+    L->stride_prep_pk = SEG_PREP_PK;
     L->off_msg = o;
-    o += 8 * msg_len;
+    o += 8 * msg_len * K;
     L->off_pk_alloc = o;
-    if (!n_keys) o += SEG_PK_ALLOC;
+    if (!n_keys) o += SEG_PK_ALLOC * K;
     L->off_sig_alloc = o;
     o += SEG_SIG_ALLOC;
     if (n_keys) {
@@ -54,25 +66,22 @@ inline void make_layout(uint32_t msg_len, blsw_layout_t* L, uint32_t n_keys = 0)
         o += 48 * n_keys - 12;
     }
     L->off_pk_not_zero = o;
-    o += SEG_PK_NOT_ZERO;
+    o += SEG_PK_NOT_ZERO * K;
+    // hash_to_g2 of pair j: expand, map0, map1, add, cofactor, contiguous; pair j + 1 follows at + stride_hash
     L->off_expand = o;
-    o += L->sha_bits;
-    L->off_map0 = o;
-    o += SEG_MAP;
-    L->off_map1 = o;
-    o += SEG_MAP;
-    L->off_add = o;
-    o += SEG_ADD;
-    L->off_cofactor = o;
-    o += SEG_COFACTOR;
+    L->off_map0 = L->off_expand + L->sha_bits;
+    L->off_map1 = L->off_map0 + SEG_MAP;
+    L->off_add = L->off_map1 + SEG_MAP;
+    L->off_cofactor = L->off_add + SEG_ADD;
+    o += L->stride_hash * K;
     L->off_prep_h = o;
-    o += SEG_PREP_G2;
+    o += SEG_PREP_G2 * K;
     L->off_prep_pk = o;
-    o += SEG_PREP_PK;
+    o += SEG_PREP_PK * K;
     L->off_prep_sig = o;
     o += SEG_PREP_G2;
     L->off_miller = o;
-    o += SEG_MILLER;
+    o += seg_miller(K);
     L->off_final_exp = o;
     o += SEG_FINAL_EXP;
     L->off_is_one = o;

@@ -202,6 +202,19 @@ BLSW_HD void team_load_coeff_lane(uint32_t j, Fp2* slots, const C& coeff_sig, co
     if (j == 2) team_st(slots, TS_XH0, {coeff_h.ld(4 * k + 0), coeff_h.ld(4 * k + 1)});
     if (j == 3) team_st(slots, TS_XH1, {coeff_h.ld(4 * k + 2), coeff_h.ld(4 * k + 3)});
 }
+// N+1-pair product: the sig pair's coefficients (lanes 0, 1) and pair j's coefficients + prepared key (lanes 2..5)
+template <class C>
+BLSW_HD void team_load_coeff_sig_lane(uint32_t j, Fp2* slots, const C& coeff_sig, uint32_t k) {
+    if (j == 0) team_st(slots, TS_XS0, {coeff_sig.ld(4 * k + 0), coeff_sig.ld(4 * k + 1)});
+    if (j == 1) team_st(slots, TS_XS1, fp2_mul_fp({coeff_sig.ld(4 * k + 2), coeff_sig.ld(4 * k + 3)}, K_G1_GEN_X()));
+}
+template <class C>
+BLSW_HD void team_load_pair_lane(uint32_t j, Fp2* slots, const C& coeff_h, uint32_t k, const Fp& pkx, const Fp& pky) {
+    if (j == 2) team_st(slots, TS_XH0, {coeff_h.ld(4 * k + 0), coeff_h.ld(4 * k + 1)});
+    if (j == 3) team_st(slots, TS_XH1, {coeff_h.ld(4 * k + 2), coeff_h.ld(4 * k + 3)});
+    if (j == 4) team_st(slots, TS_XYV, {pky, fp_zero()});
+    if (j == 5) team_st(slots, TS_XPX, {pkx, fp_zero()});
+}
 BLSW_HD void team_set_consts_lane(uint32_t j, Fp2* slots, const Fp& pkx, const Fp& pky) {
     if (j == 0) team_st(slots, TS_XYC, {K_G1_GEN_NEG_Y(), fp_zero()});
     if (j == 1) team_st(slots, TS_XYV, {pky, fp_zero()});
@@ -232,6 +245,35 @@ BLSW_HD typename TEAM::Reg team_miller(TEAM& t) {
             const TeamOp& T = ph == 0 ? TEAM_OP_SQR : ((ph & 1) ? TEAM_OP_ELLC : TEAM_OP_ELLV);
             f = t.exec_hot(T, f, f);
             if (ph == 2 || ph == 4) k++;
+        }
+    }
+    return t.conj(f);
+}
+// miller_loop over K + 1 pairs: (-g1 constant, sig) and (pk_j, H(m_j)), j = 0..K-1 — PairingVar::miller_loop on slices
+// (constraints.rs:121-125). Per bit: f^2, then one ell per pair in slice order; the addition step repeats the ells.
+// TEAM additionally provides load_coeff_sig(k) and load_pair(j, k) (line coefficients of H(m_j) at step k and pk_j).
+template <class TEAM>
+BLSW_HD typename TEAM::Reg team_miller_multi(TEAM& t, uint32_t K) {
+    typename TEAM::Reg f = t.zero();
+    uint32_t k = 0;
+#pragma unroll 1
+    for (int i = 62; i >= 0; i--) {
+        const int reps = ((BLSW_X_ABS >> i) & 1) ? 2 : 1;
+#pragma unroll 1
+        for (int rep = 0; rep < reps; rep++) {
+            // phases of one line-coefficient index k: 0 square (doubling step only), 1 ell(-g1, sig), 2 + j ell(pk_j, H_j)
+#pragma unroll 1
+            for (uint32_t ph = (rep == 0 && i != 62) ? 0u : 1u; ph < 2 + K; ph++) {
+                if (ph == 1) t.load_coeff_sig(k);
+                if (ph >= 2) t.load_pair(ph - 2, k);
+                if (i == 62 && rep == 0 && ph == 1) {
+                    f = t.first_f();  // f = 1 is a constant: the first ell is a linear combination
+                    continue;
+                }
+                const TeamOp& T = ph == 0 ? TEAM_OP_SQR : (ph == 1 ? TEAM_OP_ELLC : TEAM_OP_ELLV);
+                f = t.exec_hot(T, f, f);
+            }
+            k++;
         }
     }
     return t.conj(f);

@@ -25,7 +25,7 @@ def all_gather_results(local_results, n_total, group=None):
     return torch.cat([parts[r][: hi - lo] for r, (lo, hi) in enumerate(sizes)])
 
 
-def all_gather_witness_chunk(local_chunk, group=None):
+def all_gather_witness_chunk(local_chunk, group=None, out=None):
     """RCCL all-gather of one equal-sized witness micro-batch chunk ([m, k, 6] int64 per rank -> [world*m, k, 6]).
     The full gathered witness (n x 34 MB) does not fit one GPU at config-3 scale, so callers gather micro-batches
     and hand each to its consumer before the next."""
@@ -33,6 +33,8 @@ def all_gather_witness_chunk(local_chunk, group=None):
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
-    out = torch.empty((world * local_chunk.shape[0],) + tuple(local_chunk.shape[1:]), dtype=local_chunk.dtype, device=local_chunk.device)
+    if out is None:
+        out = torch.empty((world * local_chunk.shape[0],) + tuple(local_chunk.shape[1:]), dtype=local_chunk.dtype, device=local_chunk.device)
+    assert out.shape[0] == world * local_chunk.shape[0] and out.is_contiguous()
     dist.all_gather_into_tensor(out, local_chunk.contiguous(), group=group)
     return out

@@ -6,11 +6,13 @@
  *     AllocVar for ParametersVar / PublicKeyVar / SignatureVar                         src/constraints.rs:194-249
  *     hash_to_g2_with_cons(cs, &[UInt8]) -> G2Var                                      src/hasher.rs:727-740
  * and the data an arkworks prover consumes from it is ConstraintSystem::witness_assignment (Vec<Fq>, Montgomery
- * form, allocation order). These entry points replace exactly that side effect, batched over instances; they are
- * what a Rust `extern "C"` shim binds.
+ * form, allocation order) plus the constraint matrices of cs.to_matrices(). These entry points replace exactly that
+ * side effect, batched over instances; they are what a Rust `extern "C"` shim binds.
+ * tests/test_abi_contract.py parses THIS file and fails when INTEGRATION.md's Rust block, the ctypes binding or the
+ * library's exports drift from it.
  *
  * Conventions: caller-allocated buffers, integer return codes (0 = ok), no exceptions across the ABI,
- * re-entrant per (device, stream). All `d_*` pointers are DEVICE pointers on the current HIP device.
+ * re-entrant per (device, stream). All `d_*` pointers are DEVICE pointers on the engine's / current HIP device.
  * A field element is 6 little-endian u64 limbs in Montgomery form (R = 2^384) == arkworks' in-memory Fq.
  */
 #ifndef BLSW_H
@@ -20,11 +22,14 @@
 extern "C" {
 #endif
 
+#define BLSW_ABI_VERSION 5
+
 #define BLSW_OK 0
 #define BLSW_ERR_ARG 1
 #define BLSW_ERR_WORKSPACE 2
 #define BLSW_ERR_HIP 3
 #define BLSW_ERR_NO_DEVICE 4
+#define BLSW_ERR_SCRATCH 5 /* the requested mode / n_buffers combination would exhaust the runtime's per-queue scratch */
 
 /* per-instance input status (mirrors src/bls.rs:434-447 and the deserialization fixtures) */
 #define BLSW_ST_OK 0
@@ -32,18 +37,24 @@ extern "C" {
 #define BLSW_ST_NOT_ON_CURVE 2
 #define BLSW_ST_NOT_IN_SUBGROUP 3
 #define BLSW_ST_IDENTITY 4
+#define BLSW_ST_INVALID_SECRET_KEY 5
 
 /* Segment table of one instance's witness vector for the circuit of src/constraints.rs:335-366
- * (msg witness bytes, params Constant, pk Witness, sig Witness, then verify). Offsets are in field elements. */
+ * (msg witness bytes, params Constant, pk Witness, sig Witness, then verify). Offsets are in field elements.
+ * 31 uint32_t fields; the Rust mirror in INTEGRATION.md must have the same fields in the same order. */
 typedef struct {
     uint32_t msg_len;
     uint32_t n_instance_vars; /* 1: the constant one (this gadget allocates no public input) */
     uint32_t n_witness;       /* witness_assignment length */
-    uint32_t sha_bits;        /* boolean witnesses of the expand_message segment (16 lib_str bits + SHA-256 gadget) */
+    uint32_t sha_bits;        /* boolean witnesses of ONE expand_message segment (16 lib_str bits + SHA-256 gadget) */
     uint32_t off_msg, off_pk_alloc, off_sig_alloc, off_pk_not_zero, off_expand, off_map0, off_map1, off_add, off_cofactor, off_prep_h, off_prep_pk,
         off_prep_sig, off_miller, off_final_exp, off_is_one;
     /* aggregate_verify circuits (src/constraints.rs:378-441); all zero for the single-key circuit (then off_pk_alloc is used) */
     uint32_t n_keys, off_keys, off_bitmap, off_count, off_agg;
+    /* N+1-pair product (blsw_layout_multi): the segments msg, pk_alloc, pk_not_zero, {expand, map0, map1, add, cofactor},
+     * prep_h and prep_pk exist once per (pk, msg) pair; pair j's copy starts at off_* + j * stride_*. n_pairs = 1 and
+     * strides = segment lengths for the single-key and aggregate circuits. */
+    uint32_t n_pairs, stride_msg, stride_pk_alloc, stride_pk_not_zero, stride_hash, stride_prep_h, stride_prep_pk;
 } blsw_layout_t;
 
 /* layout(circuit shape) — replaces reading cs.num_witness_variables() after synthesis (constraints.rs:369-373). Host only. */
@@ -61,19 +72,52 @@ int blsw_aggregate_verify_batch(const uint64_t* d_pks_xy, const uint8_t* d_bitma
                                 uint32_t msg_len, uint64_t n, uint64_t* d_witness, uint64_t witness_stride, int32_t* d_result, uint32_t* d_count,
                                 void* d_workspace, uint64_t workspace_bytes, void* stream);
 
+/* N+1-pair product of pairings: ONE signature over n_pairs (pk_j, msg_j) pairs,
+ *     e(-g1, sig) * prod_j e(pk_j, H(msg_j)) == 1
+ * i.e. BlsSignatureVerifyGadget::verify (src/constraints.rs:90-128) with every per-key statement turned into a loop over the
+ * pairs and PairingVar::product_of_pairings called on slices of n_pairs + 1 prepared points (constraints.rs:121-125 passes
+ * slices of 2). The reference has no such entry; n_pairs == 1 reproduces the single-key witness vector
+ * bit for bit. Circuit allocation order: msg_0..msg_{K-1} witness bytes, params Constant, pk_0..pk_{K-1} Witness, sig Witness.
+ *   d_pks_xy [n][n_pairs][12], d_msgs [n][n_pairs][msg_len], d_sig_xy [n][24]
+ *   d_witness [n][witness_stride] (may be NULL), d_result [n] int32
+ * Direct mode, asynchronous on `stream`. */
+int blsw_layout_multi(uint32_t msg_len, uint32_t n_pairs, blsw_layout_t* out);
+int blsw_verify_multi_workspace_bytes(uint64_t n, uint32_t msg_len, uint32_t n_pairs, uint64_t* bytes);
+int blsw_verify_multi_batch(const uint64_t* d_pks_xy, const uint8_t* d_msgs, uint32_t msg_len, uint32_t n_pairs, const uint64_t* d_sig_xy, uint64_t n,
+                            uint64_t* d_witness, uint64_t witness_stride, int32_t* d_result, void* d_workspace, uint64_t workspace_bytes, void* stream);
+
 /* Execution engine. Batches of n instances are SUBMITTED with their input / output pointers and processed in groups
  * of up to max_steps batches by one set of kernel launches (one batch of 1024 instances is only 16 wavefronts per
- * chain; a group of 32 batches fills the 1024 SIMDs of an MI355X). max_steps == 1 is the direct mode: the chains
- * write every witness in place. With max_steps > 1 field witnesses are staged element-major (coalesced stores) and
- * each batch's witness tensor is then written, in submission order, by the streaming placement kernels.
- * n_buffers groups can be in flight at once (each with its own streams and workspace slice). Keep
- * max_steps * n / 64 wavefronts * the largest per-lane stack (11 KB) under the runtime's 140 MB per-dispatch scratch
- * limit (max_steps <= 8 for n = 1024): larger dispatches fall into ROCr's allocate-per-dispatch scratch path.
- * The caller owns the device workspace (blsw_engine_workspace_bytes). One engine per device; not thread-safe. */
+ * chain; a group of 16 batches fills a quarter of the 1024 SIMDs of an MI355X per chain kernel and several chains and
+ * groups run side by side). max_steps == 1 with n_buffers == 1 is the direct mode: the chains write every witness in
+ * place. Otherwise field witnesses are staged (coalesced stores) and each batch's witness tensor is written, in
+ * submission order, by two streaming kernels on their own streams: the SHA-256 boolean segment (93 % of the bytes) as
+ * soon as the batch's SHA witness bits exist — it does not wait for the curve / pairing chains — and the field segments
+ * when the group's chains have finished. n_buffers groups can be in flight at once (each with its own streams and
+ * workspace slice). The caller owns the device workspace (blsw_engine_workspace_bytes). Every entry point switches to
+ * the engine's device for the duration of the call. One engine per device; not thread-safe.
+ * Largest per-lane stack of the default kernels: 4.6 KB (the Fp12 inversion hint of the six-lane pairing kernel). */
 typedef struct blsw_engine blsw_engine_t;
+typedef struct {
+    int32_t device;        /* HIP device ordinal, -1 = the current device */
+    uint32_t pairing_mode; /* 0 = six lanes per instance (default), 1 = one lane per instance (9.7 KB stack: A/B runs only) */
+    uint32_t g2_mode;      /* 0 = one lane per instance (default), 1 = six lanes per instance (needs pairing_mode 0) */
+    uint32_t expand_store; /* stores of the SHA expansion kernel: 0 plain (default), 1 nontemporal, 2 sc1, 3 sc0 sc1 */
+    uint32_t prio_mode;    /* stream priorities: 0 chains high, 1 placement high (default), 2 equal */
+    uint32_t place_lds;    /* optional occupancy limiter of the expansion kernel: bytes of dynamic LDS per workgroup */
+} blsw_engine_options_t;
+/* defaults; the environment variables BLSW_PAIRING=lane, BLSW_G2=team, BLSW_EXPAND_NT, BLSW_PRIO_MODE, BLSW_PLACE_LDS override
+ * them HERE (read at every call, nothing is cached per process), so A/B runs need no recompilation */
+int blsw_engine_options_default(blsw_engine_options_t* out);
 int blsw_engine_workspace_bytes(uint64_t n, uint32_t msg_len, uint32_t max_steps, uint32_t n_buffers, uint64_t* bytes);
+/* blsw_engine_create = blsw_engine_create_ex with blsw_engine_options_default. Returns BLSW_ERR_SCRATCH (nothing is
+ * allocated) when pairing_mode 1 is combined with so many group buffers that the runtime's per-queue scratch
+ * (stack bytes x 64 lanes x wave slots of the device, per queue) would exceed what ROCr can back: that combination
+ * used to abort the process with HSA_STATUS_ERROR_OUT_OF_RESOURCES. */
 int blsw_engine_create(blsw_engine_t** out, uint64_t n, uint32_t msg_len, uint32_t max_steps, uint32_t n_buffers, void* d_workspace,
                        uint64_t workspace_bytes);
+int blsw_engine_create_ex(blsw_engine_t** out, uint64_t n, uint32_t msg_len, uint32_t max_steps, uint32_t n_buffers, const blsw_engine_options_t* options,
+                          void* d_workspace, uint64_t workspace_bytes);
 int blsw_engine_destroy(blsw_engine_t* e);
 
 /* Submits one batch of n independent (pk, msg, sig) instances: the witness vectors of the circuit of
@@ -84,14 +128,32 @@ int blsw_engine_destroy(blsw_engine_t* e);
  *   d_witness [n][witness_stride] field elements (48 B each), witness_stride >= layout.n_witness; may be NULL (results only)
  *   d_result  [n] int32, may be NULL
  * Device work is issued when max_steps batches are pending or at blsw_engine_flush; `stream` (hipStream_t, may be NULL)
- * is the stream on which the inputs become valid. Buffers must stay alive until the flush has completed. */
+ * is the stream on which THIS batch's inputs become valid (recorded per submit). Buffers must stay alive until the
+ * step has completed. Steps are numbered 0, 1, 2, ... in submission order (blsw_engine_submitted). */
 int blsw_engine_submit(blsw_engine_t* e, const uint64_t* d_pk_xy, const uint64_t* d_sig_xy, const uint8_t* d_msg, uint64_t* d_witness,
                        uint64_t witness_stride, int32_t* d_result, void* stream);
 /* Issues everything pending and makes `stream` wait for all batches submitted so far (asynchronous for the host). */
 int blsw_engine_flush(blsw_engine_t* e, void* stream);
+/* Streaming consumers (a prover draining witness tensors through a small ring of output buffers):
+ *   blsw_engine_submitted / _launched: number of steps submitted / already issued to the device;
+ *   blsw_engine_wait_step: makes `stream` wait until step `seq` (< launched) has written its witness tensor and results;
+ *   blsw_engine_output_consumed: records on `stream` that the consumer is done with the tensor at d_witness; the next
+ *   step submitted with the same d_witness pointer does not overwrite it before that point. */
+int blsw_engine_submitted(blsw_engine_t* e, uint64_t* seq);
+int blsw_engine_launched(blsw_engine_t* e, uint64_t* seq);
+int blsw_engine_wait_step(blsw_engine_t* e, uint64_t seq, void* stream);
+int blsw_engine_output_consumed(blsw_engine_t* e, const uint64_t* d_witness, void* stream);
 /* average duration (ms) of the bit->Fp expansion kernel launches issued since the previous call (HIP events on the stream they
  * ran on, at most 1024 launches); blocks until they have finished and resets the statistics */
 int blsw_engine_expand_stats(blsw_engine_t* e, uint32_t* count, float* avg_ms);
+
+/* Position-dependent, order-independent 128-bit digest of each instance's witness vector (the consumer-side check of the
+ * sharded runs): with w_k the k-th little-endian u64 word of the instance's n_witness * 6 words,
+ *     d[c] = sum_k mix64(w_k + (k + 1) * C_c)  mod 2^64,  c = 0, 1,  mix64 = the splitmix64 finalizer
+ *     (z ^= z >> 30; z *= 0xBF58476D1CE4E5B9; z ^= z >> 27; z *= 0x94D049BB133111EB; z ^= z >> 31),
+ *     C = {0x9E3779B97F4A7C15, 0xC2B2AE3D27D4EB4F}.
+ *   d_witness [n][witness_stride] elements, d_digest [n][2] u64. Reads the tensor once at HBM speed. */
+int blsw_witness_digest(const uint64_t* d_witness, uint64_t witness_stride, uint64_t n, uint32_t n_witness, uint64_t* d_digest, void* stream);
 
 /* Input decode (PublicKey::try_from / Signature::try_from -> deserialize_compressed, src/bls.rs:219-242, 316-339):
  *   d_pk48 [n][48], d_sig96 [n][96]  ZCash-format compressed points
@@ -114,12 +176,12 @@ int blsw_hash_to_g2_batch(const uint8_t* d_msg, uint32_t msg_len, uint64_t n, ui
  *   d_status [n] int32: BLSW_ST_OK, BLSW_ST_BAD_ENCODING (sk >= r) or BLSW_ST_INVALID_SECRET_KEY (sk = 0); on error
  *   the outputs of that instance are the identity encoding / zeros.
  * Workspace: blsw_hash_to_g2_workspace_bytes(n, msg_len). */
-#define BLSW_ST_INVALID_SECRET_KEY 5
 int blsw_sign_batch(const uint8_t* d_sk32_le, const uint8_t* d_msg, uint32_t msg_len, uint64_t n, uint8_t* d_sig96, uint64_t* d_sig_xy, uint8_t* d_pk48,
                     uint64_t* d_pk_xy, int32_t* d_status, void* d_workspace, uint64_t workspace_bytes, void* stream);
 
 /* Device micro-benchmarks that give the VALU roofline its MEASURED denominator:
- * which = 0: v_mad_u64_u32 rate (32x32+64 multiply-adds per second, all CUs); which = 1: Fp Montgomery products per second. */
+ * which = 0: v_mad_u64_u32 rate (32x32+64 multiply-adds per second, all CUs); 1: Fp Montgomery products per second;
+ * 2: Fp inversions (safegcd) per second; 3: Fp products per second inside witness-emitting Fp2 mul + sqr. */
 int blsw_microbench(int which, uint32_t iters, uint32_t blocks, double* ops_per_s);
 
 int blsw_version(void);

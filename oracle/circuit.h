@@ -585,6 +585,52 @@ inline Bool bls_verify_circuit(const G1Aff& pk, const uint8_t* msg, size_t msg_l
 }
 
 
+// ------------------------------------------------------------------ N+1-pair product (BASELINE configs[3])
+// One signature over K (pk_j, msg_j) pairs: e(-g1, sig) * prod_j e(pk_j, H(msg_j)) == 1. The reference has no such
+// function; this is constraints.rs:90-128 with every per-key statement turned into a loop over the pairs, in the same
+// statement order, and product_of_pairings called on slices of K + 1 prepared points (constraints.rs:121-125 passes
+// slices of 2; miller_loop above already takes slices). K == 1 is bls_verify_gadget statement for statement.
+inline Bool bls_verify_multi_gadget(const G1Var& g1_generator, const std::vector<G1Var>& pks, const std::vector<std::vector<U8>>& messages,
+                                    const G2Var& sig) {
+    assert(pks.size() == messages.size() && !pks.empty());
+    CSREF.mark("verify.pk_not_zero");
+    for (auto& pk : pks) pv_enforce_not_equal<FpT>(pk, pv_zero<FpT>());
+    G1Var g1_neg = pv_negate<FpT>(g1_generator);
+    std::vector<G2Var> hs;
+    for (auto& m : messages) hs.push_back(hash_to_g2_with_cons(m));
+    CSREF.mark("prepare.g1_neg");
+    std::vector<G1Prepared> ps;
+    std::vector<G2Prepared> qs(1);
+    ps.push_back(g1_prepare(g1_neg));
+    CSREF.mark("prepare.h");
+    for (auto& h : hs) qs.push_back(g2_prepare(h));
+    CSREF.mark("prepare.pk");
+    for (auto& pk : pks) ps.push_back(g1_prepare(pk));
+    CSREF.mark("prepare.sig");
+    qs[0] = g2_prepare(sig);
+    CSREF.mark("miller");
+    Fp12Var ml = miller_loop(ps, qs);
+    CSREF.mark("final_exp");
+    Fp12Var fe = final_exponentiation(ml);
+    CSREF.mark("is_one");
+    Bool res = f12is_eq(fe, f12one());
+    CSREF.mark("end");
+    return res;
+}
+// allocation order of constraints.rs:335-366 with K messages and K keys: msgs, params Constant, pks Witness, sig Witness
+inline Bool bls_verify_multi_circuit(const std::vector<G1Aff>& pks, const uint8_t* msgs, size_t msg_len, const G2Aff& sig) {
+    CSREF.mark("msg");
+    std::vector<std::vector<U8>> msg_vars;
+    for (size_t j = 0; j < pks.size(); j++) msg_vars.push_back(u8witness_vec(msgs + j * msg_len, msg_len));
+    G1Var g1 = pv_constant<FpT>(g1_generator());
+    CSREF.mark("pk_alloc");
+    std::vector<G1Var> pk_vars;
+    for (auto& pk : pks) pk_vars.push_back(g1_new_witness(pk));
+    CSREF.mark("sig_alloc");
+    G2Var sig_var = g2_new_witness(sig);
+    return bls_verify_multi_gadget(g1, pk_vars, msg_vars, sig_var);
+}
+
 // ------------------------------------------------------------------ aggregate_verify (constraints.rs:153-191)
 inline U32 u32witness(uint32_t v) {
     U32 r;

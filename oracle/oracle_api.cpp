@@ -367,6 +367,33 @@ uint64_t orc_witness_aggregate(const uint64_t* pks_xy, const uint8_t* bitmap, ui
     }
     return n;
 }
+// N+1-pair product circuit: pks_xy [k][12], msgs [k][msg_len], one signature. Marks as orc_witness_aggregate.
+uint64_t orc_witness_multi(const uint64_t* pks_xy, const uint8_t* msgs, size_t msg_len, uint64_t k, const uint64_t* sig_xy, uint64_t* out_witness,
+                           uint64_t out_capacity_elems, uint64_t* n_constraints, int* result, uint64_t* mark_starts, uint64_t mark_cap, char* names_buf,
+                           size_t names_cap) {
+    ValueScope s;
+    std::vector<G1Aff> pks;
+    for (uint64_t i = 0; i < k; i++) pks.push_back(limbs_to_aff1(pks_xy + 12 * i));
+    Bool r = bls_verify_multi_circuit(pks, msgs, msg_len, limbs_to_aff2(sig_xy));
+    if (result) *result = r.val;
+    if (n_constraints) *n_constraints = s.cs.ncons;
+    uint64_t n = s.cs.wit.size();
+    if (out_witness) memcpy(out_witness, s.cs.wit.data(), std::min(n, out_capacity_elems) * 48);
+    std::string names;
+    uint64_t j = 0;
+    for (auto& m : s.cs.marks) {
+        if (mark_starts && j < mark_cap) mark_starts[j] = m.second;
+        names += m.first;
+        names += '\n';
+        j++;
+    }
+    if (names_buf && names_cap) {
+        size_t c = std::min(names.size(), names_cap - 1);
+        memcpy(names_buf, names.data(), c);
+        names_buf[c] = 0;
+    }
+    return n;
+}
 // record the full R1CS for the instance and check A z o B z = C z against a witness vector.
 // witness == null: use the oracle's own. Returns the index of the first unsatisfied constraint, or -1.
 int64_t orc_check_satisfied(const uint64_t* pk_xy, const uint8_t* msg, size_t msg_len, const uint64_t* sig_xy, const uint64_t* witness,

@@ -65,6 +65,16 @@ struct TeamHost {
         for (uint32_t j = 0; j < 6; j++) r[j] = team_first_f(j, slots);
         return r;
     }
+    // N+1-pair product: per-pair inputs
+    const std::vector<std::vector<Fp>>* pair_coeff = nullptr;
+    const std::vector<G1ChainOut>* pair_pk = nullptr;
+    void load_coeff_sig(uint32_t k) {
+        for (uint32_t j = 0; j < 6; j++) team_load_coeff_sig_lane(j, slots, coeff_sig, k);
+    }
+    void load_pair(uint32_t jp, uint32_t k) {
+        CoeffLinear c{const_cast<Fp*>((*pair_coeff)[jp].data())};
+        for (uint32_t j = 0; j < 6; j++) team_load_pair_lane(j, slots, c, k, (*pair_pk)[jp].ax, (*pair_pk)[jp].ay);
+    }
     Reg inverse_w(const Reg& a) {
         for (uint32_t j = 0; j < 6; j++) team_st(slots, TS_IN0 + j, a[j]);
         team_inverse_lane0(slots);
@@ -170,6 +180,71 @@ int hostsim_witness(const uint64_t* pk_xy, const uint8_t* msg, uint32_t msg_len,
     bool res = pairing_segment(base, L, g1.ax, g1.ay, cs.data(), ch.data());
     (void)seg_ends;
     return res ? 1 : 0;
+}
+// N+1-pair product circuit for one instance (blsw_verify_multi_batch): pks_xy [K][12], msgs [K][msg_len]
+struct HostPairs {
+    const std::vector<std::vector<Fp>>* coeff;
+    const std::vector<G1ChainOut>* keys;
+    void pk(uint32_t j, Fp& x, Fp& y) const {
+        x = (*keys)[j].ax;
+        y = (*keys)[j].ay;
+    }
+    CoeffLinear coeff_h(uint32_t j) const { return CoeffLinear{const_cast<Fp*>((*coeff)[j].data())}; }
+};
+int hostsim_witness_multi(const uint64_t* pks_xy, const uint8_t* msgs, uint32_t msg_len, uint32_t K, const uint64_t* sig_xy, uint64_t* out, blsw_layout_t* Lout) {
+    blsw_layout_t L;
+    make_layout(msg_len, &L, 0, K);
+    if (Lout) *Lout = L;
+    if (!out) return 0;
+    uint32_t* base = reinterpret_cast<uint32_t*>(out);
+    std::vector<G1ChainOut> pk(K);
+    std::vector<std::vector<Fp>> ch(K, std::vector<Fp>(68 * 4));
+    for (uint32_t j = 0; j < K; j++) {
+        const uint8_t* msg = msgs + (size_t)j * msg_len;
+        Emitter em = {base, L.off_msg + j * L.stride_msg};
+        for (uint32_t i = 0; i < msg_len; i++)
+            for (int b = 0; b < 8; b++) em.put_bool((msg[i] >> b) & 1);
+        pk[j] = chain_g1_alloc({base, L.off_pk_alloc + j * L.stride_pk_alloc}, {base, L.off_pk_not_zero + j * L.stride_pk_not_zero},
+                               {base, L.off_prep_pk + j * L.stride_prep_pk}, load_fp(pks_xy + 12 * j), load_fp(pks_xy + 12 * j + 6));
+        std::vector<uint32_t> bits((L.sha_bits + 31) / 32 + 1, 0);
+        BitSink s;
+        s.init(bits.data(), 1);
+        uint32_t uw[64];
+        expand_message_w(s, msg, msg_len, false, uw);
+        if (s.nbits != L.sha_bits) return -1;
+        const uint32_t ho = j * L.stride_hash;
+        Emitter ex = {base, L.off_expand + ho};
+        for (uint32_t i = 0; i < L.sha_bits; i++) ex.put_bool((bits[i >> 5] >> (i & 31)) & 1);
+        Fp2 u0 = {hash_to_field_elem(uw), hash_to_field_elem(uw + 16)};
+        Fp2 u1 = {hash_to_field_elem(uw + 32), hash_to_field_elem(uw + 48)};
+        Proj<OpsFp2> q0 = chain_map_to_curve({base, L.off_map0 + ho}, u0);
+        Proj<OpsFp2> q1 = chain_map_to_curve({base, L.off_map1 + ho}, u1);
+        Proj<OpsFp2> h = chain_cofactor({base, L.off_add + ho}, {base, L.off_cofactor + ho}, q0, q1);
+        chain_prepare_g2({base, L.off_prep_h + j * L.stride_prep_h}, h, CoeffLinear{ch[j].data()});
+    }
+    Fp2 sx = {load_fp(sig_xy), load_fp(sig_xy + 6)}, sy = {load_fp(sig_xy + 12), load_fp(sig_xy + 18)};
+    g2_alloc_segment(base, L, sx, sy);
+    std::vector<Fp> cs(68 * 4);
+    bool sinf = fp2_is_zero(sx) && fp2_is_zero(sy);
+    Proj<OpsFp2> sp = {sinf ? fp2_zero() : sx, sinf ? fp2_one() : sy, sinf ? fp2_zero() : fp2_one()};
+    chain_prepare_g2({base, L.off_prep_sig}, sp, CoeffLinear{cs.data()});
+    if (!g_use_team) {
+        HostPairs hp = {&ch, &pk};
+        Fp12 fm = chain_miller_multi({base, L.off_miller}, K, hp, CoeffLinear{cs.data()});
+        return chain_final_exp_is_one({base, L.off_final_exp}, {base, L.off_is_one}, fm) ? 1 : 0;
+    }
+    TeamHost t;
+    t.coeff_sig = CoeffLinear{cs.data()};
+    t.coeff_h = CoeffLinear{nullptr};
+    t.pair_coeff = &ch;
+    t.pair_pk = &pk;
+    t.e = {base, L.off_miller};
+    team_st(t.slots, TS_XYC, {K_G1_GEN_NEG_Y(), fp_zero()});
+    TeamHost::Reg f = team_miller_multi(t, K);
+    if (t.e.pos != L.off_final_exp) return -2;
+    bool r = team_final_exp_is_one(t, f, Emitter{base, L.off_is_one});
+    if (t.e.pos != L.off_is_one) return -3;
+    return r ? 1 : 0;
 }
 struct HostKeys {
     const std::vector<Proj<OpsFp>>* v;

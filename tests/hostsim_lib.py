@@ -10,7 +10,8 @@ u64p = ctypes.POINTER(ctypes.c_uint64)
 
 _FIELDS = (
     "msg_len n_instance_vars n_witness sha_bits off_msg off_pk_alloc off_sig_alloc off_pk_not_zero off_expand off_map0 off_map1 "
-    "off_add off_cofactor off_prep_h off_prep_pk off_prep_sig off_miller off_final_exp off_is_one n_keys off_keys off_bitmap off_count off_agg"
+    "off_add off_cofactor off_prep_h off_prep_pk off_prep_sig off_miller off_final_exp off_is_one n_keys off_keys off_bitmap off_count off_agg "
+    "n_pairs stride_msg stride_pk_alloc stride_pk_not_zero stride_hash stride_prep_h stride_prep_pk"
 ).split()
 
 
@@ -59,6 +60,21 @@ def witness_aggregate(pks_xy, bitmap, msg, sig_xy):
     r = load().hostsim_witness_aggregate(pks_xy.ctypes.data_as(u64p), bitmap.ctypes.data_as(u8p), K, buf, len(msg), sig_xy.ctypes.data_as(u64p),
                                          out.ctypes.data_as(u64p), ctypes.byref(cnt), ctypes.byref(L))
     return r, cnt.value, out, {n: getattr(L, n) for n in _FIELDS}
+
+
+def witness_multi(pks_xy, msgs, sig_xy):
+    """N+1-pair product circuit on the host harness: pks_xy [K, 12], msgs [K, msg_len] uint8 -> (result, witness, layout)"""
+    pks_xy = np.ascontiguousarray(pks_xy, dtype=np.uint64)
+    sig_xy = np.ascontiguousarray(sig_xy, dtype=np.uint64)
+    msgs = np.ascontiguousarray(msgs, dtype=np.uint8)
+    K, msg_len = msgs.shape
+    u8p = ctypes.POINTER(ctypes.c_uint8)
+    L = Lay()
+    mp = msgs.ctypes.data_as(u8p) if msg_len else (ctypes.c_uint8 * 1)()
+    load().hostsim_witness_multi(pks_xy.ctypes.data_as(u64p), mp, msg_len, K, sig_xy.ctypes.data_as(u64p), None, ctypes.byref(L))
+    out = np.zeros((L.n_witness, 6), dtype=np.uint64)
+    r = load().hostsim_witness_multi(pks_xy.ctypes.data_as(u64p), mp, msg_len, K, sig_xy.ctypes.data_as(u64p), out.ctypes.data_as(u64p), ctypes.byref(L))
+    return r, out, {n: getattr(L, n) for n in _FIELDS}
 
 
 def sign(sk_le32, h_xy):

@@ -30,6 +30,7 @@ class Oracle:
         self.lib = lib
         lib.orc_witness.restype = ctypes.c_uint64
         lib.orc_witness_aggregate.restype = ctypes.c_uint64
+        lib.orc_witness_multi.restype = ctypes.c_uint64
         lib.orc_layout.restype = ctypes.c_uint64
         lib.orc_check_satisfied.restype = ctypes.c_int64
 
@@ -136,6 +137,27 @@ class Oracle:
             w = np.zeros((n, 6), dtype=np.uint64)
             self.lib.orc_witness_aggregate(*args(w.ctypes.data_as(u64p), n))
         return n, bool(res.value), cnt.value, marks, w
+
+    def witness_multi(self, pks_xy, msgs, sig_xy, want_vector=True):
+        """N+1-pair product circuit: pks_xy [K, 12], msgs [K, msg_len] -> (n_witness, result, marks [(name, start)], witness)"""
+        pks_xy = np.ascontiguousarray(pks_xy, dtype=np.uint64)
+        sig_xy = np.ascontiguousarray(sig_xy, dtype=np.uint64)
+        msgs = np.ascontiguousarray(msgs, dtype=np.uint8)
+        k, msg_len = msgs.shape
+        ncons, res = ctypes.c_uint64(0), ctypes.c_int(0)
+        cap = 16 + 8 * k
+        starts = (ctypes.c_uint64 * cap)()
+        names = ctypes.create_string_buffer(64 * cap)
+        mp = msgs.ctypes.data_as(u8p) if msg_len else (ctypes.c_uint8 * 1)()
+        args = lambda w, n: (pks_xy.ctypes.data_as(u64p), mp, ctypes.c_size_t(msg_len), ctypes.c_uint64(k), sig_xy.ctypes.data_as(u64p), w, ctypes.c_uint64(n),
+                             ctypes.byref(ncons), ctypes.byref(res), starts, ctypes.c_uint64(cap), names, ctypes.c_size_t(64 * cap))
+        n = self.lib.orc_witness_multi(*args(None, 0))
+        marks = list(zip(names.value.decode().split("\n"), list(starts)))
+        w = None
+        if want_vector:
+            w = np.zeros((n, 6), dtype=np.uint64)
+            self.lib.orc_witness_multi(*args(w.ctypes.data_as(u64p), n))
+        return n, bool(res.value), marks, w
 
     def witness_batch(self, pk_xy, msgs, sig_xy, threads=1, want_digests=True):
         pk_xy = np.ascontiguousarray(pk_xy, dtype=np.uint64)

@@ -42,3 +42,29 @@ def make_batch(o, n, seed=0x5EED, tamper_every=16):
         msg[i] = np.frombuffer(bytes(mb), dtype=np.uint8)
     _cache[key] = (pk, msg, sig, expect)
     return _cache[key]
+
+
+def make_multi(o, K, seed=0x5EED, msg_len=32, tamper=None, start=0):
+    """One instance of the N+1-pair product (BASELINE configs[3]): K distinct (sk_j, msg_j),
+    sigma = sum_j sk_j * H(msg_j). `tamper` = index of a message flipped after signing (expected result false).
+    -> (pks [K,12] u64, msgs [K,msg_len] u8, sig [24] u64, expect)"""
+    key = ("multi", K, seed, msg_len, tamper, start)
+    if key in _cache:
+        return _cache[key]
+    pks = np.zeros((K, 12), dtype=np.uint64)
+    msgs = np.zeros((K, msg_len), dtype=np.uint8)
+    sigs = []
+    for j in range(K):
+        sk = int.from_bytes(_h(seed, b"sk", start + j), "big") % R_MOD or 1
+        m = (_h(seed, b"mm", start + j) * (msg_len // 32 + 1))[:msg_len]
+        st, xy, _ = o.g1_decompress(o.sk_to_pk(sk))
+        assert st == 0
+        pks[j] = xy
+        msgs[j] = np.frombuffer(m, dtype=np.uint8) if msg_len else 0
+        sigs.append(o.sign(sk, m))
+    st, sxy, inf = o.g2_decompress(o.aggregate_g2(sigs))
+    assert st == 0 and not inf
+    if tamper is not None:
+        msgs[tamper, msg_len - 1] ^= 1
+    _cache[key] = (pks, msgs, sxy, tamper is None)
+    return _cache[key]

@@ -24,12 +24,12 @@ def pkg():
     return p
 
 
-def _run(pkg, pk, msg, sig, want_witness=True):
+def _run(pkg, pk, msg, sig, want_witness=True, **options):
     import torch
 
     dev = torch.device("cuda:0")
     n, msg_len = msg.shape
-    g = pkg.BlsSignatureVerifyGadget(n, msg_len, device=dev, want_witness=want_witness)
+    g = pkg.BlsSignatureVerifyGadget(n, msg_len, device=dev, want_witness=want_witness, **options)
     res = g.verify(pkg.ParametersVar(), pkg.PublicKeyVar.new_witness(torch.from_numpy(pk.view(np.int64)).to(dev)), torch.from_numpy(msg).to(dev),
                    pkg.SignatureVar.new_witness(torch.from_numpy(sig.view(np.int64)).to(dev)))
     torch.cuda.synchronize()
@@ -370,18 +370,174 @@ def test_engine_results_only(pkg, oracle):
     eng.close()
 
 
-def test_g2_allocation_on_the_team_machinery():
-    """BLSW_G2=team (experimental, off by default): the G2 allocation's subgroup chain on the six-lane machinery and its
-    segment staged instance-major at the end of the staging coordinates. The mode is read once per process, so the direct,
-    grouped and ragged parity tests are re-run in ONE child process with the variable set."""
-    import subprocess
-    import sys
+def _grouped(pkg, oracle, n, steps, max_steps, check_idx, tamper_every=3, n_buffers=None, **options):
+    """n * steps distinct instances through the grouped engine (one witness tensor per step); instances check_idx(k) of
+    every step are compared element by element with the oracle, all results with the expected booleans."""
+    import torch
 
-    if os.environ.get("BLSW_G2") == "team":
-        pytest.skip("already inside the child run")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, BLSW_G2="team")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-m", "gpu", "-x", "-q", "-k",
-                        "batch_bit_exact or engine_grouped or ragged or digests"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout
+    pk, msg, sig, expect = synth.make_batch(oracle, n * steps, tamper_every=tamper_every)
+    dev = torch.device("cuda:0")
+    eng = pkg.WitnessEngine(n, 32, max_steps=max_steps, device=dev, n_buffers=n_buffers, **options)
+    outs, ress, keep = [], [], []
+    for k in range(steps):
+        sl = slice(k * n, (k + 1) * n)
+        d = (torch.from_numpy(pk[sl].view(np.int64)).to(dev), torch.from_numpy(sig[sl].view(np.int64)).to(dev), torch.from_numpy(msg[sl]).to(dev))
+        w, r = eng.new_witness_tensor(), torch.empty(n, dtype=torch.int32, device=dev)
+        assert eng.submit(d[0], d[1], d[2], witness=w, result=r) == k
+        outs.append(w)
+        ress.append(r)
+        keep.append(d)
+    eng.flush()
+    torch.cuda.synchronize()
+    assert eng.submitted() == eng.launched() == steps
+    for k in range(steps):
+        sl = slice(k * n, (k + 1) * n)
+        got = ress[k].cpu().numpy().astype(bool)
+        assert np.array_equal(got, expect[sl])
+        idx = list(check_idx(k))
+        w = outs[k][idx].cpu().numpy().view(np.uint64)
+        for a, i in enumerate(idx):
+            nw, _, r, ow = oracle.witness(pk[sl][i], msg[sl][i].tobytes(), sig[sl][i])
+            assert r == bool(got[i]) and nw == w.shape[1]
+            bad = np.nonzero((ow != w[a]).any(axis=1))[0]
+            assert len(bad) == 0, "step %d instance %d: first mismatching witness index %d" % (k, i, bad[0])
+    eng.close()
+
+
+@pytest.mark.parametrize("options", [dict(g2_mode="team"), dict(pairing_mode="lane"), dict(expand_store=1, prio_mode=0)])
+def test_engine_mode_options(pkg, oracle, options):
+    """Kernel variants are engine-creation options (blsw_engine_options_t), not process state: the six-lane G2 allocation
+    (its segment staged instance-major at the end of the staging coordinates), the single-lane pairing kernel and the
+    store / priority knobs, each through the grouped engine with ragged tiles."""
+    _grouped(pkg, oracle, 70, 2, 2, lambda k: [0, 9, 63, 64, 69] if k == 0 else [0, 57, 58, 69], tamper_every=5, **options)
+    got, w = _run(pkg, *synth.make_batch(oracle, 70)[:3], **options)
+    pk, msg, sig, expect = synth.make_batch(oracle, 70)
+    assert np.array_equal(got, expect)
+    _compare(oracle, pk, msg, sig, got, w, [0, 15, 63, 64, 69])
+
+
+def test_lane_pairing_with_many_buffers_is_refused(pkg):
+    """The single-lane pairing kernel's 9.7 KB stack x 64 lanes x wave slots per queue used to abort the process with
+    HSA_STATUS_ERROR_OUT_OF_RESOURCES at >= 4 group buffers: blsw_engine_create_ex now returns BLSW_ERR_SCRATCH."""
+    with pytest.raises(pkg.BlswError, match="5"):
+        pkg.WitnessEngine(64, 32, max_steps=2, n_buffers=4, pairing_mode="lane")
+    pkg.WitnessEngine(64, 32, max_steps=2, n_buffers=2, pairing_mode="lane").close()
+
+
+def test_engine_1024_instances_grouped(pkg, oracle):
+    """BASELINE configs[1] shape: batches of 1024 instances, grouped (max_steps = 2, three steps: a full group and a partial
+    one). All 3072 results, and 18 instances spread over staging tiles / pairing waves / steps compared with the oracle on
+    every one of their 707 427 witness elements."""
+    import torch
+
+    n, steps = 1024, 3
+    pick = {0: [0, 63, 64, 500, 1009, 1023], 1: [0, 1, 639, 640, 777, 1023], 2: [5, 64, 127, 128, 1000, 1023]}
+    # inputs minted by the product's signer (checked against the oracle's in test_sign_batch_...), expectations from its tamper rule
+    workload = importlib.import_module("bls-verify-gadget_amd.workload")
+    dev = torch.device("cuda:0")
+    eng = pkg.WitnessEngine(n, 32, max_steps=2, device=dev, n_buffers=2)
+    outs = [eng.new_witness_tensor() for _ in range(steps)]
+    ress, ins = [], []
+    for k in range(steps):
+        pk, msg, sig, expect = workload.make_batch(pkg, n, seed=0x5EED, device=dev, start=k * n)
+        r = torch.empty(n, dtype=torch.int32, device=dev)
+        eng.submit(pk, sig, msg, witness=outs[k], result=r)
+        ress.append(r)
+        ins.append((pk, msg, sig, expect))
+    eng.flush()
+    torch.cuda.synchronize()
+    for k in range(steps):
+        pk, msg, sig, expect = ins[k]
+        got = ress[k].cpu().numpy().astype(bool)
+        assert np.array_equal(got, expect)
+        hp, hm, hs = pk.cpu().numpy().view(np.uint64), msg.cpu().numpy(), sig.cpu().numpy().view(np.uint64)
+        w = outs[k][pick[k]].cpu().numpy().view(np.uint64)
+        for a, i in enumerate(pick[k]):
+            nw, _, r, ow = oracle.witness(hp[i], hm[i].tobytes(), hs[i])
+            assert r == bool(got[i]) and nw == w.shape[1]
+            bad = np.nonzero((ow != w[a]).any(axis=1))[0]
+            assert len(bad) == 0, "step %d instance %d: first mismatching witness index %d" % (k, i, bad[0])
+    eng.close()
+
+
+def test_witness_digest_kernel(pkg, oracle):
+    """blsw_witness_digest against its host-side definition on real witness vectors (ragged: stride > n_witness)."""
+    import torch
+
+    pk, msg, sig, _ = synth.make_batch(oracle, 16)
+    got, w = _run(pkg, pk[:3], msg[:3], sig[:3])
+    dev = torch.device("cuda:0")
+    nw = w.shape[1]
+    padded = torch.zeros((3, nw + 5, 6), dtype=torch.int64, device=dev)
+    padded[:, :nw] = torch.from_numpy(w.view(np.int64)).to(dev)
+    padded[:, nw:] = 0x7777
+    d = pkg.witness_digest(padded, n_witness=nw).cpu().numpy().view(np.uint64)
+    for i in range(3):
+        assert d[i].tolist() == pkg.witness_digest_reference(w[i])
+    # a single flipped bit anywhere changes both words
+    padded[1, nw // 2, 3] ^= 1
+    d2 = pkg.witness_digest(padded, n_witness=nw).cpu().numpy().view(np.uint64)
+    assert d2[0].tolist() == d[0].tolist() and d2[1, 0] != d[1, 0] and d2[1, 1] != d[1, 1]
+
+
+def _multi_run(pkg, pks, msgs, sig):
+    import torch
+
+    res, wit = pkg.verify_multi(pkg.ParametersVar(), pkg.PublicKeyVar.new_witness(torch.from_numpy(pks.view(np.int64)).cuda()), torch.from_numpy(msgs).cuda(),
+                                pkg.SignatureVar.new_witness(torch.from_numpy(sig.view(np.int64)).cuda()))
+    return res.cpu().numpy().astype(bool), wit
+
+
+def test_verify_multi_small(pkg, oracle):
+    """N+1-pair product (BASELINE configs[3]) at K = 1, 2, 3: K = 1 equals the single-key circuit; a batch of three K = 2
+    instances (one with a tampered message); every witness element against the oracle."""
+    pk, msg, sig, expect = synth.make_batch(oracle, 16)
+    got, wit = _multi_run(pkg, pk[3:4, None, :].copy(), msg[3:4, None, :].copy(), sig[3:4].copy())
+    n, _, r, ow = oracle.witness(pk[3], msg[3].tobytes(), sig[3])
+    assert got.tolist() == [True] and np.array_equal(wit[0].cpu().numpy().view(np.uint64), ow)
+    for K, tampers in ((2, [None, 1, None]), (3, [0, None])):
+        cases = [synth.make_multi(oracle, K, tamper=t, start=7 * a) for a, t in enumerate(tampers)]
+        pks = np.stack([c[0] for c in cases])
+        msgs = np.stack([c[1] for c in cases])
+        sigs = np.stack([c[2] for c in cases])
+        got, wit = _multi_run(pkg, pks, msgs, sigs)
+        assert got.tolist() == [c[3] for c in cases]
+        for i, c in enumerate(cases):
+            n, res, _, ow = oracle.witness_multi(c[0], c[1], c[2])
+            w = wit[i].cpu().numpy().view(np.uint64)
+            assert n == w.shape[0] and res == c[3]
+            bad = np.nonzero((ow != w).any(axis=1))[0]
+            assert len(bad) == 0, "K=%d instance %d: first mismatching witness index %d" % (K, i, bad[0])
+
+
+def test_verify_multi_128_pairs(pkg, oracle):
+    """BASELINE configs[3]: ONE signature over 128 (pk, msg) pairs, a 129-pair Miller product — all 87 295 138 witness
+    elements (4.2 GB) against the oracle, plus the tampered variant's result."""
+    K = 128
+    pks, msgs, sig, _ = synth.make_multi(oracle, K)
+    got, wit = _multi_run(pkg, pks[None], msgs[None], sig[None])
+    n, res, _, ow = oracle.witness_multi(pks, msgs, sig)
+    assert res is True and got.tolist() == [True] and n == wit.shape[1] == pkg.layout_multi(32, K)["n_witness"]
+    w = wit[0].cpu().numpy().view(np.uint64)
+    del wit
+    step = 1 << 22
+    for lo in range(0, n, step):
+        blk = (ow[lo:lo + step] != w[lo:lo + step]).any(axis=1)
+        assert not blk.any(), "first mismatching witness index %d" % (lo + int(np.nonzero(blk)[0][0]))
+    del w, ow
+    bad = msgs.copy()
+    bad[77, 5] ^= 0x40
+    got, _ = _multi_run(pkg, pks[None], bad[None], sig[None])
+    assert got.tolist() == [False]
+
+
+def test_sharded_stream_rehearsal(pkg, oracle):
+    """BASELINE configs[2] procedure on one GPU: one rank's shard of 8 192 instances streamed in
+    micro-batches of 1 024 through a ring of TWO witness tensors with a digest kernel as the consumer; all 8 192 results and
+    the digests of a 1 % sample (82 instances, chosen by a fixed stride) against the oracle."""
+    rehearsal = importlib.import_module("tools.shard_rehearsal")
+    out = rehearsal.run_shard(pkg, n_shard=8192, batch=1024, ring=2, rank=0, world=8)
+    assert out["results_ok"] and out["steps"] == 8
+    bad = rehearsal.check_sample(pkg, oracle, out, frac=0.01, threads=8)
+    assert bad == [], bad
+    assert out["sampled"] >= 82

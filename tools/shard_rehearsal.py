@@ -1,0 +1,127 @@
+#!/usr/bin/env python3
+"""BASELINE configs[2] on the hardware at hand: the procedure of SURVEY.md 8d config 3 for ONE rank's shard.
+
+65 536 instances are sharded contiguously over 8 GPUs (8 192 each). A shard does not fit HBM as witness tensors
+(8 192 x 34 MB = 278 GB), so a rank streams it in micro-batches of `batch` instances through a small ring of output
+tensors; a consumer (here: the digest kernel blsw_witness_digest, standing in for a per-GPU prover or the all-gather
+of a micro-batch) drains every tensor before the engine may overwrite it:
+
+    submit(step k -> ring[k % ring])  ...  engine.wait_step(k, consumer)  ->  digest  ->  engine.output_consumed(ring[k % ring])
+
+The engine fuses `ring` steps per launch group (a step's tensor must have been released before its group is launched) and
+keeps `buffers` groups of chains in flight. `check_sample` compares the digests of a fixed-stride sample with the CPU oracle.
+
+Standalone: python tools/shard_rehearsal.py [--rank R --world W --shard 8192 --batch 1024] prints one JSON line.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def run_shard(pkg, n_shard=8192, batch=1024, ring=2, rank=0, world=8, buffers=6, seed=0x5EED, device=None):
+    import torch
+
+    workload = importlib.import_module("bls-verify-gadget_amd.workload")
+    sharding = importlib.import_module("bls-verify-gadget_amd.sharding")
+    dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    lo, hi = sharding.shard_range(n_shard * world, rank, world)  # this rank's contiguous block of the global batch
+    assert hi - lo == n_shard and n_shard % batch == 0
+    steps = n_shard // batch
+    eng = pkg.WitnessEngine(batch, 32, max_steps=ring, device=dev, n_buffers=min(buffers, max(1, steps // ring)))
+    outs = [eng.new_witness_tensor() for _ in range(ring)]
+    digests = torch.zeros((steps, batch, 2), dtype=torch.int64, device=dev)
+    results = torch.zeros((steps, batch), dtype=torch.int32, device=dev)
+    consumer = torch.cuda.Stream(device=dev)
+    inputs, expects = [], []
+    for k in range(steps):  # inputs are resident before the timed region (minted by the product's signer)
+        pk, msg, sig, expect = workload.make_batch(pkg, batch, seed=seed, device=dev, start=lo + k * batch)
+        inputs.append((pk, msg, sig))
+        expects.append(expect)
+    torch.cuda.synchronize(dev)
+    state = {"next": 0}
+
+    def drain():
+        while state["next"] < eng.launched():
+            s = state["next"]
+            eng.wait_step(s, consumer)
+            pkg.witness_digest(outs[s % ring], out=digests[s], stream=consumer)
+            eng.output_consumed(outs[s % ring], consumer)
+            state["next"] += 1
+
+    t0 = time.perf_counter()
+    for k in range(steps):
+        pk, msg, sig = inputs[k]
+        eng.submit(pk, sig, msg, witness=outs[k % ring], result=results[k])
+        drain()
+    eng.flush()
+    drain()
+    consumer.synchronize()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    res = results.cpu().numpy().astype(bool)
+    expect = np.stack(expects)
+    eng.close()
+    return {"rank": rank, "world": world, "first_instance": lo, "n_shard": n_shard, "batch": batch, "ring": ring, "steps": steps, "seconds": dt,
+            "instances_per_s": n_shard / dt, "results_ok": bool((res == expect).all()), "digests": digests.cpu().numpy().view(np.uint64).reshape(n_shard, 2),
+            "inputs": inputs, "sampled": 0}
+
+
+def check_sample(pkg, oracle, out, frac=0.01, threads=8):
+    """Digest of every (1 / frac)-th instance of the shard against the oracle's witness vector. -> list of mismatching indices"""
+    from concurrent.futures import ThreadPoolExecutor
+
+    n, batch = out["n_shard"], out["batch"]
+    stride = max(1, int(round(1.0 / frac)))
+    idx = list(range(stride // 2, n, stride))
+    host = {}
+    for i in idx:
+        k = i // batch
+        if k not in host:
+            pk, msg, sig = out["inputs"][k]
+            host[k] = (pk.cpu().numpy().view(np.uint64), msg.cpu().numpy(), sig.cpu().numpy().view(np.uint64))
+
+    def one(i):
+        pk, msg, sig = host[i // batch]
+        j = i % batch
+        _, _, _, w = oracle.witness(pk[j], msg[j].tobytes(), sig[j])  # ctypes releases the GIL
+        return i, pkg.witness_digest_reference(w)
+
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        got = list(ex.map(one, idx))
+    out["sampled"] = len(idx)
+    return [i for i, d in got if out["digests"][i].tolist() != d]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rank", type=int, default=0)
+    ap.add_argument("--world", type=int, default=8)
+    ap.add_argument("--shard", type=int, default=8192)
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--ring", type=int, default=2)
+    ap.add_argument("--buffers", type=int, default=6)
+    ap.add_argument("--no-check", action="store_true")
+    args = ap.parse_args()
+    pkg = importlib.import_module("bls-verify-gadget_amd")
+    out = run_shard(pkg, args.shard, args.batch, args.ring, args.rank, args.world, args.buffers)
+    line = {k: v for k, v in out.items() if k not in ("digests", "inputs")}
+    if not args.no_check:
+        from tests import oracle_lib  # the CPU restatement: the checker of the sample, nothing else
+
+        bad = check_sample(pkg, oracle_lib.load(), out)
+        line.update({"sampled": out["sampled"], "sample_mismatches": len(bad)})
+    line["workload"] = "configs[2] rehearsal: one rank's shard (rank %d of %d) streamed through a ring of %d tensors, digest consumer" % (args.rank, args.world, args.ring)
+    print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()
