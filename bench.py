@@ -55,7 +55,7 @@ def parse_args():
     ap.add_argument("--mem-frac", type=float, default=0.68, help="share of the free HBM the engine workspace and the output ring may take")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=256, help="instances of the batch timed on the host (all cores, and one thread)")
-    ap.add_argument("--allgather-steps", type=int, default=4, help="steps of the generation + all-gather leg (0 = skip; runs when a process group exists)")
+    ap.add_argument("--allgather-steps", type=int, default=8, help="steps of the generation + all-gather leg (0 = skip; runs when a process group exists)")
     ap.add_argument("--allgather-chunk", type=int, default=16, help="instances per rank in one all-gathered micro-batch")
     return ap.parse_args()
 
@@ -85,6 +85,21 @@ def balanced_coalesce(steps, max_group):
     return max(1, (steps + groups - 1) // groups)
 
 
+def host_cores():
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup's CPU quota (a GPU box grants a share)."""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        cores = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = min(cores, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return cores
+
+
 def cpu_baseline(args, d_pk, d_msg, d_sig, n):
     """The C++ restatement of the reference path (oracle/) on the host cores: all cores and one thread, on the first
     `--cpu-sample` instances of the batch. Built -O3 -march=native on THIS machine when a compiler is present."""
@@ -102,20 +117,19 @@ def cpu_baseline(args, d_pk, d_msg, d_sig, n):
         build = "-O3 -march=native, built on this host"
     except Exception:
         oracle = oracle_lib.load()
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except (AttributeError, OSError):
-        pass
-    m = min(args.cpu_sample, n)
+    cores = host_cores()
+    m = min(max(args.cpu_sample, 8 * cores), n)
     h_pk, h_msg, h_sig = d_pk[:m].cpu().numpy().view(np.uint64), d_msg[:m].cpu().numpy(), d_sig[:m].cpu().numpy().view(np.uint64)
     t1 = time.perf_counter()
-    oracle.witness_batch(h_pk, h_msg, h_sig, threads=cores, want_digests=False)
-    all_dt = time.perf_counter() - t1
-    m1 = min(m, max(8, int(30.0 / max(all_dt * cores / m, 1e-9))))  # the same sample on one thread, capped at ~30 s of work
+    oracle.witness_batch(h_pk[:4], h_msg[:4], h_sig[:4], threads=1, want_digests=False)  # probe: seconds per instance on one thread
+    per_inst = (time.perf_counter() - t1) / 4
+    m1 = min(m, args.cpu_sample, max(8, int(30.0 / max(per_inst, 1e-9))))  # one thread: the sample, capped at ~30 s of work
     t1 = time.perf_counter()
     oracle.witness_batch(h_pk[:m1], h_msg[:m1], h_sig[:m1], threads=1, want_digests=False)
     one_dt = time.perf_counter() - t1
+    t1 = time.perf_counter()
+    oracle.witness_batch(h_pk, h_msg, h_sig, threads=cores, want_digests=False)
+    all_dt = time.perf_counter() - t1
     return {"value": m / all_dt, "unit": "instances/s", "cores": cores, "kind": "port", "value_1thread": m1 / one_dt,
             "sample": "first %d instances of the bench batch through the C++ restatement of the reference path (oracle/, %s), %d threads: %.2f s; "
                       "first %d instances on one thread: %.2f s" % (m, build, cores, all_dt, m1, one_dt)}
@@ -130,7 +144,9 @@ def allgather_leg(args, pkg, sharding, dist, dev, inputs, lay, world):
     n, ring = args.batch, 2
     steps = min(args.allgather_steps, args.steps)
     d_pk, d_msg, d_sig = inputs
-    eng = pkg.WitnessEngine(n, 32, max_steps=ring, device=dev, n_buffers=2)
+    # groups of `ring` steps (a step's tensor must be released before its group is launched); enough groups in flight to
+    # cover the chains' latency while the gather drains the tensors
+    eng = pkg.WitnessEngine(n, 32, max_steps=ring, device=dev, n_buffers=max(1, min(8, (steps + ring - 1) // ring)))
     outs = [eng.new_witness_tensor() for _ in range(ring)]
     results = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(ring)]
     chunk = max(1, min(args.allgather_chunk, n))

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include "chains.cuh"
 #include "decode.cuh"
 #include "layout.h"
@@ -468,6 +469,7 @@ __global__ __launch_bounds__(64) void k_pairing(Group g) {
 #define BLSW_TEAMS_PER_WAVE 10
 __global__ __launch_bounds__(64) void k_pairing_team(Group g) {
     __shared__ Fp2 lds[BLSW_TEAMS_PER_WAVE * TS_NSLOTS];
+    if ((uint64_t)blockIdx.x * BLSW_TEAMS_PER_WAVE >= g.N) return;  // a wave without instances (the scratch pre-warm launch)
     if (g.chain_prio) __builtin_amdgcn_s_setprio(3);
     const uint32_t team = threadIdx.x / 6, j = threadIdx.x % 6;
     const uint64_t I0 = (uint64_t)blockIdx.x * BLSW_TEAMS_PER_WAVE + team;
@@ -777,17 +779,18 @@ struct DeviceGuard {
 
 // Execution engine. Batches ("steps") are SUBMITTED with their input/output pointers and processed in GROUPS of up
 // to max_steps batches by one set of launches (N = steps * n lanes per chain kernel), which is what fills the chip:
-// one batch of 1024 instances is only 16 waves per chain. Per group:
-//   sha  : SHA witness bits                                          (needs only msg)        -> ev_sha
-//   main : sha_values -> map -> cofactor -> prepare(H) ............ -> pairing               -> ev_chains
-//   aux0 : g1_alloc, g2_alloc                                        (needs only pk / sig)
-//   aux1 : prepare(sig)                                              (needs only sig)
-// Field witnesses go to a staging area (coalesced stores). The witness tensors are written per step, in submission
-// order, by two engine-wide streams: `expand` runs k_sha_expand (bit -> Fp, 31 MB of the 34 MB per instance, the
-// HBM-bound kernel) as soon as the group's SHA bits exist — it never waits for the curve / pairing chains, so a short
-// job does not pay the chains' latency in front of its HBM stream — and `place` runs k_place_field (staging -> its
-// place around the SHA segment) once the group's chains are done and the step's expansion has been issued.
-// n_buffers group buffers rotate, so the next groups' chains overlap the previous groups' placement.
+// one batch of 1024 instances is only 16 waves per chain. Streams (the runtime backs the streams of ONE priority level
+// with four hardware queues; streams that share a queue serialise, so the engine uses three levels and few streams):
+//   engine-wide, high priority:  sha    : SHA witness bits of every group, in order (needs only msg)  -> ev_sha per group
+//                                expand : k_sha_expand per step (bit -> Fp, 31 MB of the 34 MB per instance, the HBM-bound
+//                                         kernel), as soon as the group's SHA bits exist: it never waits for the curve /
+//                                         pairing chains, so a short job does not pay their latency before its HBM stream
+//                                place  : k_place_field per step (staging -> its place around the SHA segment), once the
+//                                         group's chains are done and the step's expansion has finished
+//   per group buffer:   normal   main : sha_values -> map -> cofactor -> prepare(H) .......... -> pairing   -> ev_chains
+//                       low      aux  : prepare(sig), g1_alloc, g2_alloc  (need only pk / sig)   -> ev_aux
+// Field witnesses go to a staging area (coalesced stores). n_buffers group buffers rotate, so the next groups' chains
+// overlap the previous groups' placement.
 #define BLSW_MAX_BUFFERS 32
 #define BLSW_MAX_TIMED 1024
 #define BLSW_MAX_CONSUMED 64
@@ -795,8 +798,8 @@ struct GroupBuf {
     void* base = nullptr;
     StepDesc* h_desc = nullptr;  // pinned host
     StepDesc* d_desc = nullptr;
-    hipStream_t st[4] = {nullptr, nullptr, nullptr, nullptr};  // main, aux0, aux1, sha
-    hipEvent_t ev_start = nullptr, ev_aux[2] = {nullptr, nullptr}, ev_sha = nullptr, ev_chains = nullptr, ev_done = nullptr;
+    hipStream_t st[2] = {nullptr, nullptr};  // main, aux
+    hipEvent_t ev_start = nullptr, ev_aux = nullptr, ev_sha = nullptr, ev_chains = nullptr, ev_done = nullptr;
     hipEvent_t* ev_in = nullptr;    // [max_steps] inputs of step s valid (recorded on the submitting stream)
     hipEvent_t* ev_x = nullptr;     // [max_steps] expansion of step s issued and finished
     hipEvent_t* ev_step = nullptr;  // [max_steps] step s complete (witness tensor + results)
@@ -816,7 +819,7 @@ struct blsw_engine {
     int cur = 0;
     uint32_t pending = 0;
     uint64_t submitted = 0, launched = 0;
-    hipStream_t expand = nullptr, place = nullptr;
+    hipStream_t sha = nullptr, expand = nullptr, place = nullptr;
     // HIP event pairs around every k_sha_expand launch since the last stats reset (live roofline measurement)
     hipEvent_t* ev_exp = nullptr;  // 2 * BLSW_MAX_TIMED events
     uint32_t n_timed = 0;
@@ -833,9 +836,9 @@ static void engine_free(blsw_engine* e) {
         GroupBuf& b = e->buf[k];
         if (b.h_desc) hipHostFree(b.h_desc);
         if (b.d_desc) hipFree(b.d_desc);
-        for (int i = 0; i < 4; i++)
+        for (int i = 0; i < 2; i++)
             if (b.st[i]) hipStreamDestroy(b.st[i]);
-        hipEvent_t single[] = {b.ev_start, b.ev_aux[0], b.ev_aux[1], b.ev_sha, b.ev_chains, b.ev_done};
+        hipEvent_t single[] = {b.ev_start, b.ev_aux, b.ev_sha, b.ev_chains, b.ev_done};
         for (hipEvent_t ev : single)
             if (ev) hipEventDestroy(ev);
         hipEvent_t* arrays[] = {b.ev_in, b.ev_x, b.ev_step};
@@ -846,6 +849,7 @@ static void engine_free(blsw_engine* e) {
             delete[] arr;
         }
     }
+    if (e->sha) hipStreamDestroy(e->sha);
     if (e->expand) hipStreamDestroy(e->expand);
     if (e->place) hipStreamDestroy(e->place);
     if (e->ev_exp) {
@@ -886,28 +890,26 @@ static int launch_group(blsw_engine* e) {
                 if (e->consumed_live[c] && e->consumed_ptr[c] == b.h_desc[s].out) hipStreamWaitEvent(st, e->consumed_ev[c], 0);
     hipMemcpyAsync(b.d_desc, b.h_desc, sizeof(StepDesc) * steps, hipMemcpyHostToDevice, st);
     hipEventRecord(b.ev_start, st);
-    for (int i = 1; i < 4; i++) hipStreamWaitEvent(b.st[i], b.ev_start, 0);
+    hipStreamWaitEvent(b.st[1], b.ev_start, 0);
     // sha: the witness bits of the in-circuit SHA-256 (first: the expansion stream is waiting for them)
-    if (any_out) hipLaunchKernelGGL(k_sha, dim3(g1), dim3(64), 0, b.st[3], g, 1, 0);
-    hipEventRecord(b.ev_sha, b.st[3]);
+    hipStreamWaitEvent(e->sha, b.ev_start, 0);
+    if (any_out) hipLaunchKernelGGL(k_sha, dim3(g1), dim3(64), 0, e->sha, g, 1, 0);
+    hipEventRecord(b.ev_sha, e->sha);
     // main, first part: the hash-to-G2 critical path
     hipLaunchKernelGGL(k_sha_values, dim3(g1), dim3(64), 0, st, g);
     hipLaunchKernelGGL(k_map, dim3(g2), dim3(64), 0, st, g);
     hipLaunchKernelGGL(k_cofactor, dim3(g1), dim3(64), 0, st, g);
     hipLaunchKernelGGL(k_prepare, dim3(g1), dim3(64), 0, st, g, 0);
-    // aux0: group allocations
+    // aux: prepare_g2(sig) and the group allocations (53 ms alone beside the 86 ms of the main stream's first part)
+    hipLaunchKernelGGL(k_prepare, dim3(g1), dim3(64), 0, b.st[1], g, 1);
     hipLaunchKernelGGL(k_g1, dim3(g1), dim3(64), 0, b.st[1], g);
     if (e->modes.g2_team)
         hipLaunchKernelGGL(k_g2_alloc_team, dim3(gt), dim3(64), 0, b.st[1], g);
     else
         hipLaunchKernelGGL(k_g2_alloc, dim3(g1), dim3(64), 0, b.st[1], g);
-    hipEventRecord(b.ev_aux[0], b.st[1]);
-    // aux1: prepare_g2(sig)
-    hipLaunchKernelGGL(k_prepare, dim3(g1), dim3(64), 0, b.st[2], g, 1);
-    hipEventRecord(b.ev_aux[1], b.st[2]);
+    hipEventRecord(b.ev_aux, b.st[1]);
     // main, second part: the pairing
-    hipStreamWaitEvent(st, b.ev_aux[0], 0);
-    hipStreamWaitEvent(st, b.ev_aux[1], 0);
+    hipStreamWaitEvent(st, b.ev_aux, 0);
     launch_pairing(g, e->modes, st);
     hipStreamWaitEvent(st, b.ev_sha, 0);
     hipEventRecord(b.ev_chains, st);
@@ -1068,15 +1070,20 @@ int blsw_engine_create_ex(blsw_engine_t** out, uint64_t n, uint32_t msg_len, uin
     for (int i = 0; i < 2 * BLSW_MAX_TIMED && rc == BLSW_OK; i++) chk(hipEventCreate(&e->ev_exp[i]), "event create");
     int prio_lo = 0, prio_hi = 0;
     chk(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi), "priority range");  // (least, greatest): numerically lower = higher priority
-    const int chain_prio = e->opt.prio_mode == 1 ? prio_lo : prio_hi, place_prio = e->opt.prio_mode == 0 ? prio_lo : prio_hi;
+    // three priority levels = three pools of hardware queues: [placement, main chains, aux chains] from high to low
+    // (prio_mode 1, default), [main, aux, placement] (prio_mode 0) or everything at the middle level (prio_mode 2)
+    const int prio_mid = (prio_hi + 1 <= prio_lo) ? prio_hi + 1 : prio_lo;  // -1 high, 0 normal, 1 low on this runtime
+    int place_prio = prio_hi, main_prio = prio_mid, aux_prio = prio_lo;
+    if (e->opt.prio_mode == 0) place_prio = prio_lo, main_prio = prio_hi, aux_prio = prio_mid;
+    if (e->opt.prio_mode == 2) place_prio = main_prio = aux_prio = prio_mid;
     for (int k = 0; k < e->nbuf && rc == BLSW_OK; k++) {
         GroupBuf& b = e->buf[k];
         b.base = reinterpret_cast<char*>(d_workspace) + (uint64_t)k * (need / e->nbuf);
         chk(hipHostMalloc(reinterpret_cast<void**>(&b.h_desc), sizeof(StepDesc) * max_steps, hipHostMallocDefault), "host alloc");
         chk(hipMalloc(reinterpret_cast<void**>(&b.d_desc), sizeof(StepDesc) * max_steps), "desc alloc");
-        // the SHA-bit stream feeds the HBM-bound expansion: it takes the placement priority
-        for (int i = 0; i < 4; i++) chk(hipStreamCreateWithPriority(&b.st[i], hipStreamNonBlocking, i == 3 ? place_prio : chain_prio), "stream create");
-        hipEvent_t* single[] = {&b.ev_start, &b.ev_aux[0], &b.ev_aux[1], &b.ev_sha, &b.ev_chains, &b.ev_done};
+        chk(hipStreamCreateWithPriority(&b.st[0], hipStreamNonBlocking, main_prio), "stream create");
+        chk(hipStreamCreateWithPriority(&b.st[1], hipStreamNonBlocking, aux_prio), "stream create");
+        hipEvent_t* single[] = {&b.ev_start, &b.ev_aux, &b.ev_sha, &b.ev_chains, &b.ev_done};
         for (hipEvent_t* ev : single) chk(hipEventCreateWithFlags(ev, hipEventDisableTiming), "event create");
         b.ev_in = new hipEvent_t[max_steps]();
         b.ev_x = new hipEvent_t[max_steps]();
@@ -1087,8 +1094,27 @@ int blsw_engine_create_ex(blsw_engine_t** out, uint64_t n, uint32_t msg_len, uin
             chk(hipEventCreateWithFlags(&b.ev_step[s], hipEventDisableTiming), "event create");
         }
     }
+    chk(hipStreamCreateWithPriority(&e->sha, hipStreamNonBlocking, place_prio), "stream create");
     chk(hipStreamCreateWithPriority(&e->expand, hipStreamNonBlocking, place_prio), "stream create");
     chk(hipStreamCreateWithPriority(&e->place, hipStreamNonBlocking, place_prio), "stream create");
+    // Scratch pre-warm. The pairing kernel has the largest stack (4.5 KB per lane): the first launch of a full-size group on
+    // a queue makes the runtime grow that queue's scratch, which stalls the queue for ~60 ms (measured: the pairing of the
+    // first group of every buffer started 60 ms late). One launch of the same grid with N = 0 (every wave exits at once)
+    // per main stream pays that here instead of in the caller's first groups.
+    if (rc == BLSW_OK) {
+        Group g0;
+        memset(&g0, 0, sizeof(g0));
+        g0.n = (uint32_t)n;
+        g0.K = 1;
+        const uint64_t Nmax = n * max_steps;
+        for (int k = 0; k < e->nbuf; k++) {
+            if (e->modes.pairing_team)
+                hipLaunchKernelGGL(k_pairing_team, dim3((unsigned)((Nmax + BLSW_TEAMS_PER_WAVE - 1) / BLSW_TEAMS_PER_WAVE)), dim3(64), 0, e->buf[k].st[0], g0);
+            else
+                hipLaunchKernelGGL(k_pairing, dim3((unsigned)((Nmax + 63) / 64)), dim3(64), 0, e->buf[k].st[0], g0);
+        }
+        for (int k = 0; k < e->nbuf; k++) chk(hipStreamSynchronize(e->buf[k].st[0]), "scratch pre-warm");
+    }
     if (rc != BLSW_OK) {
         engine_free(e);
         return rc;
