@@ -161,14 +161,11 @@ def allgather_leg(args, pkg, sharding, dist, dev, inputs, lay, world):
             s = state["next"]
             eng.wait_step(s, consumer)
             with torch.cuda.stream(consumer):
-                for c0 in range(0, n, chunk):
-                    part = outs[s % ring][c0:c0 + chunk]
-                    if part.shape[0] == chunk:
-                        g = sharding.all_gather_witness_chunk(part, out=gathered)
-                    else:
-                        g = sharding.all_gather_witness_chunk(part)
+                def consume(g, c0, rows):
                     d = pkg.witness_digest(g, out=dig[: g.shape[0]], stream=consumer)
                     acc.add_(d.sum(dim=0))
+
+                sharding.stream_allgather(outs[s % ring], chunk, consume, buffer=gathered)
             eng.output_consumed(outs[s % ring], consumer)
             state["next"] += 1
 

@@ -38,3 +38,18 @@ def all_gather_witness_chunk(local_chunk, group=None, out=None):
     assert out.shape[0] == world * local_chunk.shape[0] and out.is_contiguous()
     dist.all_gather_into_tensor(out, local_chunk.contiguous(), group=group)
     return out
+
+
+def stream_allgather(local_tensor, chunk, consume, group=None, buffer=None):
+    """All-gathers `local_tensor` ([m, k, 6] per rank) in micro-batches of `chunk` rows per rank and hands every gathered
+    micro-batch ([world * rows, k, 6], rank-major) to `consume` before the next one is gathered — the full gathered tensor
+    never exists. `buffer` ([world * chunk, k, 6]) is reused for the full-size micro-batches.
+    Returns the number of micro-batches. Used by bench.py's all-gather leg (RCCL) and by the gloo test (CPU)."""
+    m = local_tensor.shape[0]
+    count = 0
+    for c0 in range(0, m, chunk):
+        part = local_tensor[c0:c0 + chunk]
+        g = all_gather_witness_chunk(part, group=group, out=buffer if (buffer is not None and part.shape[0] == chunk) else None)
+        consume(g, c0, part.shape[0])
+        count += 1
+    return count

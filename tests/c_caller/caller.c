@@ -1,0 +1,83 @@
+/* A C caller of the drop-in boundary (include/blsw.h), compiled with gcc against the header and linked to libblsw.so:
+ * the role a Rust `extern "C"` shim plays in the reference crate. TEST PROGRAM.
+ *
+ *   caller layout                               host-only entry points (runs without a GPU): prints one line of key=value pairs
+ *   caller verify <pk48 hex> <msg hex> <sig96 hex>   decode -> engine create/submit/flush -> result + witness digest (needs a GPU)
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <hip/hip_runtime_api.h>
+#include "blsw.h"
+
+static int unhex(const char* s, uint8_t* out, size_t n) {
+    if (strlen(s) != 2 * n) return -1;
+    for (size_t i = 0; i < n; i++) {
+        unsigned v;
+        if (sscanf(s + 2 * i, "%2x", &v) != 1) return -1;
+        out[i] = (uint8_t)v;
+    }
+    return 0;
+}
+#define CHECK(x)                                                      \
+    do {                                                              \
+        int rc_ = (x);                                                \
+        if (rc_) {                                                    \
+            fprintf(stderr, "%s failed: %d (line %d)\n", #x, rc_, __LINE__); \
+            return 10;                                                \
+        }                                                             \
+    } while (0)
+
+int main(int argc, char** argv) {
+    if (argc >= 2 && !strcmp(argv[1], "layout")) {
+        blsw_layout_t L, M;
+        blsw_engine_options_t o;
+        uint64_t ws = 0, ws_multi = 0;
+        CHECK(blsw_layout(32, &L));
+        CHECK(blsw_layout_multi(32, 128, &M));
+        CHECK(blsw_engine_options_default(&o));
+        CHECK(blsw_engine_workspace_bytes(1024, 32, 16, 3, &ws));
+        CHECK(blsw_verify_multi_workspace_bytes(1, 32, 128, &ws_multi));
+        if (blsw_layout(32, NULL) != BLSW_ERR_ARG || blsw_engine_workspace_bytes(0, 32, 1, 1, &ws_multi) != BLSW_ERR_ARG) return 11;
+        printf("version=%d sizeof_layout=%zu n_witness=%u sha_bits=%u off_expand=%u off_miller=%u multi_n_witness=%u multi_pairs=%u multi_stride_hash=%u "
+               "workspace=%llu device=%d pairing_mode=%u prio_mode=%u\n",
+               blsw_version(), sizeof(blsw_layout_t), L.n_witness, L.sha_bits, L.off_expand, L.off_miller, M.n_witness, M.n_pairs, M.stride_hash,
+               (unsigned long long)ws, o.device, o.pairing_mode, o.prio_mode);
+        return 0;
+    }
+    if (argc == 5 && !strcmp(argv[1], "verify")) {
+        uint8_t pk[48], msg[32], sig[96];
+        if (unhex(argv[2], pk, 48) || unhex(argv[3], msg, 32) || unhex(argv[4], sig, 96)) return 12;
+        blsw_layout_t L;
+        CHECK(blsw_layout(32, &L));
+        uint8_t *d_pk, *d_sig, *d_msg;
+        uint64_t *d_pk_xy, *d_sig_xy, *d_wit, *d_dig;
+        int32_t *d_st, *d_res;
+        void* d_ws;
+        uint64_t ws = 0;
+        CHECK(blsw_engine_workspace_bytes(1, 32, 1, 1, &ws));
+        CHECK(hipMalloc((void**)&d_pk, 48) || hipMalloc((void**)&d_sig, 96) || hipMalloc((void**)&d_msg, 32) || hipMalloc((void**)&d_pk_xy, 96) ||
+              hipMalloc((void**)&d_sig_xy, 192) || hipMalloc((void**)&d_st, 8) || hipMalloc((void**)&d_res, 4) || hipMalloc((void**)&d_dig, 16) ||
+              hipMalloc((void**)&d_wit, (size_t)L.n_witness * 48) || hipMalloc(&d_ws, ws));
+        CHECK(hipMemcpy(d_pk, pk, 48, hipMemcpyHostToDevice) || hipMemcpy(d_sig, sig, 96, hipMemcpyHostToDevice) || hipMemcpy(d_msg, msg, 32, hipMemcpyHostToDevice));
+        CHECK(blsw_decode_batch(d_pk, d_sig, 1, d_pk_xy, d_sig_xy, d_st, NULL));
+        blsw_engine_t* e = NULL;
+        CHECK(blsw_engine_create(&e, 1, 32, 1, 1, d_ws, ws));
+        CHECK(blsw_engine_submit(e, d_pk_xy, d_sig_xy, d_msg, d_wit, L.n_witness, d_res, NULL));
+        uint64_t sub = 0, lau = 0;
+        CHECK(blsw_engine_submitted(e, &sub) || blsw_engine_launched(e, &lau));
+        CHECK(blsw_engine_flush(e, NULL));
+        CHECK(blsw_engine_wait_step(e, 0, NULL));
+        CHECK(blsw_witness_digest(d_wit, L.n_witness, 1, L.n_witness, d_dig, NULL));
+        CHECK(hipDeviceSynchronize());
+        int32_t st[2], res;
+        uint64_t dig[2];
+        CHECK(hipMemcpy(st, d_st, 8, hipMemcpyDeviceToHost) || hipMemcpy(&res, d_res, 4, hipMemcpyDeviceToHost) || hipMemcpy(dig, d_dig, 16, hipMemcpyDeviceToHost));
+        CHECK(blsw_engine_destroy(e));
+        printf("status_pk=%d status_sig=%d result=%d submitted=%llu digest0=%llu digest1=%llu n_witness=%u\n", st[0], st[1], res, (unsigned long long)sub,
+               (unsigned long long)dig[0], (unsigned long long)dig[1], L.n_witness);
+        return 0;
+    }
+    fprintf(stderr, "usage: caller layout | caller verify <pk48> <msg32> <sig96> (hex)\n");
+    return 2;
+}

@@ -541,3 +541,20 @@ def test_sharded_stream_rehearsal(pkg, oracle):
     bad = rehearsal.check_sample(pkg, oracle, out, frac=0.01, threads=8)
     assert bad == [], bad
     assert out["sampled"] >= 82
+
+
+def test_c_caller_on_the_gpu(pkg, oracle):
+    """tests/c_caller (plain C against include/blsw.h): decode -> engine create / submit / flush / wait_step -> digest for the
+    reference's gadget case (constraints.rs:337-343); result and witness digest against the oracle."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "tests", "c_caller")])
+    g = LIT["gadget_verify"]
+    out = subprocess.check_output([os.path.join(root, "tests", "c_caller", "caller"), "verify", g["pubkey"], g["messages"][0], g["signature"]], text=True, timeout=300)
+    kv = dict(p.split("=") for p in out.split())
+    _, pk, _ = oracle.g1_decompress(bytes.fromhex(g["pubkey"]))
+    _, sig, _ = oracle.g2_decompress(bytes.fromhex(g["signature"]))
+    n, _, res, w = oracle.witness(pk, bytes.fromhex(g["messages"][0]), sig)
+    assert kv["status_pk"] == kv["status_sig"] == "0" and int(kv["result"]) == int(res) == 1 and int(kv["n_witness"]) == n
+    assert [int(kv["digest0"]), int(kv["digest1"])] == pkg.witness_digest_reference(w)

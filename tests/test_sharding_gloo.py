@@ -35,8 +35,14 @@ def _worker(rank, world, port, n_total, q):
     full = sharding.all_gather_results(local, n_total)
     chunk = torch.full((2, 3, 6), rank, dtype=torch.int64)
     gathered = sharding.all_gather_witness_chunk(chunk)
+    # the micro-batched gather of bench.py's all-gather leg (same function, gloo instead of RCCL): 5 rows per rank in
+    # micro-batches of 2 (ragged tail), every micro-batch consumed before the next; the consumer sees rank-major rows
+    local = (torch.arange(5 * 4 * 6, dtype=torch.int64).reshape(5, 4, 6) + 1000 * rank)
+    seen = []
+    buf = torch.empty((world * 2, 4, 6), dtype=torch.int64)
+    nmb = sharding.stream_allgather(local, 2, lambda g, c0, rows: seen.append((c0, rows, g[:, 0, 0].tolist())), buffer=buf)
     if rank == 0:
-        q.put((full.numpy().astype(bool).tolist(), expect.tolist(), gathered[:, 0, 0].tolist()))
+        q.put((full.numpy().astype(bool).tolist(), expect.tolist(), gathered[:, 0, 0].tolist(), nmb, seen))
     dist.destroy_process_group()
 
 
@@ -61,9 +67,11 @@ def test_two_rank_gloo_gather():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, n_total, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got, expect, gathered = q.get(timeout=120)
+    got, expect, gathered, nmb, seen = q.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     assert got == expect
     assert gathered == [0, 0, 1, 1]
+    assert nmb == 3 and [(c0, rows) for c0, rows, _ in seen] == [(0, 2), (2, 2), (4, 1)]
+    assert seen[0][2] == [0, 24, 1000, 1024] and seen[2][2] == [96, 1096]
