@@ -202,72 +202,126 @@ __global__ __launch_bounds__(64) void k_sha_values(Group g) {
     for (int j = 0; j < 4; j++) st_fp(g.ws.u + (uint64_t)j * g.N + I, hash_to_field_elem(uw + 16 * j));
 }
 
-// bitstream -> Fp elements: element e of the expand segment = bit ? R mod p : 0. Thread t of a 384-thread block owns
-// the 16-byte column c = t % 3 of elements e0 + 128k, so its three R limbs-of-four are loop invariants and one store
-// instruction of a wave covers 1 KiB contiguous. ~10 VALU instructions per 16 bytes stored; streaming (nontemporal)
-// stores: the tensor is not read again on the device. blockIdx.y = instance of the step.
-#ifndef BLSW_EXPAND_ITERS
-#define BLSW_EXPAND_ITERS 8
-#endif
-#ifndef BLSW_EXPAND_THREADS
-#define BLSW_EXPAND_THREADS 384  // a multiple of 192: three 16-byte columns per element, whole waves
-#endif
-#define BLSW_EXPAND_EPI (BLSW_EXPAND_THREADS / 3)  // elements per block and iteration
-#ifndef BLSW_EXPAND_UNROLL
-#define BLSW_EXPAND_UNROLL 8
-#endif
+// bitstream -> Fp elements: element e of the expand segment = bit ? R mod p : 0. The segment is a stream of 16-byte pieces
+// (piece p = element p / 3, column p % 3) that starts at an arbitrary multiple of 16 bytes (instance vectors are 33 956 496
+// bytes apart). blockIdx.y = flat (instance, pair) index of the step. Three store geometries (blsw_engine_options_t::
+// expand_variant; measured alone in tools/expand_lab.hip -> profiles/r02_expand_lab.txt, and in the pipeline by bench.py):
+//   0  384-thread workgroups, 8 pieces per thread 6 KiB apart, pieces counted from the first 256-byte boundary
+//   1  256-thread workgroups, ONE piece per thread, every workgroup writes one 4 KiB-aligned 4 KiB chunk of the address space
+//   2  768-thread workgroups, 8 pieces per thread 12 KiB apart: every iteration writes three 4 KiB-aligned chunks; column and
+//      bit position of a thread are loop invariants (768 = 3 * 256 pieces = 256 elements = 8 bit words per iteration)
+//   3  as 2 with 4 pieces per thread
+struct ExpandArgs {
+    const uint32_t* bits;
+    uint64_t sha_words, first;
+    uint32_t sha_bits, off_expand;
+    uint64_t* d_witness;
+    uint64_t stride;
+    uint32_t K, stride_hash;  // K = 1 for the single-key circuit
+    int prio;                 // raise the wave priority (s_setprio 3): wins VALU issue arbitration against the chain waves
+};
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 template <int NT>
-__global__ __launch_bounds__(BLSW_EXPAND_THREADS) void k_sha_expand(const uint32_t* __restrict__ bits, uint64_t sha_words, uint64_t first, uint32_t sha_bits,
-                                                    uint32_t off_expand, uint64_t* __restrict__ d_witness, uint64_t stride, uint32_t K, uint32_t stride_hash) {
-    constexpr uint32_t R1[12] = BLSW_R1_LIMBS;
-    // blockIdx.y = flat (instance, pair) index of the step; K = 1 for the single-key circuit
-    const uint64_t inst = K == 1 ? blockIdx.y : blockIdx.y / K;
-    const uint32_t pair = K == 1 ? 0u : blockIdx.y - (uint32_t)inst * K;
-    uint4* out = reinterpret_cast<uint4*>(d_witness + (inst * stride + off_expand + (uint64_t)pair * stride_hash) * 6);
-    const uint64_t lane = first + blockIdx.y;
-    const uint32_t* b = bits + (lane >> 6) * sha_words * 64 + (lane & 63);
-    // The segment is a stream of 16-byte pieces (piece p = element p / 3, column p % 3) that starts at an arbitrary multiple
-    // of 16 bytes (instance vectors are 33 956 496 bytes apart). Pieces are assigned from the first 256-byte boundary on
-    // (P0 < 16 head pieces are written by block 0 as well), so every 1 KiB wave store covers whole 128-byte lines.
-    const uint32_t P0 = (16u - (uint32_t)((reinterpret_cast<uintptr_t>(out) >> 4) & 15u)) & 15u;
-    const uint32_t t = threadIdx.x, pt = P0 + t, c = pt % 3;
-    const uint32_t e0 = blockIdx.x * (BLSW_EXPAND_EPI * BLSW_EXPAND_ITERS) + pt / 3;
-    if (blockIdx.x == 0 && t < P0) {  // head pieces
-        const uint32_t he = t / 3, hc = t % 3;
-        uint32_t w = b[0];
-        uint32_t m = 0u - ((w >> he) & 1u);
-        out[(uint64_t)he * 3 + hc] = make_uint4(R1[4 * hc] & m, R1[4 * hc + 1] & m, R1[4 * hc + 2] & m, R1[4 * hc + 3] & m);
+__device__ __forceinline__ void expand_store(uint4* dst, const uint4& v) {
+    if (NT == 2) {
+        u32x4 vv = {v.x, v.y, v.z, v.w};
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(vv) : "memory");
+    } else if (NT == 3) {
+        u32x4 vv = {v.x, v.y, v.z, v.w};
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(vv) : "memory");
+    } else if (NT == 1) {
+        __builtin_nontemporal_store(v.x, &dst->x);
+        __builtin_nontemporal_store(v.y, &dst->y);
+        __builtin_nontemporal_store(v.z, &dst->z);
+        __builtin_nontemporal_store(v.w, &dst->w);
+    } else {
+        *dst = v;
     }
+}
+__device__ __forceinline__ uint4 expand_column(uint32_t c) {
+    constexpr uint32_t R1[12] = BLSW_R1_LIMBS;
     uint4 rc;
     rc.x = c == 0 ? R1[0] : (c == 1 ? R1[4] : R1[8]);
     rc.y = c == 0 ? R1[1] : (c == 1 ? R1[5] : R1[9]);
     rc.z = c == 0 ? R1[2] : (c == 1 ? R1[6] : R1[10]);
     rc.w = c == 0 ? R1[3] : (c == 1 ? R1[7] : R1[11]);
-#pragma unroll BLSW_EXPAND_UNROLL
-    for (int k = 0; k < BLSW_EXPAND_ITERS; k++) {
-        uint32_t e = e0 + BLSW_EXPAND_EPI * k;
-        if (e < sha_bits) {
-            uint32_t w = b[(uint64_t)(e >> 5) * 64];
-            uint32_t m = 0u - ((w >> (e & 31)) & 1u);
-            uint4 v = make_uint4(rc.x & m, rc.y & m, rc.z & m, rc.w & m);
-            if (NT == 2) {
-                uint4* dst = &out[(uint64_t)e * 3 + c];
-                u32x4 vv = {v.x, v.y, v.z, v.w};
-                asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(vv) : "memory");
-            } else if (NT == 3) {
-                uint4* dst = &out[(uint64_t)e * 3 + c];
-                u32x4 vv = {v.x, v.y, v.z, v.w};
-                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(vv) : "memory");
-            } else if (NT == 1) {
-                __builtin_nontemporal_store(v.x, &out[(uint64_t)e * 3 + c].x);
-                __builtin_nontemporal_store(v.y, &out[(uint64_t)e * 3 + c].y);
-                __builtin_nontemporal_store(v.z, &out[(uint64_t)e * 3 + c].z);
-                __builtin_nontemporal_store(v.w, &out[(uint64_t)e * 3 + c].w);
-            } else {
-                out[(uint64_t)e * 3 + c] = v;
-            }
+    return rc;
+}
+// instance / pair of this workgroup: where its segment starts and where its bit words are
+__device__ __forceinline__ void expand_locate(const ExpandArgs& a, uint4*& out, const uint32_t*& b) {
+    const uint64_t inst = a.K == 1 ? blockIdx.y : blockIdx.y / a.K;
+    const uint32_t pair = a.K == 1 ? 0u : blockIdx.y - (uint32_t)inst * a.K;
+    out = reinterpret_cast<uint4*>(a.d_witness + (inst * a.stride + a.off_expand + (uint64_t)pair * a.stride_hash) * 6);
+    const uint64_t lane = a.first + blockIdx.y;
+    b = a.bits + (lane >> 6) * a.sha_words * 64 + (lane & 63);
+}
+// pieces [0, P0) in front of the first boundary: written by workgroup 0 of every variant
+template <int NT>
+__device__ __forceinline__ void expand_head(uint4* out, const uint32_t* b, uint32_t P0, uint32_t n_pieces) {
+    if (blockIdx.x == 0 && threadIdx.x < P0 && threadIdx.x < n_pieces) {
+        const uint32_t e = threadIdx.x / 3, c = threadIdx.x - 3 * e;
+        const uint32_t m = 0u - ((b[(uint64_t)(e >> 5) * 64] >> (e & 31)) & 1u);
+        const uint4 rc = expand_column(c);
+        expand_store<NT>(&out[threadIdx.x], make_uint4(rc.x & m, rc.y & m, rc.z & m, rc.w & m));
+    }
+}
+// variant 0 (and, with THREADS = 768 and 4 KiB alignment, variants 2 / 3): THREADS is a multiple of 192, so a thread's column is a
+// loop invariant; a workgroup writes THREADS * ITERS consecutive pieces, THREADS of them per iteration
+template <int THREADS, int ITERS, int ALIGN_PIECES, int NT>
+__global__ __launch_bounds__(THREADS) void k_sha_expand(ExpandArgs a) {
+    if (a.prio) __builtin_amdgcn_s_setprio(3);
+    uint4* out;
+    const uint32_t* b;
+    expand_locate(a, out, b);
+    const uint32_t n_pieces = a.sha_bits * 3;
+    const uint32_t P0 = (ALIGN_PIECES - (uint32_t)((reinterpret_cast<uintptr_t>(out) >> 4) % ALIGN_PIECES)) % ALIGN_PIECES;
+    expand_head<NT>(out, b, P0, n_pieces);
+    const uint32_t pt = P0 + threadIdx.x, c = pt % 3;
+    const uint32_t e0 = blockIdx.x * ((THREADS / 3) * ITERS) + pt / 3;
+    const uint4 rc = expand_column(c);
+#pragma unroll
+    for (int k = 0; k < ITERS; k++) {
+        const uint32_t e = e0 + (THREADS / 3) * k;
+        if (e < a.sha_bits) {
+            const uint32_t w = b[(uint64_t)(e >> 5) * 64];
+            const uint32_t m = 0u - ((w >> (e & 31)) & 1u);
+            expand_store<NT>(&out[(uint64_t)e * 3 + c], make_uint4(rc.x & m, rc.y & m, rc.z & m, rc.w & m));
         }
+    }
+}
+// variant 1: one piece per thread, workgroup b >= 1 writes exactly one 4 KiB-aligned chunk
+template <int NT>
+__global__ __launch_bounds__(256) void k_sha_expand_chunk(ExpandArgs a) {
+    if (a.prio) __builtin_amdgcn_s_setprio(3);
+    uint4* out;
+    const uint32_t* b;
+    expand_locate(a, out, b);
+    const uint32_t n_pieces = a.sha_bits * 3;
+    const uint32_t P0 = (256 - (uint32_t)((reinterpret_cast<uintptr_t>(out) >> 4) % 256)) % 256;
+    expand_head<NT>(out, b, P0, n_pieces);
+    const uint32_t p = P0 + blockIdx.x * 256 + threadIdx.x;
+    if (p >= n_pieces) return;
+    const uint32_t e = p / 3, c = p - 3 * e;
+    const uint32_t m = 0u - ((b[(uint64_t)(e >> 5) * 64] >> (e & 31)) & 1u);
+    const uint4 rc = expand_column(c);
+    expand_store<NT>(&out[p], make_uint4(rc.x & m, rc.y & m, rc.z & m, rc.w & m));
+}
+// variant: low byte 0..3 = geometry, bit 8 = raised wave priority; store: 0 plain, 1 nontemporal, 2 sc1, 3 sc0 sc1 (variant 0 only)
+static void launch_expand(uint32_t variant, uint32_t store, unsigned lds, hipStream_t st, ExpandArgs a, unsigned n_y) {
+    a.prio = (variant >> 8) & 1;
+    const uint32_t n_pieces = a.sha_bits * 3;
+    auto grid = [&](uint32_t per_wg) { return dim3((n_pieces + per_wg - 1) / per_wg + 1, n_y); };
+    switch (variant & 0xff) {
+        case 1: hipLaunchKernelGGL(k_sha_expand_chunk<0>, grid(256), dim3(256), lds, st, a); break;
+        case 2: hipLaunchKernelGGL((k_sha_expand<768, 8, 256, 0>), grid(768 * 8), dim3(768), lds, st, a); break;
+        case 3: hipLaunchKernelGGL((k_sha_expand<768, 4, 256, 0>), grid(768 * 4), dim3(768), lds, st, a); break;
+        default:
+            switch (store) {
+                case 1: hipLaunchKernelGGL((k_sha_expand<384, 8, 16, 1>), grid(384 * 8), dim3(384), lds, st, a); break;
+                case 2: hipLaunchKernelGGL((k_sha_expand<384, 8, 16, 2>), grid(384 * 8), dim3(384), lds, st, a); break;
+                case 3: hipLaunchKernelGGL((k_sha_expand<384, 8, 16, 3>), grid(384 * 8), dim3(384), lds, st, a); break;
+                default: hipLaunchKernelGGL((k_sha_expand<384, 8, 16, 0>), grid(384 * 8), dim3(384), lds, st, a); break;
+            }
     }
 }
 // Engine mode: the field witnesses of one step are moved into place around the SHA segment. Rows below split_row are staged
@@ -792,6 +846,7 @@ struct DeviceGuard {
 // Field witnesses go to a staging area (coalesced stores). n_buffers group buffers rotate, so the next groups' chains
 // overlap the previous groups' placement.
 #define BLSW_MAX_BUFFERS 32
+#define BLSW_DEFAULT_EXPAND_VARIANT 0x102  // 768 x 8 in 4 KiB-aligned chunks, raised wave priority: +3..5 % over variant 0 in the pipeline (same box, same run)
 #define BLSW_MAX_TIMED 1024
 #define BLSW_MAX_CONSUMED 64
 struct GroupBuf {
@@ -923,18 +978,10 @@ static int launch_group(blsw_engine* e) {
                     hipStreamWaitEvent(e->expand, e->consumed_ev[c], 0);
                     e->consumed_live[c] = false;
                 }
-            dim3 grid((e->L.sha_bits + BLSW_EXPAND_EPI * BLSW_EXPAND_ITERS - 1) / (BLSW_EXPAND_EPI * BLSW_EXPAND_ITERS), (unsigned)e->n);
             const bool timed = e->n_timed < BLSW_MAX_TIMED;
             if (timed) hipEventRecord(e->ev_exp[2 * e->n_timed], e->expand);
-#define BLSW_LAUNCH_EXPAND(MODE)                                                                                                                         \
-    hipLaunchKernelGGL(k_sha_expand<MODE>, grid, dim3(BLSW_EXPAND_THREADS), e->opt.place_lds, e->expand, g.ws.bits, g.ws.sha_words, (uint64_t)s * e->n, \
-                       e->L.sha_bits, e->L.off_expand, d.out, d.out_stride, 1u, 0u)
-            switch (e->opt.expand_store) {
-                case 0: BLSW_LAUNCH_EXPAND(0); break;
-                case 2: BLSW_LAUNCH_EXPAND(2); break;
-                case 3: BLSW_LAUNCH_EXPAND(3); break;
-                default: BLSW_LAUNCH_EXPAND(1); break;
-            }
+            ExpandArgs xa = {g.ws.bits, g.ws.sha_words, (uint64_t)s * e->n, e->L.sha_bits, e->L.off_expand, d.out, d.out_stride, 1u, 0u, 0};
+            launch_expand(e->opt.expand_variant, e->opt.expand_store, e->opt.place_lds, e->expand, xa, (unsigned)e->n);
             if (timed) {
                 hipEventRecord(e->ev_exp[2 * e->n_timed + 1], e->expand);
                 e->n_timed++;
@@ -989,6 +1036,7 @@ int blsw_engine_options_default(blsw_engine_options_t* o) {
     o->device = -1;
     o->pairing_mode = (p && p[0] == 'l') ? 1u : 0u;
     o->g2_mode = (g2 && g2[0] == 't' && o->pairing_mode == 0) ? 1u : 0u;
+    o->expand_variant = env_u32("BLSW_EXPAND_VARIANT", BLSW_DEFAULT_EXPAND_VARIANT);
     o->expand_store = env_u32("BLSW_EXPAND_NT", 0);  // plain stores: nontemporal ones cost 8-10 % since the chains' stack traffic was cut
     o->prio_mode = env_u32("BLSW_PRIO_MODE", 1);
     o->place_lds = env_u32("BLSW_PLACE_LDS", 0);
@@ -1016,7 +1064,7 @@ int blsw_engine_create_ex(blsw_engine_t** out, uint64_t n, uint32_t msg_len, uin
     if (!out || n == 0 || n > 0x7fffffffu || max_steps == 0 || !d_workspace || n_buffers == 0 || n_buffers > BLSW_MAX_BUFFERS || !options || msg_len > 65535)
         return BLSW_ERR_ARG;
     if (options->pairing_mode > 1 || options->g2_mode > 1 || (options->g2_mode == 1 && options->pairing_mode != 0) || options->expand_store > 3 ||
-        options->prio_mode > 2)
+        options->prio_mode > 2 || (options->expand_variant & 0xff) > 3 || (options->expand_variant >> 9))
         return BLSW_ERR_ARG;
     *out = nullptr;
     int ndev = 0;
@@ -1347,9 +1395,8 @@ int blsw_aggregate_verify_batch(const uint64_t* d_pks_xy, const uint8_t* d_bitma
     hipLaunchKernelGGL(k_prepare, dim3(g1), dim3(64), 0, st, g, 1);
     hipLaunchKernelGGL(k_sha, dim3(g1), dim3(64), 0, st, g, d_witness ? 1 : 0, 1);
     if (d_witness) {
-        dim3 grid((g.L.sha_bits + BLSW_EXPAND_EPI * BLSW_EXPAND_ITERS - 1) / (BLSW_EXPAND_EPI * BLSW_EXPAND_ITERS), (unsigned)n);
-        hipLaunchKernelGGL(k_sha_expand<0>, grid, dim3(BLSW_EXPAND_THREADS), 0, st, g.ws.bits, g.ws.sha_words, (uint64_t)0, g.L.sha_bits, g.L.off_expand, d_witness,
-                           witness_stride, 1u, 0u);
+        ExpandArgs xa = {g.ws.bits, g.ws.sha_words, 0, g.L.sha_bits, g.L.off_expand, d_witness, witness_stride, 1u, 0u, 0};
+        launch_expand(BLSW_DEFAULT_EXPAND_VARIANT, 0, 0, st, xa, (unsigned)n);
     }
     hipLaunchKernelGGL(k_map, dim3(g2), dim3(64), 0, st, g);
     hipLaunchKernelGGL(k_cofactor, dim3(g1), dim3(64), 0, st, g);
@@ -1395,11 +1442,11 @@ int blsw_verify_multi_batch(const uint64_t* d_pks_xy, const uint8_t* d_msgs, uin
     hipLaunchKernelGGL(k_sha, dim3(p1), dim3(64), 0, st, gp, d_witness ? 1 : 0, 1);
     if (d_witness) {
         // blockIdx.y = flat (instance, pair); grid.y <= 65535: several launches for larger batches
-        const unsigned bx = (L.sha_bits + BLSW_EXPAND_EPI * BLSW_EXPAND_ITERS - 1) / (BLSW_EXPAND_EPI * BLSW_EXPAND_ITERS);
-        for (uint64_t first = 0; first < NP; first += (65535 / n_pairs) * (uint64_t)n_pairs) {
-            const uint64_t cnt = NP - first < (65535 / n_pairs) * (uint64_t)n_pairs ? NP - first : (65535 / n_pairs) * (uint64_t)n_pairs;
-            hipLaunchKernelGGL(k_sha_expand<0>, dim3(bx, (unsigned)cnt), dim3(BLSW_EXPAND_THREADS), 0, st, ws.bits, ws.sha_words, first, L.sha_bits, L.off_expand,
-                               d_witness + (first / n_pairs) * witness_stride * 6, witness_stride, n_pairs, L.stride_hash);
+        const uint64_t per_launch = (65535 / n_pairs) * (uint64_t)n_pairs;
+        for (uint64_t first = 0; first < NP; first += per_launch) {
+            const uint64_t cnt = NP - first < per_launch ? NP - first : per_launch;
+            ExpandArgs xa = {ws.bits, ws.sha_words, first, L.sha_bits, L.off_expand, d_witness + (first / n_pairs) * witness_stride * 6, witness_stride, n_pairs, L.stride_hash, 0};
+            launch_expand(BLSW_DEFAULT_EXPAND_VARIANT, 0, 0, st, xa, (unsigned)cnt);
         }
     }
     hipLaunchKernelGGL(k_map, dim3(p2), dim3(64), 0, st, gp);

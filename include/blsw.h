@@ -102,11 +102,13 @@ typedef struct {
     int32_t device;        /* HIP device ordinal, -1 = the current device */
     uint32_t pairing_mode; /* 0 = six lanes per instance (default), 1 = one lane per instance (9.7 KB stack: A/B runs only) */
     uint32_t g2_mode;      /* 0 = one lane per instance (default), 1 = six lanes per instance (needs pairing_mode 0) */
-    uint32_t expand_store; /* stores of the SHA expansion kernel: 0 plain (default), 1 nontemporal, 2 sc1, 3 sc0 sc1 */
+    uint32_t expand_variant; /* store geometry of the SHA expansion kernel, low byte: 0 = 384 threads x 8 pieces, 1 = one 4 KiB-aligned
+                              * chunk per 256-thread workgroup, 2 / 3 = 768 threads x 8 / 4 pieces in 4 KiB-aligned chunks; | 0x100 = raised wave priority */
+    uint32_t expand_store; /* stores of the SHA expansion kernel: 0 plain (default), 1 nontemporal, 2 sc1, 3 sc0 sc1 (variant 0) */
     uint32_t prio_mode;    /* stream priorities: 0 chains high, 1 placement high (default), 2 equal */
     uint32_t place_lds;    /* optional occupancy limiter of the expansion kernel: bytes of dynamic LDS per workgroup */
 } blsw_engine_options_t;
-/* defaults; the environment variables BLSW_PAIRING=lane, BLSW_G2=team, BLSW_EXPAND_NT, BLSW_PRIO_MODE, BLSW_PLACE_LDS override
+/* defaults; the environment variables BLSW_PAIRING=lane, BLSW_G2=team, BLSW_EXPAND_VARIANT, BLSW_EXPAND_NT, BLSW_PRIO_MODE, BLSW_PLACE_LDS override
  * them HERE (read at every call, nothing is cached per process), so A/B runs need no recompilation */
 int blsw_engine_options_default(blsw_engine_options_t* out);
 int blsw_engine_workspace_bytes(uint64_t n, uint32_t msg_len, uint32_t max_steps, uint32_t n_buffers, uint64_t* bytes);
