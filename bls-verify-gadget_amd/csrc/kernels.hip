@@ -183,10 +183,14 @@ __global__ __launch_bounds__(64) void k_sha(Group g, int want_bits, int write_u)
         uint32_t b = msg[k];
         for (int j = 0; j < 8; j++) em.put_bool((b >> j) & 1);
     }
-    BitSink s;
-    s.init(want_bits ? g.ws.bits + (I >> 6) * g.ws.sha_words * 64 + (I & 63) : nullptr, 64);
     uint32_t uw[64];
-    expand_message_w(s, msg, g.msg_len, false, uw);
+    if (want_bits) {
+        BitSink s;
+        s.init(g.ws.bits + (I >> 6) * g.ws.sha_words * 64 + (I & 63), 64);
+        expand_message_w(s, msg, g.msg_len, false, uw);
+    } else {
+        expand_message_values(msg, g.msg_len, uw);  // the device sink always stores: no bits wanted = the value-only SHA
+    }
     if (write_u)
         for (int j = 0; j < 4; j++) st_fp(g.ws.u + (uint64_t)j * g.N + I, hash_to_field_elem(uw + 16 * j));
 }

@@ -41,9 +41,13 @@ BLSW_HD int popc32(uint32_t x) {
 #endif
 }
 
-// Bit sink: either counts bits (layout) or packs them into 32-bit words stored at out[word * stride]
+// Bit sink: either counts bits (layout, host only) or packs them into 32-bit words stored at out[word * stride].
+// Hot code works on a LOCAL COPY of the sink (sha_block_w): through a reference, every store to `out` (a uint32_t*) may alias
+// the sink's own fields and forces them through memory around each append. On the device the sink always stores (kernels
+// that do not want the bits run the value-only SHA instead).
 struct BitSink {
-    uint32_t* out;    // nullptr = count only
+    uint32_t* out;    // nullptr = count only (host)
+    uint32_t* cur;    // where the next word goes
     uint64_t stride;  // distance (in u32) between consecutive words of this lane's stream
     uint64_t acc;
     uint32_t fill;
@@ -51,27 +55,44 @@ struct BitSink {
     uint64_t nbits;
     BLSW_HD void init(uint32_t* o, uint64_t s) {
         out = o;
+        cur = o;
         stride = s;
         acc = 0;
         fill = 0;
         widx = 0;
         nbits = 0;
     }
+    BLSW_HD void word_out() {
+#if defined(__HIP_DEVICE_COMPILE__)
+        *cur = (uint32_t)acc;
+        cur += stride;
+#else
+        if (out) out[(uint64_t)widx * stride] = (uint32_t)acc;
+#endif
+        widx++;
+        acc >>= 32;
+    }
     BLSW_HD void push(uint32_t bits, uint32_t n) {  // n <= 32, bits above n must be zero
-        nbits += n;
+#if !defined(__HIP_DEVICE_COMPILE__)
+        nbits += n;  // host: the layout's bit count
+#endif
         acc |= (uint64_t)bits << fill;
         fill += n;
         if (fill >= 32) {
-            if (out) out[(uint64_t)widx * stride] = (uint32_t)acc;
-            widx++;
-            acc >>= 32;
+            word_out();
             fill -= 32;
         }
     }
+    BLSW_HD void push32(uint32_t bits) {  // fill is unchanged
+#if !defined(__HIP_DEVICE_COMPILE__)
+        nbits += 32;
+#endif
+        acc |= (uint64_t)bits << fill;
+        word_out();
+    }
     BLSW_HD void flush() {
         if (fill) {
-            if (out) out[(uint64_t)widx * stride] = (uint32_t)acc;
-            widx++;
+            word_out();
             acc = 0;
             fill = 0;
         }
@@ -126,9 +147,11 @@ BLSW_HD W32 w_addmany(BitSink& s, const W32* ops, int k) {
         0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19 \
     }
 
-// Sha256Gadget::update_state
-BLSW_FN void sha_block_w(BitSink& s, W32 st[8], const W32 data[16]) {
+// Sha256Gadget::update_state, any mix of constant / variable bits (mask tracking on every operation; the schedule lives in a
+// dynamically indexed array). Reference statement of the gadget: sha_block_w below must emit the same bits.
+BLSW_FN void sha_block_generic(BitSink& sink, W32 st[8], const W32 data[16]) {
     constexpr uint32_t K[64] = BLSW_SHA_K;
+    BitSink s = sink;  // registers from here on (see BitSink)
     W32 w[64];
     for (int i = 0; i < 16; i++) w[i] = data[i];
 #pragma unroll 1
@@ -175,6 +198,182 @@ BLSW_FN void sha_block_w(BitSink& s, W32 st[8], const W32 data[16]) {
         W32 o[2] = {st[i], h[i]};
         st[i] = w_addmany(s, o, 2);
     }
+    sink = s;
+}
+
+// ---- fast path. Which bits are constants is the same for every lane, and after a few operations almost every word is
+// "pure": all 32 bits variables (cm = nm = 0) or all constants. Pure words need no mask arithmetic and no bit extraction:
+// an XOR / AND of two variable words is one 32-bit append, the sigma functions append 32 + 29 (or 22) bits, addmany appends
+// 33 / 34 / 35 bits. The message schedule runs in a rolling 16-word window in registers (static indexing) and is recomputed,
+// values only, during the rounds (the gadget allocates the whole schedule before the first round, so its witnesses cannot
+// be produced on the fly); words with partially constant bits take the generic operation in place.
+BLSW_HD bool w_is_const(const W32& a) { return a.cm == 0xffffffffu; }
+BLSW_HD bool w_is_var(const W32& a) { return (a.cm | a.nm) == 0u; }
+BLSW_HD uint32_t sigma_var(BitSink& s, uint32_t x, int r1, int r2, int sh) {  // both XOR witnesses of a sigma on a variable word
+    const uint32_t a = rotr32(x, r1) ^ rotr32(x, r2);
+    s.push32(a);
+    const uint32_t r = a ^ (x >> sh);
+    s.push(r & (0xffffffffu >> sh), 32 - sh);
+    return r;
+}
+// one word of the message schedule: w[i] = addmany(w[i-16], sigma0(w[i-15]), w[i-7], sigma1(w[i-2]))
+BLSW_HD W32 sha_sched_word(BitSink& s, const W32& w16, const W32& w15, const W32& w7, const W32& w2) {
+    W32 s0, s1;
+    if (w_is_var(w15))
+        s0 = {sigma_var(s, w15.v, 7, 18, 3), 0u, 0u};
+    else if (w_is_const(w15))
+        s0 = w_const(rotr32(w15.v, 7) ^ rotr32(w15.v, 18) ^ (w15.v >> 3));
+    else
+        s0 = w_xor(s, w_xor(s, w_rotr(w15, 7), w_rotr(w15, 18)), w_shr(w15, 3));
+    if (w_is_var(w2))
+        s1 = {sigma_var(s, w2.v, 17, 19, 10), 0u, 0u};
+    else if (w_is_const(w2))
+        s1 = w_const(rotr32(w2.v, 17) ^ rotr32(w2.v, 19) ^ (w2.v >> 10));
+    else
+        s1 = w_xor(s, w_xor(s, w_rotr(w2, 17), w_rotr(w2, 19)), w_shr(w2, 10));
+    const uint32_t sum32 = w16.v + s0.v + w7.v + s1.v;
+    if ((w16.cm & s0.cm & w7.cm & s1.cm) == 0xffffffffu) return w_const(sum32);
+    const uint64_t sum = (uint64_t)w16.v + s0.v + w7.v + s1.v;
+    s.push32((uint32_t)sum);
+    s.push((uint32_t)(sum >> 32), 2);
+    return {sum32, 0u, 0u};
+}
+BLSW_HD uint32_t sha_sched_value(uint32_t w16, uint32_t w15, uint32_t w7, uint32_t w2) {
+    return w16 + (rotr32(w15, 7) ^ rotr32(w15, 18) ^ (w15 >> 3)) + w7 + (rotr32(w2, 17) ^ rotr32(w2, 19) ^ (w2 >> 10));
+}
+// one round on mask-carrying state (the generic statement of a round; used for the first rounds on a constant state)
+BLSW_HD void sha_round_generic(BitSink& s, W32 h[8], const W32& wi, uint32_t k) {
+    W32 c1 = w_and(s, h[4], h[5]);
+    W32 c2 = w_and(s, w_not(h[4]), h[6]);
+    W32 ch = w_xor(s, c1, c2);
+    W32 m1 = w_and(s, h[0], h[1]);
+    W32 m2 = w_and(s, h[0], h[2]);
+    W32 m3 = w_and(s, h[1], h[2]);
+    W32 m12 = w_xor(s, m1, m2);
+    W32 ma = w_xor(s, m12, m3);
+    W32 p1 = w_xor(s, w_rotr(h[0], 2), w_rotr(h[0], 13));
+    W32 s0 = w_xor(s, p1, w_rotr(h[0], 22));
+    W32 q1 = w_xor(s, w_rotr(h[4], 6), w_rotr(h[4], 11));
+    W32 s1 = w_xor(s, q1, w_rotr(h[4], 25));
+    W32 o5[5] = {h[7], s1, ch, w_const(k), wi};
+    W32 t0 = w_addmany(s, o5, 5);
+    W32 o2[2] = {s0, ma};
+    W32 t1 = w_addmany(s, o2, 2);
+    h[7] = h[6];
+    h[6] = h[5];
+    h[5] = h[4];
+    W32 o3[2] = {h[3], t0};
+    h[4] = w_addmany(s, o3, 2);
+    h[3] = h[2];
+    h[2] = h[1];
+    h[1] = h[0];
+    W32 o4[2] = {t0, t1};
+    h[0] = w_addmany(s, o4, 2);
+}
+// one round on a fully variable state: twelve 32-bit appends (ch: 3, maj: 5, Sigma0: 2, Sigma1: 2) and four addmany results
+BLSW_HD void sha_round_var(BitSink& s, uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d, uint32_t& e, uint32_t& f, uint32_t& g, uint32_t& h, uint32_t kw_lo,
+                           uint32_t kw_hi) {
+    const uint32_t c1 = e & f;
+    s.push32(c1);
+    const uint32_t c2 = ~e & g;
+    s.push32(c2);
+    const uint32_t ch = c1 ^ c2;
+    s.push32(ch);
+    const uint32_t m1 = a & b, m2 = a & c, m3 = b & c;
+    s.push32(m1);
+    s.push32(m2);
+    s.push32(m3);
+    const uint32_t m12 = m1 ^ m2;
+    s.push32(m12);
+    const uint32_t ma = m12 ^ m3;
+    s.push32(ma);
+    const uint32_t p1 = rotr32(a, 2) ^ rotr32(a, 13);
+    s.push32(p1);
+    const uint32_t s0 = p1 ^ rotr32(a, 22);
+    s.push32(s0);
+    const uint32_t q1 = rotr32(e, 6) ^ rotr32(e, 11);
+    s.push32(q1);
+    const uint32_t s1 = q1 ^ rotr32(e, 25);
+    s.push32(s1);
+    // t0 = addmany(h, s1, ch, K, w): 35 result bits; (kw_lo, kw_hi) = K + w as a 33-bit number
+    const uint64_t t0 = (uint64_t)h + s1 + ch + kw_lo + ((uint64_t)kw_hi << 32);
+    s.push32((uint32_t)t0);
+    s.push((uint32_t)(t0 >> 32), 3);
+    const uint64_t t1 = (uint64_t)s0 + ma;
+    s.push32((uint32_t)t1);
+    s.push((uint32_t)(t1 >> 32), 1);
+    const uint64_t ne = (uint64_t)d + (uint32_t)t0;
+    s.push32((uint32_t)ne);
+    s.push((uint32_t)(ne >> 32), 1);
+    const uint64_t na = (uint64_t)(uint32_t)t0 + (uint32_t)t1;
+    s.push32((uint32_t)na);
+    s.push((uint32_t)(na >> 32), 1);
+    h = g;
+    g = f;
+    f = e;
+    e = (uint32_t)ne;
+    d = c;
+    c = b;
+    b = a;
+    a = (uint32_t)na;
+}
+// Sha256Gadget::update_state
+BLSW_FN void sha_block_w(BitSink& sink, W32 st[8], const W32 data[16]) {
+    constexpr uint32_t K[64] = BLSW_SHA_K;
+    // the state is fully variable (continuation blocks), or fully constant with a first data word that is not (first block
+    // of a digest: a and e become variables in round 0, the whole state after four rounds); anything else: generic
+    bool all_var = true, all_const = true;
+    for (int i = 0; i < 8; i++) {
+        all_var = all_var && w_is_var(st[i]);
+        all_const = all_const && w_is_const(st[i]);
+    }
+    if (!(all_var || (all_const && !w_is_const(data[0])))) {
+        sha_block_generic(sink, st, data);
+        return;
+    }
+    BitSink s = sink;  // registers from here on (see BitSink)
+    // ---- message schedule: all 48 words, in allocation order
+    W32 win[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) win[j] = data[j];
+#pragma unroll 1
+    for (int c = 0; c < 3; c++) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) win[j] = sha_sched_word(s, win[j], win[(j + 1) & 15], win[(j + 9) & 15], win[(j + 14) & 15]);
+    }
+    // ---- rounds
+    W32 h[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) h[i] = st[i];
+    const int prefix = all_var ? 0 : 4;
+    if (!all_var) {
+#pragma unroll 1
+        for (int r = 0; r < 4; r++) sha_round_generic(s, h, data[r], K[r]);
+    }
+    uint32_t a = h[0].v, b = h[1].v, cc = h[2].v, d = h[3].v, e = h[4].v, f = h[5].v, g = h[6].v, hh = h[7].v;
+    uint32_t wv[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) wv[j] = data[j].v;
+#pragma unroll 1
+    for (int c = 0; c < 4; c++) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            if (c > 0) wv[j] = sha_sched_value(wv[j], wv[(j + 1) & 15], wv[(j + 9) & 15], wv[(j + 14) & 15]);
+            if (c > 0 || j >= prefix) {
+                const uint64_t kw = (uint64_t)K[16 * c + j] + wv[j];
+                sha_round_var(s, a, b, cc, d, e, f, g, hh, (uint32_t)kw, (uint32_t)(kw >> 32));
+            }
+        }
+    }
+    const uint32_t fin[8] = {a, b, cc, d, e, f, g, hh};
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint64_t sum = (uint64_t)st[i].v + fin[i];  // addmany(st[i], h[i]): h[i] is a variable, 33 result bits
+        s.push32((uint32_t)sum);
+        s.push((uint32_t)(sum >> 32), 1);
+        st[i] = {(uint32_t)sum, 0u, 0u};
+    }
+    sink = s;
 }
 
 #define BLSW_DST "BLS_SIG_BLS12381G2_XMD:SHA-256_SSWU_RO_POP_"
