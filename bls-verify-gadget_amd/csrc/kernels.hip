@@ -283,13 +283,30 @@ __global__ __launch_bounds__(THREADS) void k_sha_expand(ExpandArgs a) {
     const uint32_t pt = P0 + threadIdx.x, c = pt % 3;
     const uint32_t e0 = blockIdx.x * ((THREADS / 3) * ITERS) + pt / 3;
     const uint4 rc = expand_column(c);
+    // THREADS / 3 is a multiple of 32: the bit position of a thread is a loop invariant too, its word advances by THREADS / 96
+    static_assert((THREADS / 3) % 32 == 0, "bit position must be loop invariant");
+    const uint32_t sh = e0 & 31;
+    const uint32_t* bw = b + (uint64_t)(e0 >> 5) * 64;
+    uint4* dst = out + (uint64_t)e0 * 3 + c;
+    if (blockIdx.x * ((THREADS / 3) * ITERS) + (P0 + THREADS - 1) / 3 + (THREADS / 3) * (ITERS - 1) < a.sha_bits) {
+        // whole workgroup in range (all but the last one or two of an instance): all bit words first, then the stores back to
+        // back — no bounds checks, no wait between a store and the next load
+        uint32_t w[ITERS];
 #pragma unroll
+        for (int k = 0; k < ITERS; k++) w[k] = bw[(uint64_t)k * (THREADS / 96) * 64];
+#pragma unroll
+        for (int k = 0; k < ITERS; k++) {
+            const uint32_t m = 0u - ((w[k] >> sh) & 1u);
+            expand_store<NT>(dst + (uint64_t)k * THREADS, make_uint4(rc.x & m, rc.y & m, rc.z & m, rc.w & m));
+        }
+        return;
+    }
+#pragma unroll 1
     for (int k = 0; k < ITERS; k++) {
         const uint32_t e = e0 + (THREADS / 3) * k;
         if (e < a.sha_bits) {
-            const uint32_t w = b[(uint64_t)(e >> 5) * 64];
-            const uint32_t m = 0u - ((w >> (e & 31)) & 1u);
-            expand_store<NT>(&out[(uint64_t)e * 3 + c], make_uint4(rc.x & m, rc.y & m, rc.z & m, rc.w & m));
+            const uint32_t m = 0u - ((bw[(uint64_t)k * (THREADS / 96) * 64] >> sh) & 1u);
+            expand_store<NT>(dst + (uint64_t)k * THREADS, make_uint4(rc.x & m, rc.y & m, rc.z & m, rc.w & m));
         }
     }
 }
