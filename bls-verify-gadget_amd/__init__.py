@@ -12,7 +12,8 @@ import importlib.util
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libblsw.so")
+# BLSW_LIB: an alternative build of the same library (A/B runs of compile-time choices, tools/ab_build.sh); default: the in-tree one
+LIB_PATH = os.environ.get("BLSW_LIB") or os.path.join(HERE, "libblsw.so")
 
 FP_BYTES = 48
 _LAYOUT_FIELDS = (

@@ -18,11 +18,12 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    if not force and not needs_build():
+def build(force=False, verbose=False, out=None, defines=()):
+    """out / defines: an alternative build next to the shipped one (A/B runs: BLSW_LIB=<out> selects it at import)"""
+    if out is None and not force and not needs_build():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-o", OUT] + [os.path.join(CSRC, s) for s in SOURCES]
+    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-o", out or OUT] + list(defines) + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         cmd.append("-Rpass-analysis=kernel-resource-usage")
         print(" ".join(cmd), file=sys.stderr)
@@ -31,4 +32,6 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose=True)
+    # python build.py [--force] [--out <file.so> -DNAME=VALUE ...]
+    out = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else None
+    build(force="--force" in sys.argv, verbose=out is None, out=out, defines=[a for a in sys.argv[1:] if a.startswith("-D")])

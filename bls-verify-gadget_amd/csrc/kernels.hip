@@ -214,7 +214,7 @@ __global__ __launch_bounds__(64) void k_sha_values(Group g) {
 //   1  256-thread workgroups, ONE piece per thread, every workgroup writes one 4 KiB-aligned 4 KiB chunk of the address space
 //   2  768-thread workgroups, 8 pieces per thread 12 KiB apart: every iteration writes three 4 KiB-aligned chunks; column and
 //      bit position of a thread are loop invariants (768 = 3 * 256 pieces = 256 elements = 8 bit words per iteration)
-//   3  as 2 with 4 pieces per thread
+//   3  as 2 with 4 pieces per thread;  4  as 2 with 16;  5  384 threads x 16 pieces, 4 KiB-aligned start
 struct ExpandArgs {
     const uint32_t* bits;
     uint64_t sha_words, first;
@@ -336,6 +336,8 @@ static void launch_expand(uint32_t variant, uint32_t store, unsigned lds, hipStr
         case 1: hipLaunchKernelGGL(k_sha_expand_chunk<0>, grid(256), dim3(256), lds, st, a); break;
         case 2: hipLaunchKernelGGL((k_sha_expand<768, 8, 256, 0>), grid(768 * 8), dim3(768), lds, st, a); break;
         case 3: hipLaunchKernelGGL((k_sha_expand<768, 4, 256, 0>), grid(768 * 4), dim3(768), lds, st, a); break;
+        case 4: hipLaunchKernelGGL((k_sha_expand<768, 16, 256, 0>), grid(768 * 16), dim3(768), lds, st, a); break;
+        case 5: hipLaunchKernelGGL((k_sha_expand<384, 16, 256, 0>), grid(384 * 16), dim3(384), lds, st, a); break;
         default:
             switch (store) {
                 case 1: hipLaunchKernelGGL((k_sha_expand<384, 8, 16, 1>), grid(384 * 8), dim3(384), lds, st, a); break;
@@ -806,6 +808,16 @@ __global__ __launch_bounds__(64) void k_bench_fpmul(uint32_t iters, uint32_t* ou
     if (a.l[0] == 0x12345678u && b.l[3] == 0x9abcdef0u) out[0] = a.l[1];
 }
 
+__global__ __launch_bounds__(64) void k_bench_fpmul32(uint32_t iters, uint32_t* out) {  // the 12 x 32-bit CIOS product (cross-check of fp_mul)
+    Fp a = fp_one(), b = fp_one();
+    a.l[0] ^= threadIdx.x + 1;
+    b.l[1] ^= blockIdx.x + 1;
+    for (uint32_t i = 0; i < iters; i++) {
+        a = fp_mul32(a, b);
+        b = fp_mul32(b, a);
+    }
+    if (a.l[0] == 0x12345678u && b.l[3] == 0x9abcdef0u) out[0] = a.l[1];
+}
 __global__ __launch_bounds__(64) void k_bench_fpinv(uint32_t iters, uint32_t* out) {
     Fp a = fp_one();
     a.l[0] ^= threadIdx.x * 2654435761u + 1;
@@ -867,7 +879,7 @@ struct DeviceGuard {
 // Field witnesses go to a staging area (coalesced stores). n_buffers group buffers rotate, so the next groups' chains
 // overlap the previous groups' placement.
 #define BLSW_MAX_BUFFERS 32
-#define BLSW_DEFAULT_EXPAND_VARIANT 0x102  // 768 x 8 in 4 KiB-aligned chunks, raised wave priority: +3..5 % over variant 0 in the pipeline (same box, same run)
+#define BLSW_DEFAULT_EXPAND_VARIANT 0  // 384 x 8: the geometry that stays fast beside every chain build (profiles/r02_ab_fpmul_expand.txt)
 #define BLSW_MAX_TIMED 1024
 #define BLSW_MAX_CONSUMED 64
 struct GroupBuf {
@@ -1085,7 +1097,7 @@ int blsw_engine_create_ex(blsw_engine_t** out, uint64_t n, uint32_t msg_len, uin
     if (!out || n == 0 || n > 0x7fffffffu || max_steps == 0 || !d_workspace || n_buffers == 0 || n_buffers > BLSW_MAX_BUFFERS || !options || msg_len > 65535)
         return BLSW_ERR_ARG;
     if (options->pairing_mode > 1 || options->g2_mode > 1 || (options->g2_mode == 1 && options->pairing_mode != 0) || options->expand_store > 3 ||
-        options->prio_mode > 2 || (options->expand_variant & 0xff) > 3 || (options->expand_variant >> 9))
+        options->prio_mode > 2 || (options->expand_variant & 0xff) > 5 || (options->expand_variant >> 9))
         return BLSW_ERR_ARG;
     *out = nullptr;
     int ndev = 0;
@@ -1494,14 +1506,14 @@ int blsw_hash_to_g2_workspace_bytes(uint64_t n, uint32_t msg_len, uint64_t* byte
 // which = 0: v_mad_u64_u32 issue rate (multiply-adds/s); 1: fp_mul (Fp products/s); 2: fp_inv (inversions/s); 3: Fp products/s inside
 // witness-emitting Fp2 mul + sqr. Synchronous, on the current device.
 int blsw_microbench(int which, uint32_t iters, uint32_t blocks, double* ops_per_s) {
-    if (!ops_per_s || iters == 0 || blocks == 0 || which < 0 || which > 3) return BLSW_ERR_ARG;
+    if (!ops_per_s || iters == 0 || blocks == 0 || which < 0 || which > 4) return BLSW_ERR_ARG;
     uint32_t* d = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int rc = hip_ok(hipMalloc(&d, 4), "malloc");
     if (!rc) rc = hip_ok(hipEventCreate(&e0), "event create");
     if (!rc) rc = hip_ok(hipEventCreate(&e1), "event create");
     const int threads = which == 0 ? 256 : 64;
-    const double per_iter[4] = {8.0, 2.0, 1.0, 5.0};  // MADs, fp products, fp inversions, fp products (one Fp2 mul + one Fp2 sqr)
+    const double per_iter[5] = {8.0, 2.0, 1.0, 5.0, 2.0};  // MADs, fp products, fp inversions, fp products (one Fp2 mul + one Fp2 sqr), fp products (32-bit CIOS)
     for (int rep = 0; rep < 2 && !rc; rep++) {        // first pass warms up
         hipEventRecord(e0, 0);
         if (which == 0)
@@ -1510,8 +1522,10 @@ int blsw_microbench(int which, uint32_t iters, uint32_t blocks, double* ops_per_
             hipLaunchKernelGGL(k_bench_fpmul, dim3(blocks), dim3(threads), 0, 0, iters, d);
         else if (which == 2)
             hipLaunchKernelGGL(k_bench_fpinv, dim3(blocks), dim3(threads), 0, 0, iters, d);
-        else
+        else if (which == 3)
             hipLaunchKernelGGL(k_bench_fp2mulw, dim3(blocks), dim3(threads), 0, 0, iters, d);
+        else
+            hipLaunchKernelGGL(k_bench_fpmul32, dim3(blocks), dim3(threads), 0, 0, iters, d);
         hipEventRecord(e1, 0);
         rc = hip_ok(hipEventSynchronize(e1), "event sync");
     }

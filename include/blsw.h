@@ -103,7 +103,7 @@ typedef struct {
     uint32_t pairing_mode; /* 0 = six lanes per instance (default), 1 = one lane per instance (9.7 KB stack: A/B runs only) */
     uint32_t g2_mode;      /* 0 = one lane per instance (default), 1 = six lanes per instance (needs pairing_mode 0) */
     uint32_t expand_variant; /* store geometry of the SHA expansion kernel, low byte: 0 = 384 threads x 8 pieces, 1 = one 4 KiB-aligned
-                              * chunk per 256-thread workgroup, 2 / 3 = 768 threads x 8 / 4 pieces in 4 KiB-aligned chunks; | 0x100 = raised wave priority */
+                              * chunk per 256-thread workgroup, 2 / 3 / 4 = 768 threads x 8 / 4 / 16 pieces in 4 KiB-aligned chunks, 5 = 384 x 16; | 0x100 = raised wave priority */
     uint32_t expand_store; /* stores of the SHA expansion kernel: 0 plain (default), 1 nontemporal, 2 sc1, 3 sc0 sc1 (variant 0) */
     uint32_t prio_mode;    /* stream priorities: 0 chains high, 1 placement high (default), 2 equal */
     uint32_t place_lds;    /* optional occupancy limiter of the expansion kernel: bytes of dynamic LDS per workgroup */
@@ -183,7 +183,8 @@ int blsw_sign_batch(const uint8_t* d_sk32_le, const uint8_t* d_msg, uint32_t msg
 
 /* Device micro-benchmarks that give the VALU roofline its MEASURED denominator:
  * which = 0: v_mad_u64_u32 rate (32x32+64 multiply-adds per second, all CUs); 1: Fp Montgomery products per second;
- * 2: Fp inversions (safegcd) per second; 3: Fp products per second inside witness-emitting Fp2 mul + sqr. */
+ * 2: Fp inversions (safegcd) per second; 3: Fp products per second inside witness-emitting Fp2 mul + sqr;
+ * 4: Fp products per second of the 12 x 32-bit CIOS formulation (cross-check of the shipped 14 x 28-bit one). */
 int blsw_microbench(int which, uint32_t iters, uint32_t blocks, double* ops_per_s);
 
 int blsw_version(void);

@@ -329,6 +329,10 @@ void hostsim_fp_mul(const uint64_t* a, const uint64_t* b, uint64_t* r) {
     Fp z = fp_mul(load_fp(a), load_fp(b));
     memcpy(r, z.l, 48);
 }
+void hostsim_fp_mul32(const uint64_t* a, const uint64_t* b, uint64_t* r) {
+    Fp z = fp_mul32(load_fp(a), load_fp(b));
+    memcpy(r, z.l, 48);
+}
 void hostsim_fp_inv(const uint64_t* a, uint64_t* r) {
     Fp z = fp_inv(load_fp(a));
     memcpy(r, z.l, 48);
