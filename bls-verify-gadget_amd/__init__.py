@@ -31,6 +31,14 @@ class blsw_engine_options_t(ctypes.Structure):
     _fields_ = [("device", ctypes.c_int32)] + [(n, ctypes.c_uint32) for n in "pairing_mode g2_mode expand_variant expand_store prio_mode place_lds".split()]
 
 
+class blsw_matrices_info_t(ctypes.Structure):
+    _fields_ = [("n_constraints", ctypes.c_uint64), ("n_instance_vars", ctypes.c_uint64), ("n_witness", ctypes.c_uint64), ("nnz", ctypes.c_uint64 * 3)]
+
+
+class blsw_matrices_t(ctypes.Structure):
+    _fields_ = [("row_ptr", ctypes.POINTER(ctypes.c_uint64) * 3), ("col", ctypes.POINTER(ctypes.c_uint32) * 3), ("val", ctypes.POINTER(ctypes.c_uint64) * 3)]
+
+
 class BlswError(RuntimeError):
     pass
 
@@ -67,6 +75,8 @@ def lib():
         L.blsw_engine_wait_step.argtypes = [vp, u64, vp]
         L.blsw_engine_output_consumed.argtypes = [vp, vp, vp]
         L.blsw_witness_digest.argtypes = [vp, u64, u64, u32, vp, vp]
+        L.blsw_matrices_info.argtypes = [u32, u32, u32, ctypes.POINTER(blsw_matrices_info_t)]
+        L.blsw_matrices_fill.argtypes = [u32, u32, u32, ctypes.POINTER(blsw_matrices_info_t), ctypes.POINTER(blsw_matrices_t)]
         L.blsw_layout_multi.argtypes = [u32, u32, ctypes.POINTER(blsw_layout_t)]
         L.blsw_verify_multi_workspace_bytes.argtypes = [u64, u32, u32, ctypes.POINTER(u64)]
         L.blsw_verify_multi_batch.argtypes = [vp, vp, u32, u32, vp, u64, vp, u64, vp, vp, u64, vp]
@@ -90,7 +100,7 @@ EXPORTED_SYMBOLS = ["blsw_version", "blsw_layout", "blsw_engine_options_default"
                     "blsw_engine_destroy", "blsw_engine_submit", "blsw_engine_flush", "blsw_engine_submitted", "blsw_engine_launched", "blsw_engine_wait_step",
                     "blsw_engine_output_consumed", "blsw_engine_expand_stats", "blsw_witness_digest", "blsw_hash_to_g2_workspace_bytes", "blsw_hash_to_g2_batch",
                     "blsw_decode_batch", "blsw_layout_aggregate", "blsw_aggregate_workspace_bytes", "blsw_aggregate_verify_batch", "blsw_layout_multi",
-                    "blsw_verify_multi_workspace_bytes", "blsw_verify_multi_batch", "blsw_sign_batch", "blsw_microbench"]
+                    "blsw_verify_multi_workspace_bytes", "blsw_verify_multi_batch", "blsw_matrices_info", "blsw_matrices_fill", "blsw_sign_batch", "blsw_microbench"]
 
 
 def layout(msg_len=32):
@@ -349,6 +359,32 @@ def aggregate_verify(parameters, public_keys, bitmap, message, signature, want_w
         raise BlswError("blsw_aggregate_verify_batch failed: %d" % rc)
     torch.cuda.synchronize(dev)
     return res, cnt, wit
+
+
+def matrices(msg_len=32, n_keys=0, n_pairs=1):
+    """Constraint matrices of a circuit shape (host only; blsw_matrices_info + blsw_matrices_fill): the R1CS an arkworks prover
+    takes next to the witness vectors, in ConstraintMatrices shape. Returns dict(n_constraints, n_instance_vars, n_witness,
+    A / B / C = (row_ptr uint64 [n_constraints + 1], col uint32 [nnz], val uint64 [nnz, 6] Montgomery limbs))."""
+    import numpy as np
+
+    info = blsw_matrices_info_t()
+    rc = lib().blsw_matrices_info(msg_len, n_keys, n_pairs, ctypes.byref(info))
+    if rc:
+        raise BlswError("blsw_matrices_info failed: %d" % rc)
+    u64p, u32p = ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)
+    rp = [np.zeros(info.n_constraints + 1, dtype=np.uint64) for _ in range(3)]
+    col = [np.zeros(info.nnz[m], dtype=np.uint32) for m in range(3)]
+    val = [np.zeros((info.nnz[m], 6), dtype=np.uint64) for m in range(3)]
+    out = blsw_matrices_t()
+    for m in range(3):
+        out.row_ptr[m] = rp[m].ctypes.data_as(u64p)
+        out.col[m] = col[m].ctypes.data_as(u32p)
+        out.val[m] = val[m].ctypes.data_as(u64p)
+    rc = lib().blsw_matrices_fill(msg_len, n_keys, n_pairs, ctypes.byref(info), ctypes.byref(out))
+    if rc:
+        raise BlswError("blsw_matrices_fill failed: %d" % rc)
+    return {"n_constraints": info.n_constraints, "n_instance_vars": info.n_instance_vars, "n_witness": info.n_witness,
+            "A": (rp[0], col[0], val[0]), "B": (rp[1], col[1], val[1]), "C": (rp[2], col[2], val[2])}
 
 
 def layout_multi(msg_len, n_pairs):

@@ -13,7 +13,7 @@
 #define BLSW_FN __host__ __device__ __noinline__
 #else
 #define BLSW_HD inline
-#define BLSW_HD_NOINLINE
+#define BLSW_HD_NOINLINE inline  // host-only translation units (test harness, csrc/r1cs.cpp): no second strong definition
 #define BLSW_FN inline
 #endif
 

@@ -157,6 +157,27 @@ int blsw_engine_expand_stats(blsw_engine_t* e, uint32_t* count, float* avg_ms);
  *   d_witness [n][witness_stride] elements, d_digest [n][2] u64. Reads the tensor once at HBM speed. */
 int blsw_witness_digest(const uint64_t* d_witness, uint64_t witness_stride, uint64_t n, uint32_t n_witness, uint64_t* d_digest, void* stream);
 
+/* Constraint matrices (host only, no GPU): the R1CS whose witness vectors the entry points above fill, in arkworks'
+ * ConstraintMatrices shape — what `cs.to_matrices()` returns after synthesising the circuit (the reference only prints the
+ * system's size, src/constraints.rs:369-373). Constraint i is <A_i, z> * <B_i, z> = <C_i, z> with z = [1] ++ witness; column 0
+ * is the constant one, column k is witness k - 1 (n_instance_vars = 1: the gadget allocates no public input). Rows are stored
+ * CSR: row i of matrix m occupies entries [row_ptr[m][i], row_ptr[m][i + 1]) of col[m] / val[m] (val: 6 u64 Montgomery limbs
+ * per entry), columns ascending, no zero coefficients. Circuit shape: (msg_len, n_keys, n_pairs) as blsw_layout (0, 1),
+ * blsw_layout_aggregate (n_keys, 1) and blsw_layout_multi (0, n_pairs). Synthesised symbolically from the product's own
+ * statement of the arkworks allocation rules (csrc/r1cs.cpp), independent of witness values: emit once per shape.
+ * Usage: blsw_matrices_info -> allocate (n_constraints + 1) row pointers and nnz[m] entries per matrix -> blsw_matrices_fill. */
+typedef struct {
+    uint64_t n_constraints, n_instance_vars, n_witness;
+    uint64_t nnz[3]; /* non-zeros of A, B, C */
+} blsw_matrices_info_t;
+typedef struct {
+    uint64_t* row_ptr[3]; /* [n_constraints + 1] each */
+    uint32_t* col[3];     /* [nnz[m]] */
+    uint64_t* val[3];     /* [nnz[m]][6] */
+} blsw_matrices_t;
+int blsw_matrices_info(uint32_t msg_len, uint32_t n_keys, uint32_t n_pairs, blsw_matrices_info_t* out);
+int blsw_matrices_fill(uint32_t msg_len, uint32_t n_keys, uint32_t n_pairs, const blsw_matrices_info_t* info, blsw_matrices_t* out);
+
 /* Input decode (PublicKey::try_from / Signature::try_from -> deserialize_compressed, src/bls.rs:219-242, 316-339):
  *   d_pk48 [n][48], d_sig96 [n][96]  ZCash-format compressed points
  *   d_pk_xy [n][12], d_sig_xy [n][24] affine Montgomery coordinates in the layout blsw_engine_submit takes (identity / failure = zeros)

@@ -418,6 +418,41 @@ int64_t orc_check_satisfied(const uint64_t* pk_xy, const uint8_t* msg, size_t ms
     if (n_nonzero) *n_nonzero = nnz;
     return bad;
 }
+// CSR export of the recorded R1CS (A, B, C) for a circuit SHAPE: (msg_len, n_keys, n_pairs) as the product's blsw_matrices_*.
+// The instance is a dummy (generator keys, sig = H(0...0)): the matrices do not depend on values. Two-phase: with null
+// arrays only the counts are returned in nnz[3]; returns the number of constraints.
+uint64_t orc_matrices(size_t msg_len, uint64_t n_keys, uint64_t n_pairs, uint64_t* nnz, uint64_t* n_witness, uint64_t** row_ptr, uint32_t** col, uint64_t** val) {
+    std::vector<uint8_t> msg(msg_len * (n_pairs ? n_pairs : 1) + 1, 0);
+    G2Aff h = hash_to_g2_native(msg.data(), msg_len);
+    ValueScope s(true);
+    if (n_keys) {
+        std::vector<G1Aff> pks(n_keys, g1_generator());
+        std::vector<uint8_t> bm(n_keys, 1);
+        bls_aggregate_verify_circuit(pks, bm, msg.data(), msg_len, h, nullptr);
+    } else if (n_pairs > 1) {
+        std::vector<G1Aff> pks(n_pairs, g1_generator());
+        bls_verify_multi_circuit(pks, msg.data(), msg_len, h);
+    } else
+        bls_verify_circuit(g1_generator(), msg.data(), msg_len, h);
+    const std::vector<LC>* M[3] = {&s.cs.A, &s.cs.B, &s.cs.C};
+    for (int m = 0; m < 3; m++) {
+        uint64_t k = 0;
+        for (size_t i = 0; i < M[m]->size(); i++) {
+            const LCv& row = *(*M[m])[i];
+            if (row_ptr) row_ptr[m][i] = k;
+            if (col)
+                for (size_t t = 0; t < row.size(); t++) {
+                    col[m][k + t] = row[t].v;
+                    memcpy(val[m] + (k + t) * 6, row[t].c.l, 48);
+                }
+            k += row.size();
+        }
+        if (row_ptr) row_ptr[m][M[m]->size()] = k;
+        nnz[m] = k;
+    }
+    if (n_witness) *n_witness = s.cs.wit.size();
+    return s.cs.ncons;
+}
 // checkpoints for debugging the device path: u0,u1 (2x Fp2), Q0,Q1,R,H affine (4 x 24 limbs), f_miller, f_final (2 x 72 limbs)
 void orc_trace(const uint64_t* pk_xy, const uint8_t* msg, size_t msg_len, const uint64_t* sig_xy, uint64_t* out /* 24 + 96 + 144 limbs */) {
     ValueScope s;

@@ -38,11 +38,14 @@ int main(int argc, char** argv) {
         CHECK(blsw_engine_options_default(&o));
         CHECK(blsw_engine_workspace_bytes(1024, 32, 16, 3, &ws));
         CHECK(blsw_verify_multi_workspace_bytes(1, 32, 128, &ws_multi));
+        blsw_matrices_info_t mi;
+        CHECK(blsw_matrices_info(0, 0, 1, &mi)); /* host-only synthesis of the smallest shape (empty message) */
+        if (mi.n_instance_vars != 1 || mi.n_constraints == 0 || mi.nnz[0] == 0) return 13;
         if (blsw_layout(32, NULL) != BLSW_ERR_ARG || blsw_engine_workspace_bytes(0, 32, 1, 1, &ws_multi) != BLSW_ERR_ARG) return 11;
         printf("version=%d sizeof_layout=%zu n_witness=%u sha_bits=%u off_expand=%u off_miller=%u multi_n_witness=%u multi_pairs=%u multi_stride_hash=%u "
-               "workspace=%llu device=%d pairing_mode=%u prio_mode=%u\n",
+               "workspace=%llu device=%d pairing_mode=%u prio_mode=%u matrices0_constraints=%llu matrices0_witness=%llu\n",
                blsw_version(), sizeof(blsw_layout_t), L.n_witness, L.sha_bits, L.off_expand, L.off_miller, M.n_witness, M.n_pairs, M.stride_hash,
-               (unsigned long long)ws, o.device, o.pairing_mode, o.prio_mode);
+               (unsigned long long)ws, o.device, o.pairing_mode, o.prio_mode, (unsigned long long)mi.n_constraints, (unsigned long long)mi.n_witness);
         return 0;
     }
     if (argc == 5 && !strcmp(argv[1], "verify")) {

@@ -324,6 +324,24 @@ int hostsim_sign(const uint8_t* sk32, const uint64_t* h_xy, uint8_t* sig96, uint
     g1_encode(px, py, pinf, pk48);
     return st;
 }
+// R1CS evaluator (test side): checks <A_i, z> * <B_i, z> = <C_i, z> for every constraint with z = [1] ++ witness, matrices in
+// the CSR form blsw_matrices_fill writes. Returns the index of the first unsatisfied constraint, or -1.
+int64_t hostsim_r1cs_check(uint64_t n_cons, const uint64_t* const* row_ptr, const uint32_t* const* col, const uint64_t* const* val, const uint64_t* witness,
+                           uint64_t n_witness) {
+    auto dot = [&](int m, uint64_t i) {
+        Fp acc = fp_zero();
+        for (uint64_t k = row_ptr[m][i]; k < row_ptr[m][i + 1]; k++) {
+            const uint32_t c = col[m][k];
+            if (c > n_witness) return fp_from_u32(0xdead);  // out of range: forces a mismatch
+            Fp z = c == 0 ? fp_one() : load_fp(witness + (uint64_t)(c - 1) * 6);
+            acc = fp_add(acc, fp_mul(load_fp(val[m] + k * 6), z));
+        }
+        return acc;
+    };
+    for (uint64_t i = 0; i < n_cons; i++)
+        if (!fp_eq(fp_mul(dot(0, i), dot(1, i)), dot(2, i))) return (int64_t)i;
+    return -1;
+}
 // field micro-checks
 void hostsim_fp_mul(const uint64_t* a, const uint64_t* b, uint64_t* r) {
     Fp z = fp_mul(load_fp(a), load_fp(b));

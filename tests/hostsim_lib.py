@@ -85,3 +85,15 @@ def sign(sk_le32, h_xy):
     pk = (ctypes.c_uint8 * 48)()
     st = load().hostsim_sign(sk, h_xy.ctypes.data_as(u64p), sig, pk)
     return st, bytes(sig), bytes(pk)
+
+
+def r1cs_check(mats, witness):
+    """A z o B z = C z for the matrices dict of pkg.matrices() and a witness array [n_witness, 6] uint64 -> first bad row or -1"""
+    witness = np.ascontiguousarray(witness, dtype=np.uint64)
+    u32p = ctypes.POINTER(ctypes.c_uint32)
+    rp = (u64p * 3)(*[mats[k][0].ctypes.data_as(u64p) for k in "ABC"])
+    col = (u32p * 3)(*[mats[k][1].ctypes.data_as(u32p) for k in "ABC"])
+    val = (u64p * 3)(*[mats[k][2].ctypes.data_as(u64p) for k in "ABC"])
+    fn = load().hostsim_r1cs_check
+    fn.restype = ctypes.c_int64
+    return fn(ctypes.c_uint64(mats["n_constraints"]), rp, col, val, witness.ctypes.data_as(u64p), ctypes.c_uint64(witness.shape[0]))

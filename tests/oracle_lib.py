@@ -159,6 +159,22 @@ class Oracle:
             self.lib.orc_witness_multi(*args(w.ctypes.data_as(u64p), n))
         return n, bool(res.value), marks, w
 
+    def matrices(self, msg_len=32, n_keys=0, n_pairs=1):
+        """(n_constraints, n_witness, [(row_ptr, col, val) for A, B, C]) of the oracle's recorded R1CS for a circuit shape"""
+        nnz = (ctypes.c_uint64 * 3)()
+        nw = ctypes.c_uint64(0)
+        self.lib.orc_matrices.restype = ctypes.c_uint64
+        nc = self.lib.orc_matrices(ctypes.c_size_t(msg_len), ctypes.c_uint64(n_keys), ctypes.c_uint64(n_pairs), nnz, ctypes.byref(nw), None, None, None)
+        rp = [np.zeros(nc + 1, dtype=np.uint64) for _ in range(3)]
+        col = [np.zeros(nnz[m], dtype=np.uint32) for m in range(3)]
+        val = [np.zeros((nnz[m], 6), dtype=np.uint64) for m in range(3)]
+        u32p = ctypes.POINTER(ctypes.c_uint32)
+        a_rp = (u64p * 3)(*[x.ctypes.data_as(u64p) for x in rp])
+        a_col = (u32p * 3)(*[x.ctypes.data_as(u32p) for x in col])
+        a_val = (u64p * 3)(*[x.ctypes.data_as(u64p) for x in val])
+        self.lib.orc_matrices(ctypes.c_size_t(msg_len), ctypes.c_uint64(n_keys), ctypes.c_uint64(n_pairs), nnz, ctypes.byref(nw), a_rp, a_col, a_val)
+        return nc, nw.value, list(zip(rp, col, val))
+
     def witness_batch(self, pk_xy, msgs, sig_xy, threads=1, want_digests=True):
         pk_xy = np.ascontiguousarray(pk_xy, dtype=np.uint64)
         sig_xy = np.ascontiguousarray(sig_xy, dtype=np.uint64)

@@ -558,3 +558,29 @@ def test_c_caller_on_the_gpu(pkg, oracle):
     n, _, res, w = oracle.witness(pk, bytes.fromhex(g["messages"][0]), sig)
     assert kv["status_pk"] == kv["status_sig"] == "0" and int(kv["result"]) == int(res) == 1 and int(kv["n_witness"]) == n
     assert [int(kv["digest0"]), int(kv["digest1"])] == pkg.witness_digest_reference(w)
+
+
+def test_gpu_witness_satisfies_product_matrices(pkg, oracle):
+    """f1: witness vectors produced by the HIP kernels satisfy the constraint matrices emitted by the product
+    (blsw_matrices_*: A z o B z = C z on every one of the 713 891 constraints; evaluator in the test harness) — single-key
+    circuit through the grouped engine, aggregate_verify with 2 keys and the N+1-pair product with 2 pairs."""
+    import torch
+
+    from tests import hostsim_lib
+
+    pk, msg, sig, expect = synth.make_batch(oracle, 16)
+    got, w = _run(pkg, pk[:4].copy(), msg[:4].copy(), sig[:4].copy(), max_steps=2)
+    P = pkg.matrices(32, 0, 1)
+    assert w.shape[1] == P["n_witness"]
+    for i in (0, 3):
+        assert hostsim_lib.r1cs_check(P, w[i]) == -1
+    # aggregate_verify, 2 keys (same message): sk0 + sk1 signature over msg of instance 0
+    pks, msgs, sg, _ = synth.make_multi(oracle, 2)
+    got, wit = _multi_run(pkg, pks[None], msgs[None], sg[None])
+    PM = pkg.matrices(32, 0, 2)
+    assert got.tolist() == [True] and hostsim_lib.r1cs_check(PM, wit[0].cpu().numpy().view(np.uint64)) == -1
+    PA = pkg.matrices(32, 2, 1)
+    keys = np.stack([pk[0], pk[1]])[None]
+    bm = np.array([[1, 0]], dtype=np.uint8)
+    g, cnt, wa = _agg_run(pkg, keys, bm, msg[0:1].copy(), sig[0:1].copy())  # bitmap selects key 0 only: sig of instance 0 verifies
+    assert g.tolist() == [True] and cnt.tolist() == [1] and hostsim_lib.r1cs_check(PA, wa[0]) == -1

@@ -1,0 +1,62 @@
+"""Constraint matrices of the product (blsw_matrices_info / blsw_matrices_fill, csrc/r1cs.cpp: a symbolic synthesis that shares
+no code with oracle/) against the oracle's recorded R1CS, row by row, and against witness vectors: A z o B z = C z.
+The reference never checks satisfaction (constraints.rs:369-373 only prints the system's size); SURVEY.md 8(f).1."""
+import importlib
+
+import numpy as np
+import pytest
+
+from tests import hostsim_lib, synth
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return importlib.import_module("bls-verify-gadget_amd")
+
+
+def _same(mo, mp):
+    return all(np.array_equal(x, y) for x, y in zip(mo, mp))
+
+
+@pytest.mark.parametrize("shape", [(32, 0, 1), (0, 2, 1), (0, 0, 2)])  # single key; aggregate_verify, 2 keys; N+1-pair product, 2 pairs
+def test_product_matrices_equal_the_oracles(pkg, oracle, shape):
+    nc, nw, M = oracle.matrices(*shape)
+    P = pkg.matrices(*shape)
+    assert (P["n_constraints"], P["n_witness"], P["n_instance_vars"]) == (nc, nw, 1)
+    lay = pkg.layout(shape[0]) if shape[1:] == (0, 1) else (pkg.layout_aggregate(shape[0], shape[1]) if shape[1] else pkg.layout_multi(shape[0], shape[2]))
+    assert lay["n_witness"] == nw
+    for m, name in enumerate("ABC"):
+        assert _same(M[m], P[name]), "matrix %s differs" % name
+        rp, col, val = P[name]
+        assert rp[0] == 0 and rp[-1] == len(col) and (np.diff(rp.astype(np.int64)) >= 0).all() and int(col.max()) <= nw
+    # CSR rows are sorted by column and carry no zero coefficient
+    rp, col, val = P["B"]
+    inner = np.ones(len(col), dtype=bool)
+    inner[rp[1:-1][rp[1:-1] < len(col)]] = False
+    assert (np.diff(col.astype(np.int64))[inner[1:]] > 0).all()
+    assert val.any(axis=1).all()
+
+
+def test_witness_vectors_satisfy_the_product_matrices(pkg, oracle):
+    P = pkg.matrices(32, 0, 1)
+    pk, msg, sig, expect = synth.make_batch(oracle, 16)
+    for i in (3, 15):  # a valid and a tampered instance: both assignments satisfy the system, the output Boolean differs
+        n, _, res, w = oracle.witness(pk[i], msg[i].tobytes(), sig[i])
+        assert res == bool(expect[i])
+        assert hostsim_lib.r1cs_check(P, w) == -1
+    # the host harness (device chain code compiled for the host) as the witness source
+    r, w = hostsim_lib.witness(pk[5], msg[5].tobytes(), sig[5])
+    assert hostsim_lib.r1cs_check(P, w) == -1
+    # a single flipped witness breaks it, and the evaluator says where
+    w2 = w.copy()
+    w2[P["n_witness"] // 2, 0] ^= 1
+    assert hostsim_lib.r1cs_check(P, w2) >= 0
+
+
+def test_argument_checks(pkg):
+    import ctypes
+
+    info = pkg.blsw_matrices_info_t()
+    assert pkg.lib().blsw_matrices_info(32, 2, 2, ctypes.byref(info)) == 1  # aggregate and multi together
+    assert pkg.lib().blsw_matrices_info(32, 0, 0, ctypes.byref(info)) == 1
+    assert pkg.lib().blsw_matrices_info(32, 0, 1, None) == 1

@@ -39,7 +39,9 @@ def parse_header(path=HEADER):
                 continue
             ctype, names = decl.split(" ", 1)
             for nm in names.split(","):
-                fields.append((ctype, nm.strip()))
+                nm = nm.strip()
+                am = re.fullmatch(r"(\w+)\[(\d+)\]", nm)  # fixed-size array member
+                fields.append((ctype + "[%s]" % am.group(2), am.group(1)) if am else (ctype, nm))
         structs[m.group(2)] = fields
     opaque = re.findall(r"typedef\s+struct\s+(\w+)\s+(\w+)\s*;", text)
     functions = []
@@ -56,6 +58,9 @@ def parse_header(path=HEADER):
 
 
 def rust_type(ctype):
+    am = re.fullmatch(r"(.*)\[(\d+)\]", ctype)
+    if am:
+        return "[%s; %s]" % (rust_type(am.group(1)), am.group(2))
     c = ctype.replace(" *", "*").replace("* ", "*").strip()
     const = c.startswith("const ")
     if const:
@@ -77,7 +82,8 @@ def rust_block(h=None):
         out.append("pub const %s: i32 = %d;" % (name, v))
     out.append("")
     for sname, fields in h["structs"].items():
-        out.append("#[repr(C)] #[derive(Default, Clone, Copy, Debug)]")
+        has_ptr = any("*" in ctype for ctype, _ in fields)
+        out.append("#[repr(C)] #[derive(%sClone, Copy, Debug)]" % ("" if has_ptr else "Default, "))
         out.append("pub struct %s {   // %s: %d fields" % (STRUCT_NAMES[sname], sname, len(fields)))
         line = "   "
         for ctype, f in fields:
