@@ -14,6 +14,7 @@
 // A z o B z = C z on GPU-produced witnesses). Constants come from constants.cuh / sha.cuh like the kernels'.
 #include <string.h>
 #include <algorithm>
+#include <mutex>
 #include <vector>
 #include "../../include/blsw.h"
 #include "constants.cuh"
@@ -63,25 +64,18 @@ static Lc lc_scale(const Lc& a, const Fp& s) { return lc_axpy(Lc(), a, s); }
 
 // ------------------------------------------------------------------------------------------------ the system being written
 struct Sys {
-    uint64_t n_cons = 0, nnz[3] = {0, 0, 0};
+    uint64_t n_cons = 0;
     uint32_t n_wit = 0;
-    blsw_matrices_t* out = nullptr;  // nullptr: count only
-    uint64_t cap_rows = 0, cap_nnz[3] = {0, 0, 0};
-    bool overflow = false;
+    std::vector<uint64_t> row_ptr[3];
+    std::vector<uint32_t> col[3];
+    std::vector<Fp> val[3];
     uint32_t alloc() { return ++n_wit; }
     void row(int m, const Lc& l) {
-        if (out) {
-            if (n_cons >= cap_rows || nnz[m] + l.size() > cap_nnz[m]) {
-                overflow = true;
-            } else {
-                out->row_ptr[m][n_cons] = nnz[m];
-                for (size_t k = 0; k < l.size(); k++) {
-                    out->col[m][nnz[m] + k] = l[k].v;
-                    memcpy(out->val[m] + (nnz[m] + k) * 6, l[k].c.l, 48);
-                }
-            }
+        row_ptr[m].push_back(col[m].size());
+        for (const Term& t : l) {
+            col[m].push_back(t.v);
+            val[m].push_back(t.c);
         }
-        nnz[m] += l.size();
     }
     void enforce(const Lc& a, const Lc& b, const Lc& c) {
         row(0, a);
@@ -90,8 +84,7 @@ struct Sys {
         n_cons++;
     }
     void finish() {
-        if (out && !overflow)
-            for (int m = 0; m < 3; m++) out->row_ptr[m][n_cons] = nnz[m];
+        for (int m = 0; m < 3; m++) row_ptr[m].push_back(col[m].size());
     }
 };
 static thread_local Sys* S = nullptr;
@@ -1258,6 +1251,18 @@ static int run(uint32_t msg_len, uint32_t n_keys, uint32_t n_pairs, Sys& sys) {
     S = nullptr;
     return BLSW_OK;
 }
+// blsw_matrices_info synthesises the system to count it; the result is kept (one shape, ~50 bytes per non-zero) so that the
+// blsw_matrices_fill that follows copies instead of synthesising a second time, and released by that fill
+struct Cache {
+    std::mutex mu;
+    bool valid = false;
+    uint32_t msg_len = 0, n_keys = 0, n_pairs = 0;
+    Sys sys;
+};
+static Cache& cache() {
+    static Cache c;
+    return c;
+}
 
 }  // namespace r1cs
 }  // namespace blsw
@@ -1266,13 +1271,20 @@ extern "C" {
 
 int blsw_matrices_info(uint32_t msg_len, uint32_t n_keys, uint32_t n_pairs, blsw_matrices_info_t* out) {
     if (!out) return BLSW_ERR_ARG;
-    blsw::r1cs::Sys sys;
-    int rc = blsw::r1cs::run(msg_len, n_keys, n_pairs, sys);
+    blsw::r1cs::Cache& c = blsw::r1cs::cache();
+    std::lock_guard<std::mutex> lock(c.mu);
+    c.valid = false;
+    c.sys = blsw::r1cs::Sys();
+    int rc = blsw::r1cs::run(msg_len, n_keys, n_pairs, c.sys);
     if (rc) return rc;
-    out->n_constraints = sys.n_cons;
+    c.valid = true;
+    c.msg_len = msg_len;
+    c.n_keys = n_keys;
+    c.n_pairs = n_pairs;
+    out->n_constraints = c.sys.n_cons;
     out->n_instance_vars = 1;
-    out->n_witness = sys.n_wit;
-    for (int m = 0; m < 3; m++) out->nnz[m] = sys.nnz[m];
+    out->n_witness = c.sys.n_wit;
+    for (int m = 0; m < 3; m++) out->nnz[m] = c.sys.col[m].size();
     return BLSW_OK;
 }
 
@@ -1280,13 +1292,27 @@ int blsw_matrices_fill(uint32_t msg_len, uint32_t n_keys, uint32_t n_pairs, cons
     if (!info || !out) return BLSW_ERR_ARG;
     for (int m = 0; m < 3; m++)
         if (!out->row_ptr[m] || (info->nnz[m] && (!out->col[m] || !out->val[m]))) return BLSW_ERR_ARG;
-    blsw::r1cs::Sys sys;
-    sys.out = out;
-    sys.cap_rows = info->n_constraints;
-    for (int m = 0; m < 3; m++) sys.cap_nnz[m] = info->nnz[m];
-    int rc = blsw::r1cs::run(msg_len, n_keys, n_pairs, sys);
-    if (rc) return rc;
-    if (sys.overflow || sys.n_cons != info->n_constraints || sys.n_wit != info->n_witness) return BLSW_ERR_ARG;  // info of another circuit shape
-    return BLSW_OK;
+    blsw::r1cs::Cache& c = blsw::r1cs::cache();
+    std::lock_guard<std::mutex> lock(c.mu);
+    if (!(c.valid && c.msg_len == msg_len && c.n_keys == n_keys && c.n_pairs == n_pairs)) {
+        c.valid = false;
+        c.sys = blsw::r1cs::Sys();
+        int rc = blsw::r1cs::run(msg_len, n_keys, n_pairs, c.sys);
+        if (rc) return rc;
+    }
+    const blsw::r1cs::Sys& s = c.sys;
+    bool ok = s.n_cons == info->n_constraints && s.n_wit == info->n_witness;
+    for (int m = 0; m < 3; m++) ok = ok && s.col[m].size() == info->nnz[m];
+    if (ok)
+        for (int m = 0; m < 3; m++) {
+            memcpy(out->row_ptr[m], s.row_ptr[m].data(), (s.n_cons + 1) * sizeof(uint64_t));
+            if (!s.col[m].empty()) {
+                memcpy(out->col[m], s.col[m].data(), s.col[m].size() * sizeof(uint32_t));
+                memcpy(out->val[m], s.val[m].data(), s.val[m].size() * 48);
+            }
+        }
+    c.valid = false;
+    c.sys = blsw::r1cs::Sys();  // release
+    return ok ? BLSW_OK : BLSW_ERR_ARG;  // BLSW_ERR_ARG: `info` belongs to another circuit shape
 }
 }
