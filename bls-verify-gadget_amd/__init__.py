@@ -28,7 +28,7 @@ class blsw_layout_t(ctypes.Structure):
 
 
 class blsw_engine_options_t(ctypes.Structure):
-    _fields_ = [("device", ctypes.c_int32)] + [(n, ctypes.c_uint32) for n in "pairing_mode g2_mode expand_variant expand_store prio_mode place_lds".split()]
+    _fields_ = [("device", ctypes.c_int32)] + [(n, ctypes.c_uint32) for n in "n_keys pairing_mode g2_mode expand_variant expand_store prio_mode place_lds".split()]
 
 
 class blsw_matrices_info_t(ctypes.Structure):
@@ -68,6 +68,8 @@ def lib():
         L.blsw_layout.argtypes = [u32, ctypes.POINTER(blsw_layout_t)]
         L.blsw_engine_workspace_bytes.argtypes = [u64, u32, u32, u32, ctypes.POINTER(u64)]
         L.blsw_engine_create.argtypes = [ctypes.POINTER(vp), u64, u32, u32, u32, vp, u64]
+        L.blsw_engine_workspace_bytes_ex.argtypes = [u64, u32, u32, u32, ctypes.POINTER(blsw_engine_options_t), ctypes.POINTER(u64)]
+        L.blsw_engine_submit_aggregate.argtypes = [vp, vp, vp, vp, vp, vp, u64, vp, vp, vp]
         L.blsw_engine_create_ex.argtypes = [ctypes.POINTER(vp), u64, u32, u32, u32, ctypes.POINTER(blsw_engine_options_t), vp, u64]
         L.blsw_engine_options_default.argtypes = [ctypes.POINTER(blsw_engine_options_t)]
         L.blsw_engine_submitted.argtypes = [vp, ctypes.POINTER(u64)]
@@ -96,8 +98,8 @@ def lib():
     return _lib
 
 
-EXPORTED_SYMBOLS = ["blsw_version", "blsw_layout", "blsw_engine_options_default", "blsw_engine_workspace_bytes", "blsw_engine_create", "blsw_engine_create_ex",
-                    "blsw_engine_destroy", "blsw_engine_submit", "blsw_engine_flush", "blsw_engine_submitted", "blsw_engine_launched", "blsw_engine_wait_step",
+EXPORTED_SYMBOLS = ["blsw_version", "blsw_layout", "blsw_engine_options_default", "blsw_engine_workspace_bytes", "blsw_engine_workspace_bytes_ex", "blsw_engine_create",
+                    "blsw_engine_create_ex", "blsw_engine_destroy", "blsw_engine_submit", "blsw_engine_submit_aggregate", "blsw_engine_flush", "blsw_engine_submitted", "blsw_engine_launched", "blsw_engine_wait_step",
                     "blsw_engine_output_consumed", "blsw_engine_expand_stats", "blsw_witness_digest", "blsw_hash_to_g2_workspace_bytes", "blsw_hash_to_g2_batch",
                     "blsw_decode_batch", "blsw_layout_aggregate", "blsw_aggregate_workspace_bytes", "blsw_aggregate_verify_batch", "blsw_layout_multi",
                     "blsw_verify_multi_workspace_bytes", "blsw_verify_multi_batch", "blsw_matrices_info", "blsw_matrices_fill", "blsw_sign_batch", "blsw_microbench"]
@@ -150,17 +152,23 @@ class WitnessEngine:
     Streaming consumers use the step numbers returned by submit(): wait_step(seq) / output_consumed(tensor)."""
 
     def __init__(self, n, msg_len=32, max_steps=1, device=None, n_buffers=None, **options):
+        """options: fields of blsw_engine_options_t; n_keys=K makes it an aggregate_verify engine (submit_aggregate)."""
         torch = _require_cuda()
         self.torch = torch
         self.n, self.msg_len, self.max_steps = int(n), int(msg_len), int(max_steps)
         self.n_buffers = int(n_buffers) if n_buffers is not None else (3 if self.max_steps > 1 else 1)
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
-        self.layout = layout(msg_len)
-        self.n_witness = self.layout["n_witness"]
-        self.workspace = torch.empty(engine_workspace_bytes(self.n, msg_len, self.max_steps, self.n_buffers), dtype=torch.uint8, device=self.device)
-        self._e = ctypes.c_void_p()
         opt = engine_options(**options)
         opt.device = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.n_keys = int(opt.n_keys)
+        self.layout = layout_aggregate(msg_len, self.n_keys) if self.n_keys else layout(msg_len)
+        self.n_witness = self.layout["n_witness"]
+        wb = ctypes.c_uint64(0)
+        rc = lib().blsw_engine_workspace_bytes_ex(self.n, self.msg_len, self.max_steps, self.n_buffers, ctypes.byref(opt), ctypes.byref(wb))
+        if rc:
+            raise BlswError("blsw_engine_workspace_bytes_ex failed: %d" % rc)
+        self.workspace = torch.empty(wb.value, dtype=torch.uint8, device=self.device)
+        self._e = ctypes.c_void_p()
         rc = lib().blsw_engine_create_ex(ctypes.byref(self._e), self.n, self.msg_len, self.max_steps, self.n_buffers, ctypes.byref(opt), self.workspace.data_ptr(),
                                          self.workspace.numel())
         if rc:
@@ -201,6 +209,23 @@ class WitnessEngine:
         if rc:
             raise BlswError("blsw_engine_submit failed: %d" % rc)
         self._keep.append((pk_xy, sig_xy, msg, witness, result))
+        self._keep = self._keep[-(self.n_buffers + 1) * self.max_steps:]
+        return seq
+
+    def submit_aggregate(self, pks_xy, bitmap, sig_xy, msg, witness=None, result=None, count=None, stream=None):
+        """aggregate_verify batch (engine created with n_keys=K): pks_xy [n, K, 12] int64, bitmap [n, K] uint8 -> step number"""
+        K = self.n_keys
+        assert K and pks_xy.shape == (self.n, K, 12) and bitmap.shape == (self.n, K) and sig_xy.shape == (self.n, 24) and msg.shape == (self.n, self.msg_len)
+        assert pks_xy.is_contiguous() and bitmap.is_contiguous() and sig_xy.is_contiguous() and msg.is_contiguous()
+        if witness is not None:
+            assert witness.is_contiguous() and witness.shape[0] == self.n and witness.shape[1] >= self.n_witness
+        seq = self.submitted()
+        rc = lib().blsw_engine_submit_aggregate(self._e, pks_xy.data_ptr(), bitmap.data_ptr(), sig_xy.data_ptr(), msg.data_ptr() if self.msg_len else None,
+                                                witness.data_ptr() if witness is not None else None, witness.shape[1] if witness is not None else 0,
+                                                result.data_ptr() if result is not None else None, count.data_ptr() if count is not None else None, self._stream(stream))
+        if rc:
+            raise BlswError("blsw_engine_submit_aggregate failed: %d" % rc)
+        self._keep.append((pks_xy, bitmap, sig_xy, msg, witness, result, count))
         self._keep = self._keep[-(self.n_buffers + 1) * self.max_steps:]
         return seq
 

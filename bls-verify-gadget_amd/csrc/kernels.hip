@@ -27,6 +27,7 @@ struct Workspace {
     Fp* coeff_h;     // [272][N]      line coefficients of prepare_g2(H(m))
     Fp* coeff_sig;   // [272][n_sig]  line coefficients of prepare_g2(sig)
     uint64_t n_sig;  // = N for the single-key circuit; = instances (not pairs) for the N+1-pair product
+    Fp* keyproj;     // [3][N * n_keys] allocated keys of the aggregate_verify circuit (projective), else nullptr
     Fp* staging;     // [N/64][split_row][64] field witnesses (engine mode), or nullptr (direct mode): each wave of 64
                      // instances owns one contiguous tile and appends 3 KiB rows to it (sequential HBM writes per wave)
     uint64_t staging_rows;
@@ -76,6 +77,7 @@ Workspace carve(void* base, uint64_t N, const blsw_layout_t& L, bool with_stagin
     w.coeff_h = reinterpret_cast<Fp*>(take(272ull * N * sizeof(Fp)));
     w.coeff_sig = reinterpret_cast<Fp*>(take(272ull * n_sig * sizeof(Fp)));
     w.n_sig = n_sig;
+    w.keyproj = L.n_keys ? reinterpret_cast<Fp*>(take(3ull * N * L.n_keys * sizeof(Fp))) : nullptr;
     w.staging_rows = L.n_witness - L.sha_bits;
     w.split_row = m.pairing_team ? staging_layout(L, m).off_miller : (uint32_t)w.staging_rows;
     w.pair_rows = (uint32_t)w.staging_rows - w.split_row;
@@ -990,7 +992,11 @@ static int launch_group(blsw_engine* e) {
     hipLaunchKernelGGL(k_prepare, dim3(g1), dim3(64), 0, st, g, 0);
     // aux: prepare_g2(sig) and the group allocations (53 ms alone beside the 86 ms of the main stream's first part)
     hipLaunchKernelGGL(k_prepare, dim3(g1), dim3(64), 0, b.st[1], g, 1);
-    hipLaunchKernelGGL(k_g1, dim3(g1), dim3(64), 0, b.st[1], g);
+    if (e->L.n_keys) {  // aggregate_verify: one lane per (instance, key) allocates, then mapped_aggregate + pk != 0 + prepare_g1 per instance
+        hipLaunchKernelGGL(k_agg_keys, dim3((unsigned)((g.N * e->L.n_keys + 63) / 64)), dim3(64), 0, b.st[1], g, g.ws.keyproj);
+        hipLaunchKernelGGL(k_agg_sum, dim3(g1), dim3(64), 0, b.st[1], g, (const Fp*)g.ws.keyproj);
+    } else
+        hipLaunchKernelGGL(k_g1, dim3(g1), dim3(64), 0, b.st[1], g);
     if (e->modes.g2_team)
         hipLaunchKernelGGL(k_g2_alloc_team, dim3(gt), dim3(64), 0, b.st[1], g);
     else
@@ -1067,6 +1073,7 @@ int blsw_engine_options_default(blsw_engine_options_t* o) {
     const char* p = getenv("BLSW_PAIRING");
     const char* g2 = getenv("BLSW_G2");
     o->device = -1;
+    o->n_keys = 0;
     o->pairing_mode = (p && p[0] == 'l') ? 1u : 0u;
     o->g2_mode = (g2 && g2[0] == 't' && o->pairing_mode == 0) ? 1u : 0u;
     o->expand_variant = env_u32("BLSW_EXPAND_VARIANT", BLSW_DEFAULT_EXPAND_VARIANT);
@@ -1076,10 +1083,11 @@ int blsw_engine_options_default(blsw_engine_options_t* o) {
     return BLSW_OK;
 }
 
-int blsw_engine_workspace_bytes(uint64_t n, uint32_t msg_len, uint32_t max_steps, uint32_t n_buffers, uint64_t* bytes) {
-    if (!bytes || n == 0 || max_steps == 0 || n_buffers == 0 || n_buffers > BLSW_MAX_BUFFERS || msg_len > 65535) return BLSW_ERR_ARG;
+int blsw_engine_workspace_bytes_ex(uint64_t n, uint32_t msg_len, uint32_t max_steps, uint32_t n_buffers, const blsw_engine_options_t* options, uint64_t* bytes) {
+    if (!bytes || n == 0 || max_steps == 0 || n_buffers == 0 || n_buffers > BLSW_MAX_BUFFERS || msg_len > 65535 || !options || options->n_keys > 65535)
+        return BLSW_ERR_ARG;
     blsw_layout_t L;
-    make_layout(msg_len, &L);
+    make_layout(msg_len, &L, options->n_keys);
     const bool staged = max_steps > 1 || n_buffers > 1;
     // the same workspace serves every kernel variant: the largest carve of the three mode combinations
     uint64_t need = 0;
@@ -1091,13 +1099,19 @@ int blsw_engine_workspace_bytes(uint64_t n, uint32_t msg_len, uint32_t max_steps
     *bytes = (uint64_t)n_buffers * align_up(need, 4096);
     return BLSW_OK;
 }
+int blsw_engine_workspace_bytes(uint64_t n, uint32_t msg_len, uint32_t max_steps, uint32_t n_buffers, uint64_t* bytes) {
+    blsw_engine_options_t o;
+    blsw_engine_options_default(&o);
+    return blsw_engine_workspace_bytes_ex(n, msg_len, max_steps, n_buffers, &o, bytes);
+}
 
 int blsw_engine_create_ex(blsw_engine_t** out, uint64_t n, uint32_t msg_len, uint32_t max_steps, uint32_t n_buffers, const blsw_engine_options_t* options,
                           void* d_workspace, uint64_t workspace_bytes) {
     if (!out || n == 0 || n > 0x7fffffffu || max_steps == 0 || !d_workspace || n_buffers == 0 || n_buffers > BLSW_MAX_BUFFERS || !options || msg_len > 65535)
         return BLSW_ERR_ARG;
     if (options->pairing_mode > 1 || options->g2_mode > 1 || (options->g2_mode == 1 && options->pairing_mode != 0) || options->expand_store > 3 ||
-        options->prio_mode > 2 || (options->expand_variant & 0xff) > 5 || (options->expand_variant >> 9))
+        options->prio_mode > 2 || (options->expand_variant & 0xff) > 5 || (options->expand_variant >> 9) || options->n_keys > 65535 ||
+        (options->n_keys && options->g2_mode))
         return BLSW_ERR_ARG;
     *out = nullptr;
     int ndev = 0;
@@ -1107,7 +1121,7 @@ int blsw_engine_create_ex(blsw_engine_t** out, uint64_t n, uint32_t msg_len, uin
     if (dev >= ndev) return BLSW_ERR_ARG;
     DeviceGuard guard(dev);
     uint64_t need = 0;
-    if (blsw_engine_workspace_bytes(n, msg_len, max_steps, n_buffers, &need)) return BLSW_ERR_ARG;
+    if (blsw_engine_workspace_bytes_ex(n, msg_len, max_steps, n_buffers, options, &need)) return BLSW_ERR_ARG;
     if (workspace_bytes < need) return BLSW_ERR_WORKSPACE;
     // Scratch guard. ROCr backs a queue's scratch for full-device occupancy: stack bytes per lane x 64 lanes x wave slots
     // (CUs x 32), per queue that runs the kernel. The single-lane pairing kernel (9.7 KB of stack) on four or more group
@@ -1134,7 +1148,7 @@ int blsw_engine_create_ex(blsw_engine_t** out, uint64_t n, uint32_t msg_len, uin
     e->device = dev;
     e->modes = {options->pairing_mode == 0, options->g2_mode == 1};
     e->staged = max_steps > 1 || n_buffers > 1;
-    make_layout(msg_len, &e->L);
+    make_layout(msg_len, &e->L, options->n_keys);
     e->LS = staging_layout(e->L, e->modes);
     for (int i = 0; i < BLSW_MAX_CONSUMED; i++) {
         e->consumed_ptr[i] = nullptr;
@@ -1219,10 +1233,8 @@ int blsw_engine_destroy(blsw_engine_t* e) {
     return BLSW_OK;
 }
 
-int blsw_engine_submit(blsw_engine_t* e, const uint64_t* d_pk_xy, const uint64_t* d_sig_xy, const uint8_t* d_msg, uint64_t* d_witness,
-                       uint64_t witness_stride, int32_t* d_result, void* stream_) {
-    if (!e || !d_pk_xy || !d_sig_xy || (!d_msg && e->msg_len)) return BLSW_ERR_ARG;
-    if (d_witness && witness_stride < e->L.n_witness) return BLSW_ERR_ARG;
+static int engine_submit(blsw_engine_t* e, const StepDesc& step, void* stream_) {
+    if (step.out && step.out_stride < e->L.n_witness) return BLSW_ERR_ARG;
     DeviceGuard guard(e->device);
     GroupBuf& b = e->buf[e->cur];
     if (e->pending == 0 && b.used) {
@@ -1231,20 +1243,24 @@ int blsw_engine_submit(blsw_engine_t* e, const uint64_t* d_pk_xy, const uint64_t
         b.used = false;
     }
     if (hip_ok(hipEventRecord(b.ev_in[e->pending], reinterpret_cast<hipStream_t>(stream_)), "event record")) return BLSW_ERR_HIP;
-    StepDesc& d = b.h_desc[e->pending];
-    d.pk = d_pk_xy;
-    d.sig = d_sig_xy;
-    d.msg = d_msg;
-    d.out = d_witness;
-    d.out_stride = witness_stride;
-    d.result = d_result;
-    d.keys = nullptr;
-    d.bitmap = nullptr;
-    d.count = nullptr;
+    b.h_desc[e->pending] = step;
     e->pending++;
     e->submitted++;
     if (e->pending == e->max_steps) return launch_group(e);
     return BLSW_OK;
+}
+int blsw_engine_submit(blsw_engine_t* e, const uint64_t* d_pk_xy, const uint64_t* d_sig_xy, const uint8_t* d_msg, uint64_t* d_witness,
+                       uint64_t witness_stride, int32_t* d_result, void* stream_) {
+    if (!e || e->L.n_keys || !d_pk_xy || !d_sig_xy || (!d_msg && e->msg_len)) return BLSW_ERR_ARG;
+    StepDesc d = {d_pk_xy, d_sig_xy, d_msg, d_witness, witness_stride, d_result, nullptr, nullptr, nullptr};
+    return engine_submit(e, d, stream_);
+}
+// aggregate_verify through the engine (an engine created with options.n_keys = K): one batch of n instances of K keys each
+int blsw_engine_submit_aggregate(blsw_engine_t* e, const uint64_t* d_pks_xy, const uint8_t* d_bitmap, const uint64_t* d_sig_xy, const uint8_t* d_msg,
+                                 uint64_t* d_witness, uint64_t witness_stride, int32_t* d_result, uint32_t* d_count, void* stream_) {
+    if (!e || !e->L.n_keys || !d_pks_xy || !d_bitmap || !d_sig_xy || (!d_msg && e->msg_len)) return BLSW_ERR_ARG;
+    StepDesc d = {nullptr, d_sig_xy, d_msg, d_witness, witness_stride, d_result, d_pks_xy, d_bitmap, d_count};
+    return engine_submit(e, d, stream_);
 }
 
 // launches whatever is pending and makes `stream` wait for every group issued so far

@@ -100,6 +100,8 @@ int blsw_verify_multi_batch(const uint64_t* d_pks_xy, const uint8_t* d_msgs, uin
 typedef struct blsw_engine blsw_engine_t;
 typedef struct {
     int32_t device;        /* HIP device ordinal, -1 = the current device */
+    uint32_t n_keys;       /* 0 = the single-key circuit (blsw_engine_submit); K > 0 = the aggregate_verify circuit with K keys
+                            * (blsw_layout_aggregate; batches go through blsw_engine_submit_aggregate) */
     uint32_t pairing_mode; /* 0 = six lanes per instance (default), 1 = one lane per instance (9.7 KB stack: A/B runs only) */
     uint32_t g2_mode;      /* 0 = one lane per instance (default), 1 = six lanes per instance (needs pairing_mode 0) */
     uint32_t expand_variant; /* store geometry of the SHA expansion kernel, low byte: 0 = 384 threads x 8 pieces, 1 = one 4 KiB-aligned
@@ -112,6 +114,7 @@ typedef struct {
  * them HERE (read at every call, nothing is cached per process), so A/B runs need no recompilation */
 int blsw_engine_options_default(blsw_engine_options_t* out);
 int blsw_engine_workspace_bytes(uint64_t n, uint32_t msg_len, uint32_t max_steps, uint32_t n_buffers, uint64_t* bytes);
+int blsw_engine_workspace_bytes_ex(uint64_t n, uint32_t msg_len, uint32_t max_steps, uint32_t n_buffers, const blsw_engine_options_t* options, uint64_t* bytes);
 /* blsw_engine_create = blsw_engine_create_ex with blsw_engine_options_default. Returns BLSW_ERR_SCRATCH (nothing is
  * allocated) when pairing_mode 1 is combined with so many group buffers that the runtime's per-queue scratch
  * (stack bytes x 64 lanes x wave slots of the device, per queue) would exceed what ROCr can back: that combination
@@ -134,6 +137,12 @@ int blsw_engine_destroy(blsw_engine_t* e);
  * step has completed. Steps are numbered 0, 1, 2, ... in submission order (blsw_engine_submitted). */
 int blsw_engine_submit(blsw_engine_t* e, const uint64_t* d_pk_xy, const uint64_t* d_sig_xy, const uint8_t* d_msg, uint64_t* d_witness,
                        uint64_t witness_stride, int32_t* d_result, void* stream);
+/* aggregate_verify (src/constraints.rs:153-191) through the engine, for an engine created with options.n_keys = K: one batch of n
+ * instances of K keys each, same grouping / staging / streaming placement as blsw_engine_submit.
+ *   d_pks_xy [n][K][12] u64, d_bitmap [n][K] bytes (0/1), d_sig_xy [n][24], d_msg [n][msg_len]
+ *   d_witness [n][witness_stride] (stride >= blsw_layout_aggregate().n_witness; may be NULL), d_result [n] int32, d_count [n] uint32 (may be NULL) */
+int blsw_engine_submit_aggregate(blsw_engine_t* e, const uint64_t* d_pks_xy, const uint8_t* d_bitmap, const uint64_t* d_sig_xy, const uint8_t* d_msg,
+                                 uint64_t* d_witness, uint64_t witness_stride, int32_t* d_result, uint32_t* d_count, void* stream);
 /* Issues everything pending and makes `stream` wait for all batches submitted so far (asynchronous for the host). */
 int blsw_engine_flush(blsw_engine_t* e, void* stream);
 /* Streaming consumers (a prover draining witness tensors through a small ring of output buffers):

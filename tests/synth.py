@@ -68,3 +68,28 @@ def make_multi(o, K, seed=0x5EED, msg_len=32, tamper=None, start=0):
         msgs[tamper, msg_len - 1] ^= 1
     _cache[key] = (pks, msgs, sxy, tamper is None)
     return _cache[key]
+
+
+def make_aggregate(o, K, bitmap, seed=0x5EED, start=0, tamper=False):
+    """One aggregate_verify instance (constraints.rs:153-167): K keys, one message, sigma = sum over the selected keys of
+    sk_j * H(msg). -> (pks [K,12] u64, bitmap [K] u8, msg [32] u8, sig [24] u64, expect)"""
+    key = ("agg", K, tuple(bitmap), seed, start, tamper)
+    if key in _cache:
+        return _cache[key]
+    pks = np.zeros((K, 12), dtype=np.uint64)
+    m = _h(seed, b"am", start)
+    sigs = []
+    for j in range(K):
+        sk = int.from_bytes(_h(seed, b"sk", start + j), "big") % R_MOD or 1
+        st, xy, _ = o.g1_decompress(o.sk_to_pk(sk))
+        assert st == 0
+        pks[j] = xy
+        if bitmap[j]:
+            sigs.append(o.sign(sk, m))
+    st, sxy, inf = o.g2_decompress(o.aggregate_g2(sigs))
+    assert st == 0 and not inf
+    msg = np.frombuffer(m, dtype=np.uint8).copy()
+    if tamper:
+        msg[7] ^= 2
+    _cache[key] = (pks, np.array(bitmap, dtype=np.uint8), msg, sxy, not tamper)
+    return _cache[key]

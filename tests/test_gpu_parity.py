@@ -584,3 +584,42 @@ def test_gpu_witness_satisfies_product_matrices(pkg, oracle):
     bm = np.array([[1, 0]], dtype=np.uint8)
     g, cnt, wa = _agg_run(pkg, keys, bm, msg[0:1].copy(), sig[0:1].copy())  # bitmap selects key 0 only: sig of instance 0 verifies
     assert g.tolist() == [True] and cnt.tolist() == [1] and hostsim_lib.r1cs_check(PA, wa[0]) == -1
+
+
+def test_engine_aggregate_grouped(pkg, oracle):
+    """aggregate_verify through the grouped engine (options.n_keys; constraints.rs:153-191): three batches of 6 instances with 5
+    keys each, fused two per launch group, staged + placed; every instance against the oracle (results, counts, all witnesses)."""
+    import torch
+
+    K, n, steps = 5, 6, 3
+    dev = torch.device("cuda:0")
+    eng = pkg.WitnessEngine(n, 32, max_steps=2, device=dev, n_buffers=2, n_keys=K)
+    assert eng.n_witness == pkg.layout_aggregate(32, K)["n_witness"]
+    cases, outs = [], []
+    for k in range(steps):
+        batch = []
+        for i in range(n):
+            bm = [(i >> b) & 1 for b in range(K)]
+            bm[(i + k) % K] = 1  # at least one key selected
+            batch.append(synth.make_aggregate(oracle, K, bm, start=100 * k + 10 * i, tamper=(i == 4)))
+        pks = torch.from_numpy(np.stack([c[0] for c in batch]).view(np.int64)).to(dev)
+        bmt = torch.from_numpy(np.stack([c[1] for c in batch])).to(dev)
+        msg = torch.from_numpy(np.stack([c[2] for c in batch])).to(dev)
+        sig = torch.from_numpy(np.stack([c[3] for c in batch]).view(np.int64)).to(dev)
+        w = eng.new_witness_tensor()
+        r = torch.empty(n, dtype=torch.int32, device=dev)
+        c = torch.empty(n, dtype=torch.int32, device=dev)
+        assert eng.submit_aggregate(pks, bmt, sig, msg, witness=w, result=r, count=c) == k
+        cases.append(batch)
+        outs.append((w, r, c))
+    eng.flush()
+    torch.cuda.synchronize()
+    for k in range(steps):
+        w, r, c = outs[k]
+        got, cnt, wh = r.cpu().numpy().astype(bool), c.cpu().numpy(), w.cpu().numpy().view(np.uint64)
+        for i, (pks, bm, msg, sig, expect) in enumerate(cases[k]):
+            nw, res, cc, _, ow = oracle.witness_aggregate(pks, bm, msg.tobytes(), sig)
+            assert res == expect == bool(got[i]) and cc == cnt[i] == int(bm.sum()) and nw == wh.shape[1]
+            bad = np.nonzero((ow != wh[i]).any(axis=1))[0]
+            assert len(bad) == 0, "step %d instance %d: first mismatching witness index %d" % (k, i, bad[0])
+    eng.close()
