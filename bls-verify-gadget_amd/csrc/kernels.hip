@@ -19,7 +19,8 @@ namespace {
 // All per-instance scratch is stored element-major: element e of instance I lives at index e*N + I, so that the
 // 64 lanes of a wave touch one contiguous 3 KiB window per element (48 B per lane).
 struct Workspace {
-    uint32_t* bits;  // [N/64][sha_words][64] u32: SHA witness bitstream; a wave appends 256-byte rows to its own tile
+    uint32_t* bits;  // [N/64][sha_words/16][64][16] u32: SHA witness bitstream in 64-instance tiles; a wave appends 4 KiB rows
+                     // (one 64-byte run of 16 words per instance) to its own tile; sha_words is a multiple of 16
     Fp* u;           // [4][N]   hash_to_field output u0.c0,u0.c1,u1.c0,u1.c1
     Fp* q;           // [12][N]  Q0 (x.c0,x.c1,y.c0,y.c1,z.c0,z.c1), Q1
     Fp* h;           // [6][N]   H(m) projective
@@ -62,7 +63,7 @@ inline blsw_layout_t staging_layout(const blsw_layout_t& L, const Modes& m) {
 Workspace carve(void* base, uint64_t N, const blsw_layout_t& L, bool with_staging, const Modes& m, uint64_t n_sig = 0) {
     Workspace w;
     if (n_sig == 0) n_sig = N;
-    w.sha_words = (L.sha_bits + 31) / 32 + 1;
+    w.sha_words = align_up((L.sha_bits + 31) / 32 + 1, BLSW_BITS_CHUNK_WORDS);
     uint64_t off = 0;
     auto take = [&](uint64_t bytes) {
         uint64_t o = off;
@@ -174,6 +175,7 @@ __device__ __forceinline__ Emitter emitter(const Group& g, const LaneId& id, uin
 // ---------------------------------------------------------------- kernels (one instance per lane)
 // SHA-256 witness bits of expand_message (+ the message bits themselves)
 __global__ __launch_bounds__(64) void k_sha(Group g, int want_bits, int write_u) {
+    __shared__ uint32_t sha_lds[BLSW_BITS_CHUNK_WORDS * 64];  // the wave's word buffer of the bit sink
     if (g.chain_prio) __builtin_amdgcn_s_setprio(3);  // latency-critical chain: win VALU issue arbitration against the streaming placement waves
     uint64_t I = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (I >= g.N) return;
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(64) void k_sha(Group g, int want_bits, int write_u)
     uint32_t uw[64];
     if (want_bits) {
         BitSink s;
-        s.init(g.ws.bits + (I >> 6) * g.ws.sha_words * 64 + (I & 63), 64);
+        s.init_device(sha_lds + threadIdx.x, reinterpret_cast<uint4*>(g.ws.bits + (I >> 6) * g.ws.sha_words * 64 + (I & 63) * BLSW_BITS_CHUNK_WORDS));
         expand_message_w(s, msg, g.msg_len, false, uw);
     } else {
         expand_message_values(msg, g.msg_len, uw);  // the device sink always stores: no bits wanted = the value-only SHA
@@ -259,14 +261,18 @@ __device__ __forceinline__ void expand_locate(const ExpandArgs& a, uint4*& out, 
     const uint32_t pair = a.K == 1 ? 0u : blockIdx.y - (uint32_t)inst * a.K;
     out = reinterpret_cast<uint4*>(a.d_witness + (inst * a.stride + a.off_expand + (uint64_t)pair * a.stride_hash) * 6);
     const uint64_t lane = a.first + blockIdx.y;
-    b = a.bits + (lane >> 6) * a.sha_words * 64 + (lane & 63);
+    b = a.bits + (lane >> 6) * a.sha_words * 64 + (lane & 63) * BLSW_BITS_CHUNK_WORDS;
+}
+// word w of the instance whose stream starts at b (64-byte runs of 16 words, 64 instances interleaved per chunk)
+__device__ __forceinline__ uint32_t expand_word(const uint32_t* b, uint32_t w) {
+    return b[(uint64_t)(w / BLSW_BITS_CHUNK_WORDS) * (64 * BLSW_BITS_CHUNK_WORDS) + (w % BLSW_BITS_CHUNK_WORDS)];
 }
 // pieces [0, P0) in front of the first boundary: written by workgroup 0 of every variant
 template <int NT>
 __device__ __forceinline__ void expand_head(uint4* out, const uint32_t* b, uint32_t P0, uint32_t n_pieces) {
     if (blockIdx.x == 0 && threadIdx.x < P0 && threadIdx.x < n_pieces) {
         const uint32_t e = threadIdx.x / 3, c = threadIdx.x - 3 * e;
-        const uint32_t m = 0u - ((b[(uint64_t)(e >> 5) * 64] >> (e & 31)) & 1u);
+        const uint32_t m = 0u - ((expand_word(b, e >> 5) >> (e & 31)) & 1u);
         const uint4 rc = expand_column(c);
         expand_store<NT>(&out[threadIdx.x], make_uint4(rc.x & m, rc.y & m, rc.z & m, rc.w & m));
     }
@@ -287,15 +293,14 @@ __global__ __launch_bounds__(THREADS) void k_sha_expand(ExpandArgs a) {
     const uint4 rc = expand_column(c);
     // THREADS / 3 is a multiple of 32: the bit position of a thread is a loop invariant too, its word advances by THREADS / 96
     static_assert((THREADS / 3) % 32 == 0, "bit position must be loop invariant");
-    const uint32_t sh = e0 & 31;
-    const uint32_t* bw = b + (uint64_t)(e0 >> 5) * 64;
+    const uint32_t sh = e0 & 31, w0 = e0 >> 5;
     uint4* dst = out + (uint64_t)e0 * 3 + c;
     if (blockIdx.x * ((THREADS / 3) * ITERS) + (P0 + THREADS - 1) / 3 + (THREADS / 3) * (ITERS - 1) < a.sha_bits) {
         // whole workgroup in range (all but the last one or two of an instance): all bit words first, then the stores back to
         // back — no bounds checks, no wait between a store and the next load
         uint32_t w[ITERS];
 #pragma unroll
-        for (int k = 0; k < ITERS; k++) w[k] = bw[(uint64_t)k * (THREADS / 96) * 64];
+        for (int k = 0; k < ITERS; k++) w[k] = expand_word(b, w0 + k * (THREADS / 96));
 #pragma unroll
         for (int k = 0; k < ITERS; k++) {
             const uint32_t m = 0u - ((w[k] >> sh) & 1u);
@@ -307,7 +312,7 @@ __global__ __launch_bounds__(THREADS) void k_sha_expand(ExpandArgs a) {
     for (int k = 0; k < ITERS; k++) {
         const uint32_t e = e0 + (THREADS / 3) * k;
         if (e < a.sha_bits) {
-            const uint32_t m = 0u - ((bw[(uint64_t)k * (THREADS / 96) * 64] >> sh) & 1u);
+            const uint32_t m = 0u - ((expand_word(b, w0 + k * (THREADS / 96)) >> sh) & 1u);
             expand_store<NT>(dst + (uint64_t)k * THREADS, make_uint4(rc.x & m, rc.y & m, rc.z & m, rc.w & m));
         }
     }
@@ -325,7 +330,7 @@ __global__ __launch_bounds__(256) void k_sha_expand_chunk(ExpandArgs a) {
     const uint32_t p = P0 + blockIdx.x * 256 + threadIdx.x;
     if (p >= n_pieces) return;
     const uint32_t e = p / 3, c = p - 3 * e;
-    const uint32_t m = 0u - ((b[(uint64_t)(e >> 5) * 64] >> (e & 31)) & 1u);
+    const uint32_t m = 0u - ((expand_word(b, e >> 5) >> (e & 31)) & 1u);
     const uint4 rc = expand_column(c);
     expand_store<NT>(&out[p], make_uint4(rc.x & m, rc.y & m, rc.z & m, rc.w & m));
 }

@@ -41,21 +41,48 @@ BLSW_HD int popc32(uint32_t x) {
 #endif
 }
 
-// Bit sink: either counts bits (layout, host only) or packs them into 32-bit words stored at out[word * stride].
-// Hot code works on a LOCAL COPY of the sink (sha_block_w): through a reference, every store to `out` (a uint32_t*) may alias
-// the sink's own fields and forces them through memory around each append. On the device the sink always stores (kernels
-// that do not want the bits run the value-only SHA instead).
+// Bit sink: packs the appended bits into 32-bit words.
+//  host  : words stored at out[word * stride] (nullptr = count only: the layout's bit count)
+//  device: the wave's 64 lanes are 64 instances of one tile. Words are collected in LDS ([16][64] u32, 4 KiB per wave, written
+//          and read back by the same lane) and leave as 64-BYTE RUNS: chunk c of lane l lives at tile + (c * 64 + l) * 64 bytes,
+//          so that the expansion kernel, which walks ONE instance's bits, uses whole 64-byte pieces of every line it fetches
+//          (with one word per lane per row a 128-byte line held the words of 32 instances that are expanded at 32 different
+//          times: 33x the bytes, 1.4 GB of re-reads per 1024-instance step).
+// Hot code works on a LOCAL COPY of the sink (sha_block_w): through a reference, every store through a uint32_t* may alias the
+// sink's own fields and forces them through memory around each append. On the device the sink always stores (kernels that do
+// not want the bits run the value-only SHA instead).
+#define BLSW_BITS_CHUNK_WORDS 16
 struct BitSink {
-    uint32_t* out;    // nullptr = count only (host)
-    uint32_t* cur;    // where the next word goes
-    uint64_t stride;  // distance (in u32) between consecutive words of this lane's stream
+    uint32_t* out;    // host: nullptr = count only; device: unused
+    uint64_t stride;  // host: distance (in u32) between consecutive words of this stream
     uint64_t acc;
     uint32_t fill;
     uint32_t widx;
     uint64_t nbits;
+#if defined(__HIPCC__)  // members exist in both passes of a HIP translation unit; only the device pass uses them
+    uint32_t* lds;  // this lane's column of the wave's [16][64] word buffer (LDS address space behind a generic pointer)
+    uint4* gcur;    // where this lane's next 64-byte run goes
+    BLSW_HD void init_device(uint32_t* lds_lane, uint4* first_run) {
+        out = nullptr;
+        stride = 0;
+        acc = 0;
+        fill = 0;
+        widx = 0;
+        nbits = 0;
+        lds = lds_lane;
+        gcur = first_run;
+    }
+    BLSW_HD void run_out() {  // the 16 words this lane collected -> one 64-byte run
+        uint32_t w[BLSW_BITS_CHUNK_WORDS];
+#pragma unroll
+        for (int k = 0; k < BLSW_BITS_CHUNK_WORDS; k++) w[k] = lds[k * 64];
+#pragma unroll
+        for (int k = 0; k < 4; k++) gcur[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+        gcur += 64 * 4;  // next chunk of this lane: 64 lanes x 64 bytes further
+    }
+#endif
     BLSW_HD void init(uint32_t* o, uint64_t s) {
         out = o;
-        cur = o;
         stride = s;
         acc = 0;
         fill = 0;
@@ -64,12 +91,13 @@ struct BitSink {
     }
     BLSW_HD void word_out() {
 #if defined(__HIP_DEVICE_COMPILE__)
-        *cur = (uint32_t)acc;
-        cur += stride;
+        lds[(widx & (BLSW_BITS_CHUNK_WORDS - 1)) * 64] = (uint32_t)acc;
+        widx++;
+        if ((widx & (BLSW_BITS_CHUNK_WORDS - 1)) == 0) run_out();
 #else
         if (out) out[(uint64_t)widx * stride] = (uint32_t)acc;
-#endif
         widx++;
+#endif
         acc >>= 32;
     }
     BLSW_HD void push(uint32_t bits, uint32_t n) {  // n <= 32, bits above n must be zero
@@ -96,6 +124,9 @@ struct BitSink {
             acc = 0;
             fill = 0;
         }
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (widx & (BLSW_BITS_CHUNK_WORDS - 1)) run_out();  // the last, partial run (words beyond the stream are never read)
+#endif
     }
 };
 
