@@ -327,7 +327,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "u32 (12 x 32-bit limb Montgomery integers mod the 381-bit BLS12-381 prime; SHA-256 words)",
+        "dtype": "u32 (381-bit Montgomery integers mod the BLS12-381 prime as 12 x 32-bit limbs in memory, products on 14 x 28-bit limbs with 64-bit columns; SHA-256 words)",
         "data": "synthetic",
         "config": {"workload": "configs[1]: batch of 1024 independent BLS-verify instances per GPU per step (1024 distinct messages, 16 keys, every 16th tampered), 32-byte messages, full witness vectors written",
                    "instances_per_gpu_per_step": n, "batches_fused_per_launch_group": coalesce, "groups_in_flight": buffers, "output_ring": n_out, "n_witness": lay["n_witness"], "results_ok": ok,

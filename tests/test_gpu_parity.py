@@ -290,10 +290,13 @@ def test_sign_batch_fixtures_and_synthetic_workload(pkg, oracle):
     assert (gmsg.cpu().numpy() == omsg).all() and (gexp == oexp).all()
 
 
-def test_witness_digests_against_committed_goldens(pkg, oracle):
-    """The HIP path against tests/golden/witness_digests.json directly (no oracle call for the expected values): SHA-256 of
-    every witness vector and of its Miller-loop segment for the valid verify fixtures and the reference gadget case; inputs
-    are decoded from the compressed fixture bytes on the GPU."""
+def test_gpu_matches_oracle_emitted_digests(pkg, oracle):
+    """ORACLE-vs-GPU (T2), not a T3 check: tests/golden/witness_digests.json was emitted by this repository's own oracle
+    (tests/golden/gen_oracle_vectors.py), so it pins the GPU to the oracle, not to real arkworks — the witness ORDER of real
+    arkworks stays unpinned until tools/t3_dumper is run by someone with cargo. What it adds over the
+    element-wise tests: the committed file freezes the oracle's output across rounds (SHA-256 of every witness vector and of its
+    Miller-loop segment for the valid verify fixtures and the reference gadget case; inputs decoded from the compressed fixture
+    bytes on the GPU)."""
     import hashlib
 
     import torch
