@@ -19,7 +19,9 @@ struct Emitter {
             pos++;
             return;
         }
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(BLSW_DEBUG_NO_EMIT)  // timing experiment: chains without their staging stores
+        if (v.l[0] == 0x12345678u && v.l[7] == 0x9abcdef0u) *reinterpret_cast<uint32_t*>(base + (size_t)pos * stride) = 1;
+#elif defined(__HIP_DEVICE_COMPILE__)
         uint4* d = reinterpret_cast<uint4*>(base + (size_t)pos * stride);
         d[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
         d[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);

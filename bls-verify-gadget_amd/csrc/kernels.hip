@@ -39,6 +39,7 @@ struct Workspace {
     uint64_t total_bytes;
 };
 inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
+BLSW_HD inline uint64_t bits_tile_words(uint64_t sha_words) { return sha_words * 64; }  // u32 per 64-instance tile
 // kernel variants, fixed per engine at creation (blsw_engine_options_t)
 struct Modes {
     bool pairing_team;  // pairing segment: six lanes per instance (default) or the single-lane chain (kept for A/B runs)
@@ -70,7 +71,7 @@ Workspace carve(void* base, uint64_t N, const blsw_layout_t& L, bool with_stagin
         off = align_up(off + bytes, 256);
         return reinterpret_cast<char*>(base) + o;
     };
-    w.bits = reinterpret_cast<uint32_t*>(take(w.sha_words * align_up(N, 64) * 4));
+    w.bits = reinterpret_cast<uint32_t*>(take(bits_tile_words(w.sha_words) * (align_up(N, 64) / 64) * 4));
     w.u = reinterpret_cast<Fp*>(take(4 * N * sizeof(Fp)));
     w.q = reinterpret_cast<Fp*>(take(12 * N * sizeof(Fp)));
     w.h = reinterpret_cast<Fp*>(take(6 * N * sizeof(Fp)));
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(64) void k_sha(Group g, int want_bits, int write_u)
     uint32_t uw[64];
     if (want_bits) {
         BitSink s;
-        s.init_device(sha_lds + threadIdx.x, reinterpret_cast<uint4*>(g.ws.bits + (I >> 6) * g.ws.sha_words * 64 + (I & 63) * BLSW_BITS_CHUNK_WORDS));
+        s.init_device(sha_lds + threadIdx.x, reinterpret_cast<uint4*>(g.ws.bits + (I >> 6) * bits_tile_words(g.ws.sha_words) + (I & 63) * BLSW_BITS_CHUNK_WORDS));
         expand_message_w(s, msg, g.msg_len, false, uw);
     } else {
         expand_message_values(msg, g.msg_len, uw);  // the device sink always stores: no bits wanted = the value-only SHA
@@ -261,10 +262,13 @@ __device__ __forceinline__ void expand_locate(const ExpandArgs& a, uint4*& out, 
     const uint32_t pair = a.K == 1 ? 0u : blockIdx.y - (uint32_t)inst * a.K;
     out = reinterpret_cast<uint4*>(a.d_witness + (inst * a.stride + a.off_expand + (uint64_t)pair * a.stride_hash) * 6);
     const uint64_t lane = a.first + blockIdx.y;
-    b = a.bits + (lane >> 6) * a.sha_words * 64 + (lane & 63) * BLSW_BITS_CHUNK_WORDS;
+    b = a.bits + (lane >> 6) * bits_tile_words(a.sha_words) + (lane & 63) * BLSW_BITS_CHUNK_WORDS;
 }
 // word w of the instance whose stream starts at b (64-byte runs of 16 words, 64 instances interleaved per chunk)
 __device__ __forceinline__ uint32_t expand_word(const uint32_t* b, uint32_t w) {
+    #ifdef BLSW_DEBUG_EXPAND_NOREAD  // timing experiment
+    return 0x55555555u + w;
+#endif
     return b[(uint64_t)(w / BLSW_BITS_CHUNK_WORDS) * (64 * BLSW_BITS_CHUNK_WORDS) + (w % BLSW_BITS_CHUNK_WORDS)];
 }
 // pieces [0, P0) in front of the first boundary: written by workgroup 0 of every variant
@@ -971,6 +975,11 @@ static int launch_group(blsw_engine* e) {
     g.LS = e->LS;
     g.ws = carve(b.base, g.N, e->L, e->staged, e->modes);
     g.chain_prio = e->opt.prio_mode == 0;
+#ifdef BLSW_DEBUG_KNOBS  // timing experiments only (wrong witnesses): BLSW_DEBUG_SKIP bit 0 chains, bit 1 placement, bit 2 expansion
+    static const uint32_t dbg_skip = getenv("BLSW_DEBUG_SKIP") ? (uint32_t)atoi(getenv("BLSW_DEBUG_SKIP")) : 0u;
+#else
+    constexpr uint32_t dbg_skip = 0;
+#endif
     const unsigned g1 = (unsigned)((g.N + 63) / 64), g2 = (unsigned)((2 * g.N + 63) / 64);
     const unsigned gt = (unsigned)((g.N + BLSW_TEAMS_PER_WAVE - 1) / BLSW_TEAMS_PER_WAVE);
     hipStream_t st = b.st[0];
@@ -991,6 +1000,7 @@ static int launch_group(blsw_engine* e) {
     if (any_out) hipLaunchKernelGGL(k_sha, dim3(g1), dim3(64), 0, e->sha, g, 1, 0);
     hipEventRecord(b.ev_sha, e->sha);
     // main, first part: the hash-to-G2 critical path
+    if (!(dbg_skip & 1)) {
     hipLaunchKernelGGL(k_sha_values, dim3(g1), dim3(64), 0, st, g);
     hipLaunchKernelGGL(k_map, dim3(g2), dim3(64), 0, st, g);
     hipLaunchKernelGGL(k_cofactor, dim3(g1), dim3(64), 0, st, g);
@@ -1006,10 +1016,11 @@ static int launch_group(blsw_engine* e) {
         hipLaunchKernelGGL(k_g2_alloc_team, dim3(gt), dim3(64), 0, b.st[1], g);
     else
         hipLaunchKernelGGL(k_g2_alloc, dim3(g1), dim3(64), 0, b.st[1], g);
+    }
     hipEventRecord(b.ev_aux, b.st[1]);
     // main, second part: the pairing
     hipStreamWaitEvent(st, b.ev_aux, 0);
-    launch_pairing(g, e->modes, st);
+    if (!(dbg_skip & 1)) launch_pairing(g, e->modes, st);
     hipStreamWaitEvent(st, b.ev_sha, 0);
     hipEventRecord(b.ev_chains, st);
     // expansion of the SHA segments, per step, in submission order: waits for the SHA bits only
@@ -1025,7 +1036,7 @@ static int launch_group(blsw_engine* e) {
             const bool timed = e->n_timed < BLSW_MAX_TIMED;
             if (timed) hipEventRecord(e->ev_exp[2 * e->n_timed], e->expand);
             ExpandArgs xa = {g.ws.bits, g.ws.sha_words, (uint64_t)s * e->n, e->L.sha_bits, e->L.off_expand, d.out, d.out_stride, 1u, 0u, 0};
-            launch_expand(e->opt.expand_variant, e->opt.expand_store, e->opt.place_lds, e->expand, xa, (unsigned)e->n);
+            if (!(dbg_skip & 4)) launch_expand(e->opt.expand_variant, e->opt.expand_store, e->opt.place_lds, e->expand, xa, (unsigned)e->n);
             if (timed) {
                 hipEventRecord(e->ev_exp[2 * e->n_timed + 1], e->expand);
                 e->n_timed++;
@@ -1038,7 +1049,7 @@ static int launch_group(blsw_engine* e) {
     for (uint32_t s = 0; s < steps; s++) {
         const StepDesc& d = b.h_desc[s];
         hipStreamWaitEvent(e->place, b.ev_x[s], 0);
-        if (d.out && e->staged) {
+        if (d.out && e->staged && !(dbg_skip & 2)) {
             const uint32_t rows = e->L.n_witness - e->L.sha_bits;
             const unsigned chunks = (rows * 3 + 256 * BLSW_PLACE_ITERS - 1) / (256 * BLSW_PLACE_ITERS);
             dim3 grid2(8 * ((chunks + 7) / 8) * (unsigned)e->n);

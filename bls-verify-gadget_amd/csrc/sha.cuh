@@ -51,7 +51,9 @@ BLSW_HD int popc32(uint32_t x) {
 // Hot code works on a LOCAL COPY of the sink (sha_block_w): through a reference, every store through a uint32_t* may alias the
 // sink's own fields and forces them through memory around each append. On the device the sink always stores (kernels that do
 // not want the bits run the value-only SHA instead).
+#ifndef BLSW_BITS_CHUNK_WORDS
 #define BLSW_BITS_CHUNK_WORDS 16
+#endif
 struct BitSink {
     uint32_t* out;    // host: nullptr = count only; device: unused
     uint64_t stride;  // host: distance (in u32) between consecutive words of this stream
@@ -77,8 +79,8 @@ struct BitSink {
 #pragma unroll
         for (int k = 0; k < BLSW_BITS_CHUNK_WORDS; k++) w[k] = lds[k * 64];
 #pragma unroll
-        for (int k = 0; k < 4; k++) gcur[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
-        gcur += 64 * 4;  // next chunk of this lane: 64 lanes x 64 bytes further
+        for (int k = 0; k < BLSW_BITS_CHUNK_WORDS / 4; k++) gcur[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+        gcur += 64 * BLSW_BITS_CHUNK_WORDS / 4;  // next run of this lane: one tile row (64 lanes x one run) further
     }
 #endif
     BLSW_HD void init(uint32_t* o, uint64_t s) {
