@@ -14,8 +14,10 @@ Multi-GPU: one process per GPU over RCCL. `python bench.py --gpus N` starts the 
 `python -m torch.distributed.run`, spawned before this process touches the GPU) and prints the child's one JSON line; under
 an external launcher (RANK / WORLD_SIZE in the environment) it is a rank and checks WORLD_SIZE == --gpus. Instances are
 independent: each rank processes its own 1 024-instance shard per step (weak scaling, NO data-path collective in `value`);
-the north-star's all-gather of witness shards is timed separately (`value_with_allgather`): micro-batches of every step's
-tensor are all-gathered over RCCL and consumed by the digest kernel before the ring slot is reused.
+the north-star's all-gather of witness shards is timed separately (`value_with_allgather`). Default `--allgather-form compact`:
+every step leaves the engine in its compact wire form (bit-packed SHA witnesses + field witnesses, 2.6 MB per instance), THAT is
+all-gathered over RCCL, and every rank expands all ranks' batches back into full witness tensors (34 MB per instance), each
+consumed by the digest kernel before the next; `--allgather-form full` gathers the full tensors in micro-batches instead.
 """
 import argparse
 import importlib
@@ -56,7 +58,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=256, help="instances of the batch timed on the host (all cores, and one thread)")
     ap.add_argument("--allgather-steps", type=int, default=8, help="steps of the generation + all-gather leg (0 = skip; runs when a process group exists)")
-    ap.add_argument("--allgather-chunk", type=int, default=16, help="instances per rank in one all-gathered micro-batch")
+    ap.add_argument("--allgather-chunk", type=int, default=64, help="instances per rank in one all-gathered micro-batch (form full)")
+    ap.add_argument("--allgather-form", choices=("compact", "full"), default="compact",
+                    help="what travels in the all-gather leg: the compact wire form, expanded by every receiver, or the full witness tensors")
     return ap.parse_args()
 
 
@@ -190,7 +194,75 @@ def allgather_leg(args, pkg, sharding, dist, dev, inputs, lay, world):
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     eng.close()
-    return float(t.item()), steps, chunk
+    return float(t.item()), steps, {"form": "full", "micro_batch_instances_per_rank": chunk, "ring": ring,
+                                    "consumer": "blsw_witness_digest over each gathered micro-batch",
+                                    "bytes_received_per_gpu_per_step": (world - 1) * n * lay["n_witness"] * 48}
+
+
+def allgather_leg_compact(args, pkg, sharding, dist, dev, inputs, lay, world):
+    """Generation + all-gather in compact wire form: a step is submitted with submit_compact, its 2.6 MB per
+    instance are all-gathered (one RCCL all-gather of [world][compact_bytes] per step), and this rank expands every rank's
+    batch into a full witness tensor (expand_compact: the same expansion / placement kernels as a local step) which the
+    digest kernel consumes before the next one is expanded. Per step every GPU writes and reads world x 34 MB x n of vectors."""
+    import torch
+
+    n = args.batch
+    steps = min(args.allgather_steps, args.steps)
+    group = max(1, min(8, steps))
+    ring = 2 * group  # a compact buffer is released (output_consumed) before the group that reuses it is launched
+    eng = pkg.WitnessEngine(n, 32, max_steps=group, device=dev, n_buffers=max(2, min(3, (steps + group - 1) // group)))
+    cbufs = eng.new_compact_buffer(ring)
+    results = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(ring)]
+    gathered = torch.empty((world, eng.compact_bytes()), dtype=torch.uint8, device=dev)
+    wit = eng.new_witness_tensor()
+    dig = torch.empty((n, 2), dtype=torch.int64, device=dev)
+    acc = torch.zeros(2, dtype=torch.int64, device=dev)
+    consumer = torch.cuda.Stream(device=dev)
+    d_pk, d_msg, d_sig = inputs
+    state = {"next": 0}
+
+    def expand(c):
+        eng.expand_compact(c, wit, stream=consumer)
+        return wit
+
+    def consume(w, r):
+        acc.add_(pkg.witness_digest(w, out=dig, stream=consumer).sum(dim=0))
+
+    def drain():
+        while state["next"] < eng.launched():
+            s = state["next"]
+            eng.wait_step(s, consumer)
+            with torch.cuda.stream(consumer):
+                sharding.stream_allgather_compact(cbufs[s % ring], expand, consume, buffer=gathered)
+            eng.output_consumed(cbufs[s % ring], consumer)
+            state["next"] += 1
+
+    def run(k_steps):
+        for k in range(k_steps):
+            eng.submit_compact(d_pk, d_sig, d_msg, cbufs[k % ring], result=results[k % ring])
+            drain()
+        eng.flush()
+        drain()
+        consumer.synchronize()
+        torch.cuda.synchronize()
+
+    run(group)  # warm-up: communicator, buffers
+    state["next"] = eng.launched()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(steps)
+    dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    cb = eng.compact_bytes()
+    eng.close()
+    return float(t.item()), steps, {"form": "compact", "group_steps": group, "ring": ring, "wire_bytes_per_instance": cb / n,
+                                    "bytes_received_per_gpu_per_step": (world - 1) * cb,
+                                    "bytes_expanded_per_gpu_per_step": world * n * lay["n_witness"] * 48,
+                                    "consumer": "blsw_witness_digest over every expanded batch (all ranks' batches, on every rank)"}
 
 
 def main():
@@ -289,7 +361,8 @@ def main():
 
     ag = None
     if dist and args.allgather_steps > 0:
-        ag = allgather_leg(args, pkg, sharding, dist, dev, (d_pk, d_msg, d_sig), lay, world)
+        leg = allgather_leg_compact if (args.allgather_form == "compact" and n % 64 == 0) else allgather_leg
+        ag = leg(args, pkg, sharding, dist, dev, (d_pk, d_msg, d_sig), lay, world)
     if dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -346,11 +419,9 @@ def main():
                                    "measured_peak_fpmul_per_s": fpmul_peak, "frac": value / world * executed_fpmul / fpmul_peak},
     }
     if ag:
-        ag_dt, ag_steps, ag_chunk = ag
+        ag_dt, ag_steps, ag_info = ag
         out["value_with_allgather"] = n * world * ag_steps / ag_dt
-        out["allgather"] = {"steps": ag_steps, "seconds": ag_dt, "micro_batch_instances_per_rank": ag_chunk, "ring": 2,
-                            "consumer": "blsw_witness_digest over each gathered micro-batch",
-                            "bytes_received_per_gpu_per_step": (world - 1) * n * lay["n_witness"] * 48}
+        out["allgather"] = dict({"steps": ag_steps, "seconds": ag_dt}, **ag_info)
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, d_pk, d_msg, d_sig, n)
     print(json.dumps(out))

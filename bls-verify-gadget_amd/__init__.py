@@ -76,6 +76,9 @@ def lib():
         L.blsw_engine_launched.argtypes = [vp, ctypes.POINTER(u64)]
         L.blsw_engine_wait_step.argtypes = [vp, u64, vp]
         L.blsw_engine_output_consumed.argtypes = [vp, vp, vp]
+        L.blsw_engine_compact_bytes.argtypes = [vp, ctypes.POINTER(u64)]
+        L.blsw_engine_submit_compact.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+        L.blsw_engine_expand_compact.argtypes = [vp, vp, vp, u64, vp]
         L.blsw_witness_digest.argtypes = [vp, u64, u64, u32, vp, vp]
         L.blsw_matrices_info.argtypes = [u32, u32, u32, ctypes.POINTER(blsw_matrices_info_t)]
         L.blsw_matrices_fill.argtypes = [u32, u32, u32, ctypes.POINTER(blsw_matrices_info_t), ctypes.POINTER(blsw_matrices_t)]
@@ -100,7 +103,7 @@ def lib():
 
 EXPORTED_SYMBOLS = ["blsw_version", "blsw_layout", "blsw_engine_options_default", "blsw_engine_workspace_bytes", "blsw_engine_workspace_bytes_ex", "blsw_engine_create",
                     "blsw_engine_create_ex", "blsw_engine_destroy", "blsw_engine_submit", "blsw_engine_submit_aggregate", "blsw_engine_flush", "blsw_engine_submitted", "blsw_engine_launched", "blsw_engine_wait_step",
-                    "blsw_engine_output_consumed", "blsw_engine_expand_stats", "blsw_witness_digest", "blsw_hash_to_g2_workspace_bytes", "blsw_hash_to_g2_batch",
+                    "blsw_engine_output_consumed", "blsw_engine_compact_bytes", "blsw_engine_submit_compact", "blsw_engine_expand_compact", "blsw_engine_expand_stats", "blsw_witness_digest", "blsw_hash_to_g2_workspace_bytes", "blsw_hash_to_g2_batch",
                     "blsw_decode_batch", "blsw_layout_aggregate", "blsw_aggregate_workspace_bytes", "blsw_aggregate_verify_batch", "blsw_layout_multi",
                     "blsw_verify_multi_workspace_bytes", "blsw_verify_multi_batch", "blsw_matrices_info", "blsw_matrices_fill", "blsw_sign_batch", "blsw_microbench"]
 
@@ -228,6 +231,37 @@ class WitnessEngine:
         self._keep.append((pks_xy, bitmap, sig_xy, msg, witness, result, count))
         self._keep = self._keep[-(self.n_buffers + 1) * self.max_steps:]
         return seq
+
+    def compact_bytes(self):
+        """Bytes of one batch in compact wire form (bit-packed SHA witnesses + staged field witnesses, ~2.6 MB per instance)."""
+        return self._counter(lib().blsw_engine_compact_bytes)
+
+    def new_compact_buffer(self, batches=1):
+        import torch
+
+        return torch.empty((batches, self.compact_bytes()), dtype=torch.uint8, device=self.device)
+
+    def submit_compact(self, pk_xy, sig_xy, msg, compact, result=None, stream=None):
+        """As submit(), but the step's output is its compact wire form in `compact` (uint8 tensor of compact_bytes()) -> step number"""
+        assert pk_xy.shape == (self.n, 12) and sig_xy.shape == (self.n, 24) and msg.shape == (self.n, self.msg_len)
+        assert pk_xy.is_contiguous() and sig_xy.is_contiguous() and msg.is_contiguous()
+        assert compact.is_cuda and compact.is_contiguous() and compact.dtype.itemsize == 1 and compact.numel() >= self.compact_bytes()
+        seq = self.submitted()
+        rc = lib().blsw_engine_submit_compact(self._e, pk_xy.data_ptr(), sig_xy.data_ptr(), msg.data_ptr() if self.msg_len else None, compact.data_ptr(),
+                                              result.data_ptr() if result is not None else None, self._stream(stream))
+        if rc:
+            raise BlswError("blsw_engine_submit_compact failed: %d" % rc)
+        self._keep.append((pk_xy, sig_xy, msg, compact, result))
+        self._keep = self._keep[-(self.n_buffers + 1) * self.max_steps:]
+        return seq
+
+    def expand_compact(self, compact, witness, stream=None):
+        """Receiver side: one batch in compact form (this engine's or another rank's) -> its n witness vectors in `witness`."""
+        assert compact.is_cuda and compact.is_contiguous() and compact.numel() >= self.compact_bytes()
+        assert witness.is_contiguous() and witness.shape[0] == self.n and witness.shape[1] >= self.n_witness
+        rc = lib().blsw_engine_expand_compact(self._e, compact.data_ptr(), witness.data_ptr(), witness.shape[1], self._stream(stream))
+        if rc:
+            raise BlswError("blsw_engine_expand_compact failed: %d" % rc)
 
     def flush(self, stream=None):
         rc = lib().blsw_engine_flush(self._e, self._stream(stream))

@@ -101,7 +101,24 @@ struct StepDesc {
     const uint64_t* keys;   // [n][n_keys][12]
     const uint8_t* bitmap;  // [n][n_keys]
     uint32_t* count;        // [n]
+    // host side only: the step leaves the engine in its compact wire form (blsw_engine_submit_compact) instead of as witness vectors
+    void* compact;
 };
+// Compact wire form of a step of n instances (n a multiple of 64): the step's slices of the group workspace, back to back —
+// [n/64][sha_words/16][64][16] u32 bit words | [n/64][split_row][64] Fp tile-major rows | [n][pair_rows] Fp instance-major rows
+struct CompactForm {
+    uint64_t bits_bytes, staging_bytes, pair_bytes, off_staging, off_pair, total;
+};
+static CompactForm compact_form(uint64_t n, const Workspace& w) {
+    CompactForm c;
+    c.bits_bytes = bits_tile_words(w.sha_words) * (n / 64) * 4;
+    c.staging_bytes = (uint64_t)w.split_row * n * sizeof(Fp);
+    c.pair_bytes = (uint64_t)w.pair_rows * n * sizeof(Fp);
+    c.off_staging = align_up(c.bits_bytes, 256);
+    c.off_pair = align_up(c.off_staging + c.staging_bytes, 256);
+    c.total = align_up(c.off_pair + c.pair_bytes, 256);
+    return c;
+}
 // a group of `steps` batches of n instances each, processed by one set of launches (N = steps * n * K lanes per chain;
 // K = (pk, msg) pairs per instance: 1 except for the N+1-pair product)
 struct Group {
@@ -961,6 +978,16 @@ static void engine_free(blsw_engine* e) {
     delete e;
 }
 
+// field witnesses of one step: staged rows (lanes first .. first + n of the tiles at `staging` / the rows at `pair`) -> their
+// places around the SHA segment of the step's witness vectors
+static void launch_place(blsw_engine* e, hipStream_t st, const Fp* staging, const Fp* pair, uint32_t split_row, uint64_t first, uint64_t* out, uint64_t out_stride) {
+    const uint32_t rows = e->L.n_witness - e->L.sha_bits;
+    const unsigned chunks = (rows * 3 + 256 * BLSW_PLACE_ITERS - 1) / (256 * BLSW_PLACE_ITERS);
+    dim3 grid2(8 * ((chunks + 7) / 8) * (unsigned)e->n);
+    hipLaunchKernelGGL(k_place_field, grid2, dim3(256), 0, st, staging, pair, first, e->L.off_expand, e->L.sha_bits, rows, split_row, out, out_stride, (uint32_t)e->n,
+                       e->L.off_sig_alloc, e->modes.g2_team ? e->L.off_pk_not_zero - e->L.off_sig_alloc : 0u, e->LS.off_sig_alloc);
+}
+
 static int launch_group(blsw_engine* e) {
     GroupBuf& b = e->buf[e->cur];
     const uint32_t steps = e->pending;
@@ -986,7 +1013,16 @@ static int launch_group(blsw_engine* e) {
     // inputs of every step are ready once its submitting stream reached the point of the submit
     for (uint32_t s = 0; s < steps; s++) hipStreamWaitEvent(st, b.ev_in[s], 0);
     bool any_out = false;
-    for (uint32_t s = 0; s < steps; s++) any_out = any_out || b.h_desc[s].out != nullptr;
+    for (uint32_t s = 0; s < steps; s++) any_out = any_out || b.h_desc[s].out != nullptr || b.h_desc[s].compact != nullptr;
+    const CompactForm cf = compact_form(e->n, g.ws);
+    // a consumer's release of an output (blsw_engine_output_consumed): the stream that is about to overwrite it waits for it
+    auto wait_released = [&](hipStream_t stream, const void* ptr) {
+        for (int c = 0; c < BLSW_MAX_CONSUMED; c++)
+            if (e->consumed_live[c] && e->consumed_ptr[c] == ptr) {
+                hipStreamWaitEvent(stream, e->consumed_ev[c], 0);
+                e->consumed_live[c] = false;
+            }
+    };
     // direct mode: the chains themselves write into the output tensors, so they wait for the consumer's release
     if (!e->staged)
         for (uint32_t s = 0; s < steps; s++)
@@ -1027,12 +1063,12 @@ static int launch_group(blsw_engine* e) {
     hipStreamWaitEvent(e->expand, b.ev_sha, 0);
     for (uint32_t s = 0; s < steps; s++) {
         const StepDesc& d = b.h_desc[s];
+        if (d.compact) {  // the step's bit words leave as they are
+            wait_released(e->expand, d.compact);
+            hipMemcpyAsync(d.compact, g.ws.bits + (uint64_t)s * (e->n / 64) * bits_tile_words(g.ws.sha_words), cf.bits_bytes, hipMemcpyDeviceToDevice, e->expand);
+        }
         if (d.out) {
-            for (int c = 0; c < BLSW_MAX_CONSUMED; c++)
-                if (e->consumed_live[c] && e->consumed_ptr[c] == d.out) {
-                    hipStreamWaitEvent(e->expand, e->consumed_ev[c], 0);
-                    e->consumed_live[c] = false;
-                }
+            wait_released(e->expand, d.out);
             const bool timed = e->n_timed < BLSW_MAX_TIMED;
             if (timed) hipEventRecord(e->ev_exp[2 * e->n_timed], e->expand);
             ExpandArgs xa = {g.ws.bits, g.ws.sha_words, (uint64_t)s * e->n, e->L.sha_bits, e->L.off_expand, d.out, d.out_stride, 1u, 0u, 0};
@@ -1049,14 +1085,13 @@ static int launch_group(blsw_engine* e) {
     for (uint32_t s = 0; s < steps; s++) {
         const StepDesc& d = b.h_desc[s];
         hipStreamWaitEvent(e->place, b.ev_x[s], 0);
-        if (d.out && e->staged && !(dbg_skip & 2)) {
-            const uint32_t rows = e->L.n_witness - e->L.sha_bits;
-            const unsigned chunks = (rows * 3 + 256 * BLSW_PLACE_ITERS - 1) / (256 * BLSW_PLACE_ITERS);
-            dim3 grid2(8 * ((chunks + 7) / 8) * (unsigned)e->n);
-            hipLaunchKernelGGL(k_place_field, grid2, dim3(256), 0, e->place, g.ws.staging, g.ws.pair, (uint64_t)s * e->n, e->L.off_expand, e->L.sha_bits, rows,
-                               g.ws.split_row, d.out, d.out_stride, (uint32_t)e->n, e->L.off_sig_alloc,
-                               e->modes.g2_team ? e->L.off_pk_not_zero - e->L.off_sig_alloc : 0u, e->LS.off_sig_alloc);
+        if (d.compact) {  // and so do its staged field witnesses
+            char* dst = reinterpret_cast<char*>(d.compact);
+            hipMemcpyAsync(dst + cf.off_staging, g.ws.staging + (uint64_t)s * (e->n / 64) * g.ws.split_row * 64, cf.staging_bytes, hipMemcpyDeviceToDevice, e->place);
+            if (cf.pair_bytes)
+                hipMemcpyAsync(dst + cf.off_pair, g.ws.pair + (uint64_t)s * e->n * g.ws.pair_rows, cf.pair_bytes, hipMemcpyDeviceToDevice, e->place);
         }
+        if (d.out && e->staged && !(dbg_skip & 2)) launch_place(e, e->place, g.ws.staging, g.ws.pair, g.ws.split_row, (uint64_t)s * e->n, d.out, d.out_stride);
         hipEventRecord(b.ev_step[s], e->place);
     }
     hipEventRecord(b.ev_done, e->place);
@@ -1268,15 +1303,43 @@ static int engine_submit(blsw_engine_t* e, const StepDesc& step, void* stream_) 
 int blsw_engine_submit(blsw_engine_t* e, const uint64_t* d_pk_xy, const uint64_t* d_sig_xy, const uint8_t* d_msg, uint64_t* d_witness,
                        uint64_t witness_stride, int32_t* d_result, void* stream_) {
     if (!e || e->L.n_keys || !d_pk_xy || !d_sig_xy || (!d_msg && e->msg_len)) return BLSW_ERR_ARG;
-    StepDesc d = {d_pk_xy, d_sig_xy, d_msg, d_witness, witness_stride, d_result, nullptr, nullptr, nullptr};
+    StepDesc d = {d_pk_xy, d_sig_xy, d_msg, d_witness, witness_stride, d_result, nullptr, nullptr, nullptr, nullptr};
     return engine_submit(e, d, stream_);
 }
 // aggregate_verify through the engine (an engine created with options.n_keys = K): one batch of n instances of K keys each
 int blsw_engine_submit_aggregate(blsw_engine_t* e, const uint64_t* d_pks_xy, const uint8_t* d_bitmap, const uint64_t* d_sig_xy, const uint8_t* d_msg,
                                  uint64_t* d_witness, uint64_t witness_stride, int32_t* d_result, uint32_t* d_count, void* stream_) {
     if (!e || !e->L.n_keys || !d_pks_xy || !d_bitmap || !d_sig_xy || (!d_msg && e->msg_len)) return BLSW_ERR_ARG;
-    StepDesc d = {nullptr, d_sig_xy, d_msg, d_witness, witness_stride, d_result, d_pks_xy, d_bitmap, d_count};
+    StepDesc d = {nullptr, d_sig_xy, d_msg, d_witness, witness_stride, d_result, d_pks_xy, d_bitmap, d_count, nullptr};
     return engine_submit(e, d, stream_);
+}
+
+// Compact wire form (the all-gather of full witness vectors is capped by xGMI at a fraction of the generation
+// rate; 2.6 MB per instance travel instead of 34 MB and the receiver expands them).
+int blsw_engine_compact_bytes(blsw_engine_t* e, uint64_t* bytes) {
+    if (!e || !bytes || !e->staged || e->n % 64) return BLSW_ERR_ARG;
+    *bytes = compact_form(e->n, carve(nullptr, e->n, e->L, true, e->modes)).total;
+    return BLSW_OK;
+}
+int blsw_engine_submit_compact(blsw_engine_t* e, const uint64_t* d_pk_xy, const uint64_t* d_sig_xy, const uint8_t* d_msg, void* d_compact, int32_t* d_result,
+                               void* stream_) {
+    if (!e || e->L.n_keys || !e->staged || e->n % 64 || !d_compact || !d_pk_xy || !d_sig_xy || (!d_msg && e->msg_len)) return BLSW_ERR_ARG;
+    StepDesc d = {d_pk_xy, d_sig_xy, d_msg, nullptr, 0, d_result, nullptr, nullptr, nullptr, d_compact};
+    return engine_submit(e, d, stream_);
+}
+// receiver side: one batch in compact form -> its n witness vectors, on `stream` (the expansion and placement kernels of the
+// engine's own steps, pointed at the compact buffer)
+int blsw_engine_expand_compact(blsw_engine_t* e, const void* d_compact, uint64_t* d_witness, uint64_t witness_stride, void* stream_) {
+    if (!e || !e->staged || e->n % 64 || !d_compact || !d_witness || witness_stride < e->L.n_witness) return BLSW_ERR_ARG;
+    DeviceGuard guard(e->device);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream_);
+    const Workspace w = carve(nullptr, e->n, e->L, true, e->modes);
+    const CompactForm cf = compact_form(e->n, w);
+    const char* src = reinterpret_cast<const char*>(d_compact);
+    ExpandArgs xa = {reinterpret_cast<const uint32_t*>(src), w.sha_words, 0, e->L.sha_bits, e->L.off_expand, d_witness, witness_stride, 1u, 0u, 0};
+    launch_expand(e->opt.expand_variant, e->opt.expand_store, e->opt.place_lds, st, xa, (unsigned)e->n);
+    launch_place(e, st, reinterpret_cast<const Fp*>(src + cf.off_staging), reinterpret_cast<const Fp*>(src + cf.off_pair), w.split_row, 0, d_witness, witness_stride);
+    return hip_ok(hipGetLastError(), "expand compact");
 }
 
 // launches whatever is pending and makes `stream` wait for every group issued so far

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define BLSW_ABI_VERSION 5
+#define BLSW_ABI_VERSION 6
 
 #define BLSW_OK 0
 #define BLSW_ERR_ARG 1
@@ -154,6 +154,20 @@ int blsw_engine_submitted(blsw_engine_t* e, uint64_t* seq);
 int blsw_engine_launched(blsw_engine_t* e, uint64_t* seq);
 int blsw_engine_wait_step(blsw_engine_t* e, uint64_t seq, void* stream);
 int blsw_engine_output_consumed(blsw_engine_t* e, const uint64_t* d_witness, void* stream);
+/* Compact wire form of a step, for the multi-GPU all-gather of witness shards: the full vectors are 34 MB per
+ * instance and 94 % of their elements are SHA-256 booleans, so every rank receiving the other ranks' shards over xGMI caps an
+ * 8-GPU job far below the generation rate. In compact form a batch is its bit-packed SHA witnesses plus its field witnesses as
+ * 48-byte elements (2.6 MB per instance: blsw_engine_compact_bytes per batch); that is what travels, and the receiver turns it
+ * into the n witness vectors — bit-exact what blsw_engine_submit writes — with blsw_engine_expand_compact. Engines with
+ * n % 64 == 0 and (max_steps > 1 or n_buffers > 1), single-key circuit.
+ *   blsw_engine_submit_compact: as blsw_engine_submit, the step's output is d_compact (compact_bytes bytes) instead of d_witness;
+ *     blsw_engine_wait_step / _output_consumed (with the d_compact pointer) work as for witness tensors;
+ *   blsw_engine_expand_compact: enqueues on `stream` the expansion of one compact batch (produced by ANY engine of the same
+ *     n, msg_len and options, e.g. another rank's) into d_witness [n][witness_stride]. */
+int blsw_engine_compact_bytes(blsw_engine_t* e, uint64_t* bytes);
+int blsw_engine_submit_compact(blsw_engine_t* e, const uint64_t* d_pk_xy, const uint64_t* d_sig_xy, const uint8_t* d_msg, void* d_compact, int32_t* d_result,
+                               void* stream);
+int blsw_engine_expand_compact(blsw_engine_t* e, const void* d_compact, uint64_t* d_witness, uint64_t witness_stride, void* stream);
 /* average duration (ms) of the bit->Fp expansion kernel launches issued since the previous call (HIP events on the stream they
  * ran on, at most 1024 launches); blocks until they have finished and resets the statistics */
 int blsw_engine_expand_stats(blsw_engine_t* e, uint32_t* count, float* avg_ms);

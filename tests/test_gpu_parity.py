@@ -463,6 +463,53 @@ def test_engine_1024_instances_grouped(pkg, oracle):
     eng.close()
 
 
+def test_engine_compact_form_round_trip(pkg, oracle):
+    """The compact wire form of a step (blsw_engine_submit_compact: bit-packed SHA witnesses + staged field witnesses, what the
+    multi-GPU all-gather ships) expanded on the 'receiver' (blsw_engine_expand_compact, here a SECOND engine) gives bit for bit
+    the witness tensor blsw_engine_submit writes: three steps with distinct inputs (a full group of two and a partial one),
+    compact and plain submits mixed in one group; one instance per step also against the oracle."""
+    import torch
+
+    n, steps = 128, 3
+    workload = importlib.import_module("bls-verify-gadget_amd.workload")
+    dev = torch.device("cuda:0")
+    eng = pkg.WitnessEngine(n, 32, max_steps=2, device=dev, n_buffers=2)
+    recv = pkg.WitnessEngine(n, 32, max_steps=2, device=dev, n_buffers=1)  # the receiving rank's engine
+    assert recv.compact_bytes() == eng.compact_bytes() and eng.compact_bytes() < 0.08 * n * eng.n_witness * 48
+    plain = [eng.new_witness_tensor() for _ in range(steps)]
+    comp = eng.new_compact_buffer(steps)
+    ins, r_plain, r_comp = [], [], []
+    for k in range(steps):
+        pk, msg, sig, expect = workload.make_batch(pkg, n, seed=0x5EED, device=dev, start=1000 + k * n)
+        ins.append((pk, msg, sig, expect))
+        r_plain.append(torch.empty(n, dtype=torch.int32, device=dev))
+        r_comp.append(torch.empty(n, dtype=torch.int32, device=dev))
+    # group 1: [compact 0, plain 0]; group 2: [compact 1, compact 2]; group 3: [plain 1, plain 2]
+    eng.submit_compact(ins[0][0], ins[0][2], ins[0][1], comp[0], result=r_comp[0])
+    eng.submit(ins[0][0], ins[0][2], ins[0][1], witness=plain[0], result=r_plain[0])
+    eng.submit_compact(ins[1][0], ins[1][2], ins[1][1], comp[1], result=r_comp[1])
+    eng.submit_compact(ins[2][0], ins[2][2], ins[2][1], comp[2], result=r_comp[2])
+    eng.submit(ins[1][0], ins[1][2], ins[1][1], witness=plain[1], result=r_plain[1])
+    eng.submit(ins[2][0], ins[2][2], ins[2][1], witness=plain[2], result=r_plain[2])
+    eng.flush()
+    torch.cuda.synchronize()
+    out = recv.new_witness_tensor()
+    for k in range(steps):
+        out.fill_(-1)
+        recv.expand_compact(comp[k], out)
+        torch.cuda.synchronize()
+        assert torch.equal(out, plain[k]), "step %d: expanded compact form differs from the plain witness tensor" % k
+        assert torch.equal(r_comp[k], r_plain[k]) and np.array_equal(r_plain[k].cpu().numpy().astype(bool), ins[k][3])
+        i = (17, 64, 127)[k]
+        pk, msg, sig, _ = ins[k]
+        nw, _, r, ow = oracle.witness(pk[i].cpu().numpy().view(np.uint64), msg[i].cpu().numpy().tobytes(), sig[i].cpu().numpy().view(np.uint64))
+        assert nw == out.shape[1] and np.array_equal(ow, out[i].cpu().numpy().view(np.uint64))
+    with pytest.raises(pkg.BlswError):
+        pkg.WitnessEngine(n, 32, max_steps=1, device=dev, n_buffers=1).compact_bytes()  # direct mode stages nothing
+    eng.close()
+    recv.close()
+
+
 def test_witness_digest_kernel(pkg, oracle):
     """blsw_witness_digest against its host-side definition on real witness vectors (ragged: stride > n_witness)."""
     import torch

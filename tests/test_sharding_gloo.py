@@ -41,8 +41,13 @@ def _worker(rank, world, port, n_total, q):
     seen = []
     buf = torch.empty((world * 2, 4, 6), dtype=torch.int64)
     nmb = sharding.stream_allgather(local, 2, lambda g, c0, rows: seen.append((c0, rows, g[:, 0, 0].tolist())), buffer=buf)
+    # the compact-form gather (bench.py's default all-gather leg): one uint8 batch per rank, expanded rank by rank on the receiver
+    # (stand-in expansion on the CPU: bytes -> int64; the GPU engine's expand_compact plugs in at the same place)
+    comp = torch.arange(40, dtype=torch.uint8) + 100 * rank
+    cseen = []
+    nb = sharding.stream_allgather_compact(comp, lambda c: c.to(torch.int64) * 2, lambda w, r: cseen.append((r, int(w[0]), int(w[-1]), w.numel())))
     if rank == 0:
-        q.put((full.numpy().astype(bool).tolist(), expect.tolist(), gathered[:, 0, 0].tolist(), nmb, seen))
+        q.put((full.numpy().astype(bool).tolist(), expect.tolist(), gathered[:, 0, 0].tolist(), nmb, seen, nb, cseen))
     dist.destroy_process_group()
 
 
@@ -67,11 +72,12 @@ def test_two_rank_gloo_gather():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, n_total, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got, expect, gathered, nmb, seen = q.get(timeout=120)
+    got, expect, gathered, nmb, seen, nb, cseen = q.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     assert got == expect
     assert gathered == [0, 0, 1, 1]
+    assert nb == 2 and cseen == [(0, 0, 78, 40), (1, 200, 278, 40)]
     assert nmb == 3 and [(c0, rows) for c0, rows, _ in seen] == [(0, 2), (2, 2), (4, 1)]
     assert seen[0][2] == [0, 24, 1000, 1024] and seen[2][2] == [96, 1096]
