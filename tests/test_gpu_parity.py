@@ -154,6 +154,21 @@ def test_hash_to_g2_batch(pkg, oracle):
         assert np.array_equal(aff, out[i])
 
 
+def test_hash_to_curve_reference_strings(pkg, oracle):
+    """hasher.rs:1004-1026 (test_hash_to_curve) on the GPU: the reference's five messages — lengths 0, 3, 7, 23 and 251 bytes,
+    i.e. up to five SHA-256 blocks of msg' — through blsw_hash_to_g2_batch, against the frozen oracle outputs."""
+    import torch
+
+    frozen = json.load(open(os.path.join(GOLDEN, "oracle_hash_strings.json")))
+    for s, want in zip(LIT["hash_strings"], frozen["compressed"]):
+        m = np.frombuffer(s.encode("utf-8"), dtype=np.uint8).reshape(1, -1).repeat(3, axis=0).copy()
+        out = pkg.hash_to_g2_batch(torch.from_numpy(m).cuda())
+        torch.cuda.synchronize()
+        out = out.cpu().numpy().view(np.uint64)
+        for i in range(3):
+            assert oracle.g2_compress(out[i]).hex() == want, "message %r" % s[:24]
+
+
 def test_decode_and_verify_bytes_fixtures(pkg, oracle):
     """tests/tests.rs:239-268 end to end on the GPU: all 29 verify/*.json cases from their compressed bytes
     (decode kernel -> gadget), plus the deserialization_G1/G2 accept/reject fixtures through the decode kernel."""

@@ -1,0 +1,23 @@
+#!/bin/bash
+# after `gpurun -- bash tools/prof_round2.sh`: copies the summaries the judge reads from gpurun_out/r02prof into profiles/ (tracked)
+O=gpurun_out/r02prof
+P=profiles
+cp $O/bench_default.json $P/r02_bench_default.json
+cp $O/bench_20_5.json $P/r02_bench_20_5.json
+cp $(ls $O/stats/*kernel_stats.csv $O/stats/*/*kernel_stats.csv 2>/dev/null | head -1) $P/r02_kernel_stats_bench.csv
+grep -v '^{' $O/pmc_hbm.txt > $P/r02_pmc_hbm_traffic.txt; tail -1 $O/pmc_hbm.txt >> $P/r02_pmc_hbm_traffic.txt
+cp $O/pmc_sq.txt $P/r02_pmc_sq.txt
+cp $O/pmc_l2.txt $P/r02_pmc_l2.txt
+cp $O/alone_timeline.txt $P/r02_group_timeline.txt
+cp $O/short_timeline.txt $P/r02_short_job_timeline.txt
+[ -s $O/side_configs.jsonl ] && cp $O/side_configs.jsonl $P/r02_side_configs.jsonl
+[ -s $O/engine_bench_c.json ] && cp $O/engine_bench_c.json $P/r02_engine_bench_c.json
+python3 - <<'PY'
+import json
+line = [l for l in open("gpurun_out/r02prof/pmc_hbm.txt") if l.startswith("{")][-1]
+d = json.loads(line)
+old = json.load(open("profiles/r02_traffic.json"))
+d["_comment"] = old["_comment"]
+json.dump(d, open("profiles/r02_traffic.json", "w"), indent=1)
+print(d["k_sha_expand"])
+PY

@@ -29,7 +29,7 @@ int main(int argc, char** argv) {
     CK(hipStreamCreateWithPriority(&s_hi, hipStreamNonBlocking, hi));
     hipEvent_t evs[64];
     for (auto& e : evs) CK(hipEventCreate(&e));
-    auto run = [&](const char* name, uint32_t variant, hipStream_t st, bool events, bool ring) {
+    auto run = [&](const char* name, uint32_t variant, hipStream_t st, bool events, bool ring, unsigned lds = 0) {
         hipEvent_t a, b;
         CK(hipEventCreate(&a));
         CK(hipEventCreate(&b));
@@ -41,7 +41,7 @@ int main(int argc, char** argv) {
             }
             ExpandArgs xa = {d_bits, sha_words, 0, L.sha_bits, L.off_expand, d_wit[ring ? (i & 1) : 0], L.n_witness, 1u, 0u, 0};
             if (events && i >= 0) CK(hipEventRecord(evs[2 * i], st));
-            launch_expand(variant, 0, 0, st, xa, (unsigned)n);
+            launch_expand(variant, 0, lds, st, xa, (unsigned)n);
             if (events && i >= 0) CK(hipEventRecord(evs[2 * i + 1], st));
         }
         CK(hipEventRecord(b, st));
@@ -87,6 +87,13 @@ int main(int argc, char** argv) {
         run("v1 high-priority stream, events around each launch", 1, s_hi, true, false);
         run("v1 high-priority stream, events, ring of 2 outputs", 1, s_hi, true, true);
         run("v0 high-priority stream, events, ring of 2 outputs", 0, s_hi, true, true);
+        // occupancy limited through dynamic LDS (160 KB per CU): fewer resident workgroups = a smaller window of addresses in flight
+        for (unsigned lds : {16384u, 32768u, 49152u, 65536u})
+            for (uint32_t v : {0u, 2u, 5u}) {
+                char nm[64];
+                snprintf(nm, sizeof nm, "v%u null stream, %u KB LDS per workgroup", v, lds / 1024);
+                run(nm, v, 0, false, false, lds);
+            }
         for (uint32_t v = 2; v <= 5; v++) {
             char nm[64];
             snprintf(nm, sizeof nm, "v%u null stream", v);

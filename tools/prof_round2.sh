@@ -18,6 +18,9 @@ cd $R
 python3 tools/pmc_summary.py $O/pmc_WRITE_SIZE $O/pmc_FETCH_SIZE --json > $O/pmc_hbm.txt
 python3 tools/pmc_summary.py $O/pmc_SQ_WAVE_CYCLES > $O/pmc_sq.txt
 python3 tools/pmc_summary.py $O/pmc_TCP_TCC_WRITE_REQ_sum > $O/pmc_l2.txt
-python3 tools/timeline.py $(ls $O/alone/*/*kernel_trace.csv) > $O/alone_timeline.txt
-python3 tools/timeline.py $(ls $O/short/*/*kernel_trace.csv) > $O/short_timeline.txt
+python3 tools/timeline.py $(ls $O/alone/*kernel_trace.csv $O/alone/*/*kernel_trace.csv 2>/dev/null | head -1) > $O/alone_timeline.txt
+python3 tools/timeline.py $(ls $O/short/*kernel_trace.csv $O/short/*/*kernel_trace.csv 2>/dev/null | head -1) > $O/short_timeline.txt
 echo done
+python3 tools/bench_configs.py > $O/side_configs.jsonl 2> $O/side_configs.err
+make -C tools engine_bench > /dev/null 2>&1 && tools/engine_bench > $O/engine_bench_c.json 2> $O/engine_bench_c.err
+echo all done
