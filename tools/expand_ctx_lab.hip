@@ -87,13 +87,6 @@ int main(int argc, char** argv) {
         run("v1 high-priority stream, events around each launch", 1, s_hi, true, false);
         run("v1 high-priority stream, events, ring of 2 outputs", 1, s_hi, true, true);
         run("v0 high-priority stream, events, ring of 2 outputs", 0, s_hi, true, true);
-        // occupancy limited through dynamic LDS (160 KB per CU): fewer resident workgroups = a smaller window of addresses in flight
-        for (unsigned lds : {16384u, 32768u, 49152u, 65536u})
-            for (uint32_t v : {0u, 2u, 5u}) {
-                char nm[64];
-                snprintf(nm, sizeof nm, "v%u null stream, %u KB LDS per workgroup", v, lds / 1024);
-                run(nm, v, 0, false, false, lds);
-            }
         for (uint32_t v = 2; v <= 5; v++) {
             char nm[64];
             snprintf(nm, sizeof nm, "v%u null stream", v);
