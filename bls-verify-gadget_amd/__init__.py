@@ -28,7 +28,7 @@ class blsw_layout_t(ctypes.Structure):
 
 
 class blsw_engine_options_t(ctypes.Structure):
-    _fields_ = [("device", ctypes.c_int32)] + [(n, ctypes.c_uint32) for n in "n_keys pairing_mode g2_mode expand_variant expand_store prio_mode place_lds".split()]
+    _fields_ = [("device", ctypes.c_int32)] + [(n, ctypes.c_uint32) for n in "n_keys pairing_mode g2_mode expand_variant expand_store prio_mode place_lds consumer_mode".split()]
 
 
 class blsw_matrices_info_t(ctypes.Structure):
@@ -39,8 +39,16 @@ class blsw_matrices_t(ctypes.Structure):
     _fields_ = [("row_ptr", ctypes.POINTER(ctypes.c_uint64) * 3), ("col", ctypes.POINTER(ctypes.c_uint32) * 3), ("val", ctypes.POINTER(ctypes.c_uint64) * 3)]
 
 
+ERR_BUSY = 6
+
+
 class BlswError(RuntimeError):
     pass
+
+
+class BlswBusy(BlswError):
+    """consumer_mode engines: the call would have to wait for outputs the caller still holds — drain (wait_step / output_consumed)
+    and call again (BLSW_ERR_BUSY)."""
 
 
 _lib = None
@@ -74,6 +82,7 @@ def lib():
         L.blsw_engine_options_default.argtypes = [ctypes.POINTER(blsw_engine_options_t)]
         L.blsw_engine_submitted.argtypes = [vp, ctypes.POINTER(u64)]
         L.blsw_engine_launched.argtypes = [vp, ctypes.POINTER(u64)]
+        L.blsw_engine_materialised.argtypes = [vp, ctypes.POINTER(u64)]
         L.blsw_engine_wait_step.argtypes = [vp, u64, vp]
         L.blsw_engine_output_consumed.argtypes = [vp, vp, vp]
         L.blsw_engine_compact_bytes.argtypes = [vp, ctypes.POINTER(u64)]
@@ -102,7 +111,7 @@ def lib():
 
 
 EXPORTED_SYMBOLS = ["blsw_version", "blsw_layout", "blsw_engine_options_default", "blsw_engine_workspace_bytes", "blsw_engine_workspace_bytes_ex", "blsw_engine_create",
-                    "blsw_engine_create_ex", "blsw_engine_destroy", "blsw_engine_submit", "blsw_engine_submit_aggregate", "blsw_engine_flush", "blsw_engine_submitted", "blsw_engine_launched", "blsw_engine_wait_step",
+                    "blsw_engine_create_ex", "blsw_engine_destroy", "blsw_engine_submit", "blsw_engine_submit_aggregate", "blsw_engine_flush", "blsw_engine_submitted", "blsw_engine_launched", "blsw_engine_materialised", "blsw_engine_wait_step",
                     "blsw_engine_output_consumed", "blsw_engine_compact_bytes", "blsw_engine_submit_compact", "blsw_engine_expand_compact", "blsw_engine_expand_stats", "blsw_witness_digest", "blsw_hash_to_g2_workspace_bytes", "blsw_hash_to_g2_batch",
                     "blsw_decode_batch", "blsw_layout_aggregate", "blsw_aggregate_workspace_bytes", "blsw_aggregate_verify_batch", "blsw_layout_multi",
                     "blsw_verify_multi_workspace_bytes", "blsw_verify_multi_batch", "blsw_matrices_info", "blsw_matrices_fill", "blsw_sign_batch", "blsw_microbench"]
@@ -210,7 +219,7 @@ class WitnessEngine:
                                       witness.data_ptr() if witness is not None else None, witness.shape[1] if witness is not None else 0,
                                       result.data_ptr() if result is not None else None, self._stream(stream))
         if rc:
-            raise BlswError("blsw_engine_submit failed: %d" % rc)
+            raise (BlswBusy if rc == ERR_BUSY else BlswError)("blsw_engine_submit failed: %d" % rc)
         self._keep.append((pk_xy, sig_xy, msg, witness, result))
         self._keep = self._keep[-(self.n_buffers + 1) * self.max_steps:]
         return seq
@@ -250,7 +259,7 @@ class WitnessEngine:
         rc = lib().blsw_engine_submit_compact(self._e, pk_xy.data_ptr(), sig_xy.data_ptr(), msg.data_ptr() if self.msg_len else None, compact.data_ptr(),
                                               result.data_ptr() if result is not None else None, self._stream(stream))
         if rc:
-            raise BlswError("blsw_engine_submit_compact failed: %d" % rc)
+            raise (BlswBusy if rc == ERR_BUSY else BlswError)("blsw_engine_submit_compact failed: %d" % rc)
         self._keep.append((pk_xy, sig_xy, msg, compact, result))
         self._keep = self._keep[-(self.n_buffers + 1) * self.max_steps:]
         return seq
@@ -281,11 +290,15 @@ class WitnessEngine:
     def launched(self):
         return self._counter(lib().blsw_engine_launched)
 
+    def materialised(self):
+        """Steps whose output writes have been issued (= launched() unless consumer_mode holds steps back for their outputs)."""
+        return self._counter(lib().blsw_engine_materialised)
+
     def wait_step(self, seq, stream=None):
         """Makes `stream` (default: the current stream) wait for step `seq`'s witness tensor and results (seq < launched())."""
         rc = lib().blsw_engine_wait_step(self._e, seq, self._stream(stream))
         if rc:
-            raise BlswError("blsw_engine_wait_step failed: %d" % rc)
+            raise (BlswBusy if rc == ERR_BUSY else BlswError)("blsw_engine_wait_step failed: %d" % rc)
 
     def output_consumed(self, witness, stream=None):
         """The consumer is done with `witness` once `stream` reaches this point: the next step submitted with the same tensor

@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <deque>
 #include "chains.cuh"
 #include "decode.cuh"
 #include "layout.h"
@@ -922,6 +923,12 @@ struct GroupBuf {
     uint64_t first_seq = 0;
     uint32_t steps = 0;
     bool used = false;
+    Workspace ws;            // of the group launched last from this buffer
+    uint32_t jobs_left = 0;  // its steps whose expansion / placement has not been issued yet
+};
+struct Job {  // materialisation of one step: bit expansion + field placement into its output (or its compact form)
+    int buf;
+    uint32_t s;
 };
 struct blsw_engine {
     uint64_t n = 0;
@@ -934,15 +941,17 @@ struct blsw_engine {
     int nbuf = 0;
     int cur = 0;
     uint32_t pending = 0;
-    uint64_t submitted = 0, launched = 0;
+    uint64_t submitted = 0, launched = 0, materialised = 0;
+    std::deque<Job> jobs;  // steps whose chains are issued, in submission order, waiting for their output to be free (consumer mode)
     hipStream_t sha = nullptr, expand = nullptr, place = nullptr;
     // HIP event pairs around every k_sha_expand launch since the last stats reset (live roofline measurement)
     hipEvent_t* ev_exp = nullptr;  // 2 * BLSW_MAX_TIMED events
     uint32_t n_timed = 0;
     // consumer releases: output tensor pointer -> event after which it may be overwritten
-    const uint64_t* consumed_ptr[BLSW_MAX_CONSUMED];
+    const void* consumed_ptr[BLSW_MAX_CONSUMED];
     hipEvent_t consumed_ev[BLSW_MAX_CONSUMED];
-    bool consumed_live[BLSW_MAX_CONSUMED];
+    bool consumed_live[BLSW_MAX_CONSUMED];  // a release has been recorded and not yet waited for
+    bool held[BLSW_MAX_CONSUMED];           // consumer mode: a step was materialised into this output and it has not been released
     bool staged = false;  // false: direct mode (max_steps == 1, no staging; witnesses written in place by the chains)
 };
 
@@ -988,6 +997,89 @@ static void launch_place(blsw_engine* e, hipStream_t st, const Fp* staging, cons
                        e->L.off_sig_alloc, e->modes.g2_team ? e->L.off_pk_not_zero - e->L.off_sig_alloc : 0u, e->LS.off_sig_alloc);
 }
 
+#ifdef BLSW_DEBUG_KNOBS  // timing experiments only (wrong witnesses): BLSW_DEBUG_SKIP bit 0 chains, bit 1 placement, bit 2 expansion
+static const uint32_t dbg_skip = getenv("BLSW_DEBUG_SKIP") ? (uint32_t)atoi(getenv("BLSW_DEBUG_SKIP")) : 0u;
+#else
+constexpr uint32_t dbg_skip = 0;
+#endif
+
+static int consumed_slot(blsw_engine* e, const void* ptr) {
+    for (int c = 0; c < BLSW_MAX_CONSUMED; c++)
+        if (e->consumed_ptr[c] == ptr && (e->consumed_live[c] || e->held[c])) return c;
+    return -1;
+}
+// a consumer's release of an output (blsw_engine_output_consumed): the stream that is about to overwrite it waits for it
+static void wait_released(blsw_engine* e, hipStream_t stream, const void* ptr) {
+    const int c = consumed_slot(e, ptr);
+    if (c >= 0 && e->consumed_live[c]) {
+        hipStreamWaitEvent(stream, e->consumed_ev[c], 0);
+        e->consumed_live[c] = false;
+    }
+}
+// Issues the expansion (expansion stream: needs the group's SHA bits) and the field placement (placement stream: needs the
+// group's chains) of step s of buffer k. A step is complete after both.
+static void materialise(blsw_engine* e, int k, uint32_t s) {
+    GroupBuf& b = e->buf[k];
+    const StepDesc& d = b.h_desc[s];
+    const Workspace& ws = b.ws;
+    const CompactForm cf = compact_form(e->n, ws);
+    hipStreamWaitEvent(e->expand, b.ev_sha, 0);
+    if (d.compact) {  // the step's bit words leave as they are
+        wait_released(e, e->expand, d.compact);
+        hipMemcpyAsync(d.compact, ws.bits + (uint64_t)s * (e->n / 64) * bits_tile_words(ws.sha_words), cf.bits_bytes, hipMemcpyDeviceToDevice, e->expand);
+    }
+    if (d.out) {
+        wait_released(e, e->expand, d.out);
+        const bool timed = e->n_timed < BLSW_MAX_TIMED;
+        if (timed) hipEventRecord(e->ev_exp[2 * e->n_timed], e->expand);
+        ExpandArgs xa = {ws.bits, ws.sha_words, (uint64_t)s * e->n, e->L.sha_bits, e->L.off_expand, d.out, d.out_stride, 1u, 0u, 0};
+        if (!(dbg_skip & 4)) launch_expand(e->opt.expand_variant, e->opt.expand_store, e->opt.place_lds, e->expand, xa, (unsigned)e->n);
+        if (timed) {
+            hipEventRecord(e->ev_exp[2 * e->n_timed + 1], e->expand);
+            e->n_timed++;
+        }
+    }
+    hipEventRecord(b.ev_x[s], e->expand);
+    hipStreamWaitEvent(e->place, b.ev_chains, 0);
+    hipStreamWaitEvent(e->place, b.ev_x[s], 0);
+    if (d.compact) {  // and so do its staged field witnesses
+        char* dst = reinterpret_cast<char*>(d.compact);
+        hipMemcpyAsync(dst + cf.off_staging, ws.staging + (uint64_t)s * (e->n / 64) * ws.split_row * 64, cf.staging_bytes, hipMemcpyDeviceToDevice, e->place);
+        if (cf.pair_bytes) hipMemcpyAsync(dst + cf.off_pair, ws.pair + (uint64_t)s * e->n * ws.pair_rows, cf.pair_bytes, hipMemcpyDeviceToDevice, e->place);
+    }
+    if (d.out && e->staged && !(dbg_skip & 2)) launch_place(e, e->place, ws.staging, ws.pair, ws.split_row, (uint64_t)s * e->n, d.out, d.out_stride);
+    hipEventRecord(b.ev_step[s], e->place);
+}
+// Materialises queued steps in submission order. Free-running engines (consumer_mode 0) issue every step as soon as its
+// group is launched; in consumer mode a step whose output still holds an unreleased earlier step stops the queue until
+// blsw_engine_output_consumed names that output.
+static int pump(blsw_engine* e) {
+    while (!e->jobs.empty()) {
+        const Job j = e->jobs.front();
+        GroupBuf& b = e->buf[j.buf];
+        const StepDesc& d = b.h_desc[j.s];
+        const void* ptr = d.out ? static_cast<const void*>(d.out) : d.compact;
+        const bool track = e->opt.consumer_mode && e->staged && ptr;
+        if (track) {
+            const int c = consumed_slot(e, ptr);
+            if (c >= 0 && e->held[c]) break;
+        }
+        materialise(e, j.buf, j.s);
+        if (track) {
+            int c = consumed_slot(e, ptr);
+            for (int i = 0; i < BLSW_MAX_CONSUMED && c < 0; i++)
+                if (!e->consumed_live[i] && !e->held[i]) c = i;
+            if (c < 0) return BLSW_ERR_ARG;  // more than BLSW_MAX_CONSUMED outputs in use
+            e->consumed_ptr[c] = ptr;
+            e->held[c] = true;
+        }
+        e->jobs.pop_front();
+        e->materialised++;
+        if (--b.jobs_left == 0) hipEventRecord(b.ev_done, e->place);
+    }
+    return hip_ok(hipGetLastError(), "materialise");
+}
+
 static int launch_group(blsw_engine* e) {
     GroupBuf& b = e->buf[e->cur];
     const uint32_t steps = e->pending;
@@ -1002,11 +1094,6 @@ static int launch_group(blsw_engine* e) {
     g.LS = e->LS;
     g.ws = carve(b.base, g.N, e->L, e->staged, e->modes);
     g.chain_prio = e->opt.prio_mode == 0;
-#ifdef BLSW_DEBUG_KNOBS  // timing experiments only (wrong witnesses): BLSW_DEBUG_SKIP bit 0 chains, bit 1 placement, bit 2 expansion
-    static const uint32_t dbg_skip = getenv("BLSW_DEBUG_SKIP") ? (uint32_t)atoi(getenv("BLSW_DEBUG_SKIP")) : 0u;
-#else
-    constexpr uint32_t dbg_skip = 0;
-#endif
     const unsigned g1 = (unsigned)((g.N + 63) / 64), g2 = (unsigned)((2 * g.N + 63) / 64);
     const unsigned gt = (unsigned)((g.N + BLSW_TEAMS_PER_WAVE - 1) / BLSW_TEAMS_PER_WAVE);
     hipStream_t st = b.st[0];
@@ -1014,20 +1101,10 @@ static int launch_group(blsw_engine* e) {
     for (uint32_t s = 0; s < steps; s++) hipStreamWaitEvent(st, b.ev_in[s], 0);
     bool any_out = false;
     for (uint32_t s = 0; s < steps; s++) any_out = any_out || b.h_desc[s].out != nullptr || b.h_desc[s].compact != nullptr;
-    const CompactForm cf = compact_form(e->n, g.ws);
-    // a consumer's release of an output (blsw_engine_output_consumed): the stream that is about to overwrite it waits for it
-    auto wait_released = [&](hipStream_t stream, const void* ptr) {
-        for (int c = 0; c < BLSW_MAX_CONSUMED; c++)
-            if (e->consumed_live[c] && e->consumed_ptr[c] == ptr) {
-                hipStreamWaitEvent(stream, e->consumed_ev[c], 0);
-                e->consumed_live[c] = false;
-            }
-    };
     // direct mode: the chains themselves write into the output tensors, so they wait for the consumer's release
     if (!e->staged)
         for (uint32_t s = 0; s < steps; s++)
-            for (int c = 0; c < BLSW_MAX_CONSUMED; c++)
-                if (e->consumed_live[c] && e->consumed_ptr[c] == b.h_desc[s].out) hipStreamWaitEvent(st, e->consumed_ev[c], 0);
+            if (b.h_desc[s].out) wait_released(e, st, b.h_desc[s].out);
     hipMemcpyAsync(b.d_desc, b.h_desc, sizeof(StepDesc) * steps, hipMemcpyHostToDevice, st);
     hipEventRecord(b.ev_start, st);
     hipStreamWaitEvent(b.st[1], b.ev_start, 0);
@@ -1059,49 +1136,18 @@ static int launch_group(blsw_engine* e) {
     if (!(dbg_skip & 1)) launch_pairing(g, e->modes, st);
     hipStreamWaitEvent(st, b.ev_sha, 0);
     hipEventRecord(b.ev_chains, st);
-    // expansion of the SHA segments, per step, in submission order: waits for the SHA bits only
-    hipStreamWaitEvent(e->expand, b.ev_sha, 0);
-    for (uint32_t s = 0; s < steps; s++) {
-        const StepDesc& d = b.h_desc[s];
-        if (d.compact) {  // the step's bit words leave as they are
-            wait_released(e->expand, d.compact);
-            hipMemcpyAsync(d.compact, g.ws.bits + (uint64_t)s * (e->n / 64) * bits_tile_words(g.ws.sha_words), cf.bits_bytes, hipMemcpyDeviceToDevice, e->expand);
-        }
-        if (d.out) {
-            wait_released(e->expand, d.out);
-            const bool timed = e->n_timed < BLSW_MAX_TIMED;
-            if (timed) hipEventRecord(e->ev_exp[2 * e->n_timed], e->expand);
-            ExpandArgs xa = {g.ws.bits, g.ws.sha_words, (uint64_t)s * e->n, e->L.sha_bits, e->L.off_expand, d.out, d.out_stride, 1u, 0u, 0};
-            if (!(dbg_skip & 4)) launch_expand(e->opt.expand_variant, e->opt.expand_store, e->opt.place_lds, e->expand, xa, (unsigned)e->n);
-            if (timed) {
-                hipEventRecord(e->ev_exp[2 * e->n_timed + 1], e->expand);
-                e->n_timed++;
-            }
-        }
-        hipEventRecord(b.ev_x[s], e->expand);
-    }
-    // field segments, per step, once the group's chains are done; a step is complete after both kernels
-    hipStreamWaitEvent(e->place, b.ev_chains, 0);
-    for (uint32_t s = 0; s < steps; s++) {
-        const StepDesc& d = b.h_desc[s];
-        hipStreamWaitEvent(e->place, b.ev_x[s], 0);
-        if (d.compact) {  // and so do its staged field witnesses
-            char* dst = reinterpret_cast<char*>(d.compact);
-            hipMemcpyAsync(dst + cf.off_staging, g.ws.staging + (uint64_t)s * (e->n / 64) * g.ws.split_row * 64, cf.staging_bytes, hipMemcpyDeviceToDevice, e->place);
-            if (cf.pair_bytes)
-                hipMemcpyAsync(dst + cf.off_pair, g.ws.pair + (uint64_t)s * e->n * g.ws.pair_rows, cf.pair_bytes, hipMemcpyDeviceToDevice, e->place);
-        }
-        if (d.out && e->staged && !(dbg_skip & 2)) launch_place(e, e->place, g.ws.staging, g.ws.pair, g.ws.split_row, (uint64_t)s * e->n, d.out, d.out_stride);
-        hipEventRecord(b.ev_step[s], e->place);
-    }
-    hipEventRecord(b.ev_done, e->place);
+    // expansion + placement of the group's steps: queued, issued in submission order (at once unless a consumer holds an output)
+    b.ws = g.ws;
+    b.jobs_left = steps;
+    for (uint32_t s = 0; s < steps; s++) e->jobs.push_back({e->cur, s});
     b.used = true;
     b.first_seq = e->launched;
     b.steps = steps;
     e->launched += steps;
     e->pending = 0;
     e->cur = (e->cur + 1) % e->nbuf;
-    return hip_ok(hipGetLastError(), "launch");
+    if (hip_ok(hipGetLastError(), "launch")) return BLSW_ERR_HIP;
+    return pump(e);
 }
 
 static uint32_t env_u32(const char* name, uint32_t dflt) {
@@ -1131,6 +1177,7 @@ int blsw_engine_options_default(blsw_engine_options_t* o) {
     o->expand_store = env_u32("BLSW_EXPAND_NT", 0);  // plain stores: nontemporal ones cost 8-10 % since the chains' stack traffic was cut
     o->prio_mode = env_u32("BLSW_PRIO_MODE", 1);
     o->place_lds = env_u32("BLSW_PLACE_LDS", 0);
+    o->consumer_mode = 0;
     return BLSW_OK;
 }
 
@@ -1205,6 +1252,7 @@ int blsw_engine_create_ex(blsw_engine_t** out, uint64_t n, uint32_t msg_len, uin
         e->consumed_ptr[i] = nullptr;
         e->consumed_ev[i] = nullptr;
         e->consumed_live[i] = false;
+        e->held[i] = false;
     }
     e->nbuf = (int)n_buffers;
     int rc = BLSW_OK;
@@ -1289,7 +1337,9 @@ static int engine_submit(blsw_engine_t* e, const StepDesc& step, void* stream_) 
     DeviceGuard guard(e->device);
     GroupBuf& b = e->buf[e->cur];
     if (e->pending == 0 && b.used) {
-        // the buffer's previous group must have been fully placed before its staging is overwritten
+        // the buffer's previous group must have been fully placed before its staging is overwritten; in consumer mode some of
+        // its steps may still wait for their outputs: the caller has to drain (wait_step / output_consumed) first
+        if (b.jobs_left) return BLSW_ERR_BUSY;
         if (hip_ok(hipEventSynchronize(b.ev_done), "event sync")) return BLSW_ERR_HIP;
         b.used = false;
     }
@@ -1349,8 +1399,9 @@ int blsw_engine_flush(blsw_engine_t* e, void* stream_) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream_);
     int rc = launch_group(e);
     if (rc) return rc;
+    if ((rc = pump(e))) return rc;
     for (int k = 0; k < e->nbuf; k++)
-        if (e->buf[k].used) hipStreamWaitEvent(st, e->buf[k].ev_done, 0);
+        if (e->buf[k].used && e->buf[k].jobs_left == 0) hipStreamWaitEvent(st, e->buf[k].ev_done, 0);
     return hip_ok(hipGetLastError(), "flush");
 }
 
@@ -1364,10 +1415,16 @@ int blsw_engine_launched(blsw_engine_t* e, uint64_t* seq) {
     *seq = e->launched;
     return BLSW_OK;
 }
+int blsw_engine_materialised(blsw_engine_t* e, uint64_t* seq) {
+    if (!e || !seq) return BLSW_ERR_ARG;
+    *seq = e->materialised;
+    return BLSW_OK;
+}
 // Step `seq` must have been issued (seq < launched) and its group buffer not yet recycled (at most n_buffers groups back:
 // older steps completed before their buffer was reused, so there is nothing to wait for).
 int blsw_engine_wait_step(blsw_engine_t* e, uint64_t seq, void* stream_) {
     if (!e || seq >= e->launched) return BLSW_ERR_ARG;
+    if (seq >= e->materialised) return BLSW_ERR_BUSY;  // consumer mode: its output is still held by an earlier step
     DeviceGuard guard(e->device);
     for (int k = 0; k < e->nbuf; k++) {
         GroupBuf& b = e->buf[k];
@@ -1376,19 +1433,19 @@ int blsw_engine_wait_step(blsw_engine_t* e, uint64_t seq, void* stream_) {
     }
     return BLSW_OK;
 }
-int blsw_engine_output_consumed(blsw_engine_t* e, const uint64_t* d_witness, void* stream_) {
-    if (!e || !d_witness) return BLSW_ERR_ARG;
+int blsw_engine_output_consumed(blsw_engine_t* e, const void* d_output, void* stream_) {
+    if (!e || !d_output) return BLSW_ERR_ARG;
     DeviceGuard guard(e->device);
-    int slot = -1;
-    for (int c = 0; c < BLSW_MAX_CONSUMED; c++)
-        if (e->consumed_ptr[c] == d_witness) slot = c;
+    int slot = consumed_slot(e, d_output);
     for (int c = 0; c < BLSW_MAX_CONSUMED && slot < 0; c++)
-        if (!e->consumed_live[c]) slot = c;
-    if (slot < 0) return BLSW_ERR_ARG;  // more than BLSW_MAX_CONSUMED distinct tensors with an outstanding release
+        if (!e->consumed_live[c] && !e->held[c]) slot = c;
+    if (slot < 0) return BLSW_ERR_ARG;  // more than BLSW_MAX_CONSUMED distinct outputs in use
     if (!e->consumed_ev[slot] && hip_ok(hipEventCreateWithFlags(&e->consumed_ev[slot], hipEventDisableTiming), "event create")) return BLSW_ERR_HIP;
-    e->consumed_ptr[slot] = d_witness;
+    if (hip_ok(hipEventRecord(e->consumed_ev[slot], reinterpret_cast<hipStream_t>(stream_)), "event record")) return BLSW_ERR_HIP;
+    e->consumed_ptr[slot] = d_output;
     e->consumed_live[slot] = true;
-    return hip_ok(hipEventRecord(e->consumed_ev[slot], reinterpret_cast<hipStream_t>(stream_)), "event record");
+    e->held[slot] = false;
+    return pump(e);  // consumer mode: steps that waited for this output go out now
 }
 
 // Average duration (ms) of the k_sha_expand launches issued since the last call (HIP events recorded on the stream the

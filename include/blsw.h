@@ -30,6 +30,7 @@ extern "C" {
 #define BLSW_ERR_HIP 3
 #define BLSW_ERR_NO_DEVICE 4
 #define BLSW_ERR_SCRATCH 5 /* the requested mode / n_buffers combination would exhaust the runtime's per-queue scratch */
+#define BLSW_ERR_BUSY 6    /* consumer mode: the call has to wait for outputs the caller still holds (drain and release first) */
 
 /* per-instance input status (mirrors src/bls.rs:434-447 and the deserialization fixtures) */
 #define BLSW_ST_OK 0
@@ -109,6 +110,12 @@ typedef struct {
     uint32_t expand_store; /* stores of the SHA expansion kernel: 0 plain (default), 1 nontemporal, 2 sc1, 3 sc0 sc1 (variant 0) */
     uint32_t prio_mode;    /* stream priorities: 0 chains high, 1 placement high (default), 2 equal */
     uint32_t place_lds;    /* optional occupancy limiter of the expansion kernel: bytes of dynamic LDS per workgroup */
+    uint32_t consumer_mode; /* 0 (default): free running — a step is written into its output as soon as stream order allows, the
+                              caller guarantees that reusing an output is safe; 1: every output (witness tensor or compact buffer)
+                              must be released with blsw_engine_output_consumed before its next use, and a step whose output is
+                              still held is written later, when it is released (outputs can then be a ring much smaller than
+                              the number of steps in flight: the chains run ahead into the staging, the 34 MB vectors exist only
+                              between expansion and consumption) */
 } blsw_engine_options_t;
 /* defaults; the environment variables BLSW_PAIRING=lane, BLSW_G2=team, BLSW_EXPAND_VARIANT, BLSW_EXPAND_NT, BLSW_PRIO_MODE, BLSW_PLACE_LDS override
  * them HERE (read at every call, nothing is cached per process), so A/B runs need no recompilation */
@@ -143,17 +150,25 @@ int blsw_engine_submit(blsw_engine_t* e, const uint64_t* d_pk_xy, const uint64_t
  *   d_witness [n][witness_stride] (stride >= blsw_layout_aggregate().n_witness; may be NULL), d_result [n] int32, d_count [n] uint32 (may be NULL) */
 int blsw_engine_submit_aggregate(blsw_engine_t* e, const uint64_t* d_pks_xy, const uint8_t* d_bitmap, const uint64_t* d_sig_xy, const uint8_t* d_msg,
                                  uint64_t* d_witness, uint64_t witness_stride, int32_t* d_result, uint32_t* d_count, void* stream);
-/* Issues everything pending and makes `stream` wait for all batches submitted so far (asynchronous for the host). */
+/* Issues everything pending and makes `stream` wait for all batches submitted so far (asynchronous for the host). In consumer
+ * mode: for all steps written so far (blsw_engine_materialised); the rest follow as their outputs are released. */
 int blsw_engine_flush(blsw_engine_t* e, void* stream);
 /* Streaming consumers (a prover draining witness tensors through a small ring of output buffers):
- *   blsw_engine_submitted / _launched: number of steps submitted / already issued to the device;
- *   blsw_engine_wait_step: makes `stream` wait until step `seq` (< launched) has written its witness tensor and results;
- *   blsw_engine_output_consumed: records on `stream` that the consumer is done with the tensor at d_witness; the next
- *   step submitted with the same d_witness pointer does not overwrite it before that point. */
+ *   blsw_engine_submitted / _launched / _materialised: number of steps submitted / whose chains are issued to the device /
+ *   whose output writes are issued (equal to launched unless options.consumer_mode holds steps back);
+ *   blsw_engine_wait_step: makes `stream` wait until step `seq` has written its output and results (seq < launched;
+ *   BLSW_ERR_BUSY while seq >= materialised);
+ *   blsw_engine_output_consumed: records on `stream` that the consumer is done with the output at d_output (witness tensor or
+ *   compact buffer); the next step submitted with the same pointer does not overwrite it before that point.
+ * consumer_mode 0: that release must have been recorded before the group containing the next user of the output is launched
+ * (max_steps <= ring). consumer_mode 1: no such rule — steps are written into their outputs in submission order, each as soon
+ * as its output has been released; blsw_engine_submit returns BLSW_ERR_BUSY instead of blocking when the group buffer it needs
+ * still has unwritten steps (drain: wait_step + output_consumed of the materialised steps, then submit again). */
 int blsw_engine_submitted(blsw_engine_t* e, uint64_t* seq);
 int blsw_engine_launched(blsw_engine_t* e, uint64_t* seq);
+int blsw_engine_materialised(blsw_engine_t* e, uint64_t* seq);
 int blsw_engine_wait_step(blsw_engine_t* e, uint64_t seq, void* stream);
-int blsw_engine_output_consumed(blsw_engine_t* e, const uint64_t* d_witness, void* stream);
+int blsw_engine_output_consumed(blsw_engine_t* e, const void* d_output, void* stream);
 /* Compact wire form of a step, for the multi-GPU all-gather of witness shards: the full vectors are 34 MB per
  * instance and 94 % of their elements are SHA-256 booleans, so every rank receiving the other ranks' shards over xGMI caps an
  * 8-GPU job far below the generation rate. In compact form a batch is its bit-packed SHA witnesses plus its field witnesses as

@@ -525,6 +525,72 @@ def test_engine_compact_form_round_trip(pkg, oracle):
     recv.close()
 
 
+def test_engine_consumer_mode_small_ring(pkg, oracle):
+    """options.consumer_mode = 1: ten steps of 64 instances in groups of four through a ring of TWO output tensors (fewer than
+    one group): a step is written into its tensor only after the consumer released the previous user of that tensor, so every
+    step's digests must equal those of a free-running engine that had ten separate tensors. The consumer is the digest
+    kernel on its own stream; submit returning BUSY is answered by draining."""
+    import torch
+
+    n, steps, ring = 64, 10, 2
+    workload = importlib.import_module("bls-verify-gadget_amd.workload")
+    dev = torch.device("cuda:0")
+    ins = [workload.make_batch(pkg, n, seed=0x5EED, device=dev, start=5000 + k * n) for k in range(steps)]
+    # reference: free running, one tensor per step
+    ref = pkg.WitnessEngine(n, 32, max_steps=4, device=dev, n_buffers=2)
+    ref_out = [ref.new_witness_tensor() for _ in range(steps)]
+    ref_res = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(steps)]
+    for k in range(steps):
+        ref.submit(ins[k][0], ins[k][2], ins[k][1], witness=ref_out[k], result=ref_res[k])
+    ref.flush()
+    torch.cuda.synchronize()
+    want = [pkg.witness_digest(t).cpu().numpy().copy() for t in ref_out]
+    ref.close()
+    del ref_out
+    torch.cuda.empty_cache()
+    # consumer mode, ring of two
+    eng = pkg.WitnessEngine(n, 32, max_steps=4, device=dev, n_buffers=2, consumer_mode=1)
+    outs = [eng.new_witness_tensor() for _ in range(ring)]
+    res = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(steps)]
+    got = [torch.empty((n, 2), dtype=torch.int64, device=dev) for _ in range(steps)]
+    consumer = torch.cuda.Stream(device=dev)
+    state = {"next": 0, "busy": 0}
+
+    def drain():
+        while state["next"] < eng.materialised():
+            s = state["next"]
+            eng.wait_step(s, consumer)
+            pkg.witness_digest(outs[s % ring], out=got[s], stream=consumer)
+            eng.output_consumed(outs[s % ring], consumer)
+            state["next"] += 1
+
+    for k in range(steps):
+        while True:
+            try:
+                eng.submit(ins[k][0], ins[k][2], ins[k][1], witness=outs[k % ring], result=res[k])
+                break
+            except pkg.BlswBusy:
+                state["busy"] += 1
+                before = state["next"]
+                drain()
+                assert state["next"] > before, "BUSY with nothing to drain"
+        drain()
+    eng.flush()
+    while state["next"] < steps:
+        before = state["next"]
+        drain()
+        assert state["next"] > before
+    assert eng.materialised() == steps
+    with pytest.raises(pkg.BlswError):
+        eng.wait_step(steps)  # not submitted
+    consumer.synchronize()
+    torch.cuda.synchronize()
+    for k in range(steps):
+        assert np.array_equal(got[k].cpu().numpy(), want[k]), "step %d: digests differ from the free-running engine's" % k
+        assert torch.equal(res[k], ref_res[k]) and np.array_equal(res[k].cpu().numpy().astype(bool), ins[k][3])
+    eng.close()
+
+
 def test_witness_digest_kernel(pkg, oracle):
     """blsw_witness_digest against its host-side definition on real witness vectors (ragged: stride > n_witness)."""
     import torch
