@@ -57,7 +57,7 @@ def parse_args():
     ap.add_argument("--mem-frac", type=float, default=0.68, help="share of the free HBM the engine workspace and the output ring may take")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=256, help="instances of the batch timed on the host (all cores, and one thread)")
-    ap.add_argument("--allgather-steps", type=int, default=8, help="steps of the generation + all-gather leg (0 = skip; runs when a process group exists)")
+    ap.add_argument("--allgather-steps", type=int, default=32, help="steps of the generation + all-gather leg (0 = skip; runs when a process group exists)")
     ap.add_argument("--allgather-chunk", type=int, default=64, help="instances per rank in one all-gathered micro-batch (form full)")
     ap.add_argument("--allgather-form", choices=("compact", "full"), default="compact",
                     help="what travels in the all-gather leg: the compact wire form, expanded by every receiver, or the full witness tensors")
@@ -148,9 +148,10 @@ def allgather_leg(args, pkg, sharding, dist, dev, inputs, lay, world):
     n, ring = args.batch, 2
     steps = min(args.allgather_steps, args.steps)
     d_pk, d_msg, d_sig = inputs
-    # groups of `ring` steps (a step's tensor must be released before its group is launched); enough groups in flight to
-    # cover the chains' latency while the gather drains the tensors
-    eng = pkg.WitnessEngine(n, 32, max_steps=ring, device=dev, n_buffers=max(1, min(8, (steps + ring - 1) // ring)))
+    # consumer mode: groups of chains run ahead into the staging, a step is expanded into its ring tensor when the gather has
+    # released that tensor's previous user
+    group = max(1, min(16, steps // 2))
+    eng = pkg.WitnessEngine(n, 32, max_steps=group, device=dev, n_buffers=max(2, min(3, (steps + group - 1) // group)), consumer_mode=1)
     outs = [eng.new_witness_tensor() for _ in range(ring)]
     results = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(ring)]
     chunk = max(1, min(args.allgather_chunk, n))
@@ -161,7 +162,7 @@ def allgather_leg(args, pkg, sharding, dist, dev, inputs, lay, world):
     state = {"next": 0}
 
     def drain():
-        while state["next"] < eng.launched():
+        while state["next"] < eng.materialised():
             s = state["next"]
             eng.wait_step(s, consumer)
             with torch.cuda.stream(consumer):
@@ -174,16 +175,23 @@ def allgather_leg(args, pkg, sharding, dist, dev, inputs, lay, world):
             state["next"] += 1
 
     def run(k_steps):
+        goal = state["next"] + k_steps
         for k in range(k_steps):
-            eng.submit(d_pk, d_sig, d_msg, witness=outs[k % ring], result=results[k % ring])
+            while True:
+                try:
+                    q = eng.submitted()  # global step number: the consumer indexes the ring with it too
+                    eng.submit(d_pk, d_sig, d_msg, witness=outs[q % ring], result=results[q % ring])
+                    break
+                except pkg.BlswBusy:
+                    drain()
             drain()
         eng.flush()
-        drain()
+        while state["next"] < goal:
+            drain()
         consumer.synchronize()
         torch.cuda.synchronize()
 
-    run(ring)  # warm-up: communicator, buffers
-    state["next"] = eng.launched()
+    run(group)  # warm-up: communicator, buffers
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -194,7 +202,7 @@ def allgather_leg(args, pkg, sharding, dist, dev, inputs, lay, world):
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     eng.close()
-    return float(t.item()), steps, {"form": "full", "micro_batch_instances_per_rank": chunk, "ring": ring,
+    return float(t.item()), steps, {"form": "full", "micro_batch_instances_per_rank": chunk, "ring": ring, "group_steps": group, "consumer_mode": True,
                                     "consumer": "blsw_witness_digest over each gathered micro-batch",
                                     "bytes_received_per_gpu_per_step": (world - 1) * n * lay["n_witness"] * 48}
 
@@ -208,9 +216,9 @@ def allgather_leg_compact(args, pkg, sharding, dist, dev, inputs, lay, world):
 
     n = args.batch
     steps = min(args.allgather_steps, args.steps)
-    group = max(1, min(8, steps))
-    ring = 2 * group  # a compact buffer is released (output_consumed) before the group that reuses it is launched
-    eng = pkg.WitnessEngine(n, 32, max_steps=group, device=dev, n_buffers=max(2, min(3, (steps + group - 1) // group)))
+    group = max(1, min(16, steps // 2))
+    ring = 4  # compact buffers; consumer mode: a step leaves for its buffer when the gather has released the buffer's previous user
+    eng = pkg.WitnessEngine(n, 32, max_steps=group, device=dev, n_buffers=max(2, min(3, (steps + group - 1) // group)), consumer_mode=1)
     cbufs = eng.new_compact_buffer(ring)
     results = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(ring)]
     gathered = torch.empty((world, eng.compact_bytes()), dtype=torch.uint8, device=dev)
@@ -229,7 +237,7 @@ def allgather_leg_compact(args, pkg, sharding, dist, dev, inputs, lay, world):
         acc.add_(pkg.witness_digest(w, out=dig, stream=consumer).sum(dim=0))
 
     def drain():
-        while state["next"] < eng.launched():
+        while state["next"] < eng.materialised():
             s = state["next"]
             eng.wait_step(s, consumer)
             with torch.cuda.stream(consumer):
@@ -238,16 +246,23 @@ def allgather_leg_compact(args, pkg, sharding, dist, dev, inputs, lay, world):
             state["next"] += 1
 
     def run(k_steps):
+        goal = state["next"] + k_steps
         for k in range(k_steps):
-            eng.submit_compact(d_pk, d_sig, d_msg, cbufs[k % ring], result=results[k % ring])
+            while True:
+                try:
+                    q = eng.submitted()  # global step number: the consumer indexes the ring with it too
+                    eng.submit_compact(d_pk, d_sig, d_msg, cbufs[q % ring], result=results[q % ring])
+                    break
+                except pkg.BlswBusy:
+                    drain()
             drain()
         eng.flush()
-        drain()
+        while state["next"] < goal:
+            drain()
         consumer.synchronize()
         torch.cuda.synchronize()
 
     run(group)  # warm-up: communicator, buffers
-    state["next"] = eng.launched()
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -259,7 +274,7 @@ def allgather_leg_compact(args, pkg, sharding, dist, dev, inputs, lay, world):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     cb = eng.compact_bytes()
     eng.close()
-    return float(t.item()), steps, {"form": "compact", "group_steps": group, "ring": ring, "wire_bytes_per_instance": cb / n,
+    return float(t.item()), steps, {"form": "compact", "group_steps": group, "ring": ring, "consumer_mode": True, "wire_bytes_per_instance": cb / n,
                                     "bytes_received_per_gpu_per_step": (world - 1) * cb,
                                     "bytes_expanded_per_gpu_per_step": world * n * lay["n_witness"] * 48,
                                     "consumer": "blsw_witness_digest over every expanded batch (all ranks' batches, on every rank)"}

@@ -8,8 +8,10 @@ of a micro-batch) drains every tensor before the engine may overwrite it:
 
     submit(step k -> ring[k % ring])  ...  engine.wait_step(k, consumer)  ->  digest  ->  engine.output_consumed(ring[k % ring])
 
-The engine fuses `ring` steps per launch group (a step's tensor must have been released before its group is launched) and
-keeps `buffers` groups of chains in flight. `check_sample` compares the digests of a fixed-stride sample with the CPU oracle.
+The engine runs in consumer mode (options.consumer_mode): groups of `group` steps of chains run ahead into the staging, and a
+step is expanded into its ring tensor only once the consumer has released that tensor's previous user — the ring can be much
+smaller than a group (`--group 0` = the old scheme: free-running engine, groups of `ring` steps, so that a step's tensor is
+released before its group is launched). `check_sample` compares the digests of a fixed-stride sample with the CPU oracle.
 
 Standalone: python tools/shard_rehearsal.py [--rank R --world W --shard 8192 --batch 1024] prints one JSON line.
 """
@@ -27,7 +29,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-def run_shard(pkg, n_shard=8192, batch=1024, ring=2, rank=0, world=8, buffers=6, seed=0x5EED, device=None):
+def run_shard(pkg, n_shard=8192, batch=1024, ring=2, rank=0, world=8, buffers=6, seed=0x5EED, device=None, group=None):
     import torch
 
     workload = importlib.import_module("bls-verify-gadget_amd.workload")
@@ -36,7 +38,12 @@ def run_shard(pkg, n_shard=8192, batch=1024, ring=2, rank=0, world=8, buffers=6,
     lo, hi = sharding.shard_range(n_shard * world, rank, world)  # this rank's contiguous block of the global batch
     assert hi - lo == n_shard and n_shard % batch == 0
     steps = n_shard // batch
-    eng = pkg.WitnessEngine(batch, 32, max_steps=ring, device=dev, n_buffers=min(buffers, max(1, steps // ring)))
+    if group is None:
+        group = max(1, min(16, steps // 2))
+    if group:
+        eng = pkg.WitnessEngine(batch, 32, max_steps=group, device=dev, n_buffers=max(2, min(3, (steps + group - 1) // group)), consumer_mode=1)
+    else:
+        eng = pkg.WitnessEngine(batch, 32, max_steps=ring, device=dev, n_buffers=min(buffers, max(1, steps // ring)))
     outs = [eng.new_witness_tensor() for _ in range(ring)]
     digests = torch.zeros((steps, batch, 2), dtype=torch.int64, device=dev)
     results = torch.zeros((steps, batch), dtype=torch.int32, device=dev)
@@ -50,7 +57,7 @@ def run_shard(pkg, n_shard=8192, batch=1024, ring=2, rank=0, world=8, buffers=6,
     state = {"next": 0}
 
     def drain():
-        while state["next"] < eng.launched():
+        while state["next"] < eng.materialised():
             s = state["next"]
             eng.wait_step(s, consumer)
             pkg.witness_digest(outs[s % ring], out=digests[s], stream=consumer)
@@ -60,17 +67,24 @@ def run_shard(pkg, n_shard=8192, batch=1024, ring=2, rank=0, world=8, buffers=6,
     t0 = time.perf_counter()
     for k in range(steps):
         pk, msg, sig = inputs[k]
-        eng.submit(pk, sig, msg, witness=outs[k % ring], result=results[k])
+        while True:
+            try:
+                eng.submit(pk, sig, msg, witness=outs[k % ring], result=results[k])
+                break
+            except pkg.BlswBusy:  # the group buffer still has unwritten steps: their outputs are ours to release
+                drain()
         drain()
     eng.flush()
-    drain()
+    while state["next"] < steps:
+        drain()
     consumer.synchronize()
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     res = results.cpu().numpy().astype(bool)
     expect = np.stack(expects)
     eng.close()
-    return {"rank": rank, "world": world, "first_instance": lo, "n_shard": n_shard, "batch": batch, "ring": ring, "steps": steps, "seconds": dt,
+    return {"rank": rank, "world": world, "first_instance": lo, "n_shard": n_shard, "batch": batch, "ring": ring, "group_steps": group or ring,
+            "consumer_mode": bool(group), "steps": steps, "seconds": dt,
             "instances_per_s": n_shard / dt, "results_ok": bool((res == expect).all()), "digests": digests.cpu().numpy().view(np.uint64).reshape(n_shard, 2),
             "inputs": inputs, "sampled": 0}
 
@@ -109,10 +123,11 @@ def main():
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--ring", type=int, default=2)
     ap.add_argument("--buffers", type=int, default=6)
+    ap.add_argument("--group", type=int, default=None, help="steps per launch group in consumer mode (default min(16, steps / 2); 0 = free-running engine with groups of `ring`)")
     ap.add_argument("--no-check", action="store_true")
     args = ap.parse_args()
     pkg = importlib.import_module("bls-verify-gadget_amd")
-    out = run_shard(pkg, args.shard, args.batch, args.ring, args.rank, args.world, args.buffers)
+    out = run_shard(pkg, args.shard, args.batch, args.ring, args.rank, args.world, args.buffers, group=args.group)
     line = {k: v for k, v in out.items() if k not in ("digests", "inputs")}
     if not args.no_check:
         from tests import oracle_lib  # the CPU restatement: the checker of the sample, nothing else
