@@ -377,7 +377,10 @@ def main():
     ag = None
     if dist and args.allgather_steps > 0:
         leg = allgather_leg_compact if (args.allgather_form == "compact" and n % 64 == 0) else allgather_leg
-        ag = leg(args, pkg, sharding, dist, dev, (d_pk, d_msg, d_sig), lay, world)
+        try:  # the second leg never takes the headline line down with it
+            ag = leg(args, pkg, sharding, dist, dev, (d_pk, d_msg, d_sig), lay, world)
+        except Exception as exc:  # noqa: BLE001 (reported in the JSON line)
+            ag = (None, 0, {"form": args.allgather_form, "error": "%s: %s" % (type(exc).__name__, exc)})
     if dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -435,7 +438,8 @@ def main():
     }
     if ag:
         ag_dt, ag_steps, ag_info = ag
-        out["value_with_allgather"] = n * world * ag_steps / ag_dt
+        if ag_dt:
+            out["value_with_allgather"] = n * world * ag_steps / ag_dt
         out["allgather"] = dict({"steps": ag_steps, "seconds": ag_dt}, **ag_info)
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, d_pk, d_msg, d_sig, n)

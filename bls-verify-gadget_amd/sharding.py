@@ -69,7 +69,10 @@ def stream_allgather_compact(local_compact, expand, consume, group=None, buffer=
     if buffer is None:
         buffer = torch.empty((world, flat.numel()), dtype=flat.dtype, device=flat.device)
     assert buffer.shape == (world, flat.numel()) and buffer.is_contiguous()
-    dist.all_gather_into_tensor(buffer.reshape(-1), flat, group=group)
+    src, dst = flat, buffer.reshape(-1)
+    if flat.dtype.itemsize == 1 and flat.numel() % 8 == 0 and flat.data_ptr() % 8 == 0 and dst.data_ptr() % 8 == 0:
+        src, dst = flat.view(torch.int64), dst.view(torch.int64)  # a batch is > 2^31 bytes: keep the element count small
+    dist.all_gather_into_tensor(dst, src, group=group)
     for r in range(world):
         consume(expand(buffer[r]), r)
     return world
