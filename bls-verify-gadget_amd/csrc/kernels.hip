@@ -907,6 +907,10 @@ struct DeviceGuard {
 //                       low      aux  : prepare(sig), g1_alloc, g2_alloc  (need only pk / sig)   -> ev_aux
 // Field witnesses go to a staging area (coalesced stores). n_buffers group buffers rotate, so the next groups' chains
 // overlap the previous groups' placement.
+// Materialisation (expand + place of a step into its output) is a queue of jobs in submission order (pump): a free-running
+// engine issues a group's jobs when the group is launched; in consumer mode (options.consumer_mode) a job waits until the
+// consumer has released its output's previous user, so the 34 MB vectors exist only between expansion and consumption and
+// the output ring can be smaller than a group. A step can also leave in compact form (its slices of the staging, copied).
 #define BLSW_MAX_BUFFERS 32
 #define BLSW_DEFAULT_EXPAND_VARIANT 0  // 384 x 8: the geometry that stays fast beside every chain build (profiles/r02_ab_fpmul_expand.txt)
 #define BLSW_MAX_TIMED 1024

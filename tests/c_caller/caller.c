@@ -3,6 +3,9 @@
  *
  *   caller layout                               host-only entry points (runs without a GPU): prints one line of key=value pairs
  *   caller verify <pk48 hex> <msg hex> <sig96 hex>   decode -> engine create/submit/flush -> result + witness digest (needs a GPU)
+ *   caller stream <pk48 hex> <msg hex> <sig96 hex>   64 copies of the instance, 5 steps through a consumer-mode engine (groups of 2)
+ *       with ONE witness tensor and ONE compact buffer as the whole output ring: steps alternate plain / compact submits, the
+ *       consumer (digest kernel; expand_compact first for compact steps) releases each output before the next step may use it
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -81,6 +84,72 @@ int main(int argc, char** argv) {
                (unsigned long long)dig[0], (unsigned long long)dig[1], L.n_witness);
         return 0;
     }
-    fprintf(stderr, "usage: caller layout | caller verify <pk48> <msg32> <sig96> (hex)\n");
+    if (argc == 5 && !strcmp(argv[1], "stream")) {
+        enum { N = 64, STEPS = 5 };
+        uint8_t pk[48], msg[32], sig[96], *h_pk = malloc(N * 48), *h_msg = malloc(N * 32), *h_sig = malloc(N * 96);
+        if (unhex(argv[2], pk, 48) || unhex(argv[3], msg, 32) || unhex(argv[4], sig, 96)) return 12;
+        for (int i = 0; i < N; i++) memcpy(h_pk + 48 * i, pk, 48), memcpy(h_msg + 32 * i, msg, 32), memcpy(h_sig + 96 * i, sig, 96);
+        blsw_layout_t L;
+        CHECK(blsw_layout(32, &L));
+        blsw_engine_options_t o;
+        CHECK(blsw_engine_options_default(&o));
+        o.consumer_mode = 1;
+        uint8_t *d_pk, *d_sig, *d_msg;
+        uint64_t *d_pk_xy, *d_sig_xy, *d_wit, *d_scratch, *d_dig;
+        int32_t *d_st, *d_res;
+        void *d_ws, *d_compact;
+        uint64_t ws = 0, cb = 0;
+        CHECK(blsw_engine_workspace_bytes_ex(N, 32, 2, 2, &o, &ws));
+        CHECK(hipMalloc((void**)&d_pk, N * 48) || hipMalloc((void**)&d_sig, N * 96) || hipMalloc((void**)&d_msg, N * 32) || hipMalloc((void**)&d_pk_xy, N * 96) ||
+              hipMalloc((void**)&d_sig_xy, N * 192) || hipMalloc((void**)&d_st, N * 8) || hipMalloc((void**)&d_res, STEPS * N * 4) ||
+              hipMalloc((void**)&d_dig, STEPS * N * 16) || hipMalloc((void**)&d_wit, (size_t)N * L.n_witness * 48) ||
+              hipMalloc((void**)&d_scratch, (size_t)N * L.n_witness * 48) || hipMalloc(&d_ws, ws));
+        CHECK(hipMemcpy(d_pk, h_pk, N * 48, hipMemcpyHostToDevice) || hipMemcpy(d_sig, h_sig, N * 96, hipMemcpyHostToDevice) || hipMemcpy(d_msg, h_msg, N * 32, hipMemcpyHostToDevice));
+        CHECK(blsw_decode_batch(d_pk, d_sig, N, d_pk_xy, d_sig_xy, d_st, NULL));
+        blsw_engine_t* e = NULL;
+        CHECK(blsw_engine_create_ex(&e, N, 32, 2, 2, &o, d_ws, ws));
+        CHECK(blsw_engine_compact_bytes(e, &cb));
+        CHECK(hipMalloc(&d_compact, cb));
+        hipStream_t consumer;
+        CHECK(hipStreamCreateWithFlags(&consumer, hipStreamNonBlocking));
+        uint64_t next = 0, mat = 0;
+        int busy = 0;
+        for (int k = 0; k <= STEPS; k++) { /* k == STEPS: flush and drain the rest */
+            for (;;) {
+                int rc = k == STEPS ? blsw_engine_flush(e, NULL)
+                         : (k & 1) ? blsw_engine_submit_compact(e, d_pk_xy, d_sig_xy, d_msg, d_compact, d_res + k * N, NULL)
+                                   : blsw_engine_submit(e, d_pk_xy, d_sig_xy, d_msg, d_wit, L.n_witness, d_res + k * N, NULL);
+                if (rc != BLSW_OK && rc != BLSW_ERR_BUSY) return 20 + rc;
+                busy += rc == BLSW_ERR_BUSY;
+                /* drain: every materialised step is consumed and its output released (which lets the next user of it go) */
+                for (;;) {
+                    CHECK(blsw_engine_materialised(e, &mat));
+                    if (next >= mat) break;
+                    CHECK(blsw_engine_wait_step(e, next, consumer));
+                    const uint64_t* vec = d_wit;
+                    if (next & 1) {
+                        CHECK(blsw_engine_expand_compact(e, d_compact, d_scratch, L.n_witness, consumer));
+                        vec = d_scratch;
+                    }
+                    CHECK(blsw_witness_digest(vec, L.n_witness, N, L.n_witness, d_dig + next * N * 2, consumer));
+                    CHECK(blsw_engine_output_consumed(e, (next & 1) ? d_compact : (void*)d_wit, consumer));
+                    next++;
+                }
+                if (rc == BLSW_OK) break;
+            }
+        }
+        if (next != STEPS) return 14;
+        CHECK(hipDeviceSynchronize());
+        uint64_t* dig = malloc(STEPS * N * 16);
+        int32_t* res = malloc(STEPS * N * 4);
+        CHECK(hipMemcpy(dig, d_dig, STEPS * N * 16, hipMemcpyDeviceToHost) || hipMemcpy(res, d_res, STEPS * N * 4, hipMemcpyDeviceToHost));
+        int same = 1, ok = 1;
+        for (int i = 0; i < STEPS * N; i++) same &= dig[2 * i] == dig[0] && dig[2 * i + 1] == dig[1], ok &= res[i] == res[0];
+        CHECK(blsw_engine_destroy(e));
+        printf("steps=%d n=%d compact_bytes=%llu all_digests_equal=%d all_results_equal=%d result=%d busy_returns=%d digest0=%llu digest1=%llu\n", STEPS, N,
+               (unsigned long long)cb, same, ok, res[0], busy, (unsigned long long)dig[0], (unsigned long long)dig[1]);
+        return 0;
+    }
+    fprintf(stderr, "usage: caller layout | caller verify <pk48> <msg32> <sig96> | caller stream <pk48> <msg32> <sig96> (hex)\n");
     return 2;
 }

@@ -689,6 +689,11 @@ def test_c_caller_on_the_gpu(pkg, oracle):
     n, _, res, w = oracle.witness(pk, bytes.fromhex(g["messages"][0]), sig)
     assert kv["status_pk"] == kv["status_sig"] == "0" and int(kv["result"]) == int(res) == 1 and int(kv["n_witness"]) == n
     assert [int(kv["digest0"]), int(kv["digest1"])] == pkg.witness_digest_reference(w)
+    # the streaming side of the ABI from C: consumer-mode engine, one witness tensor + one compact buffer as the whole ring
+    out = subprocess.check_output([os.path.join(root, "tests", "c_caller", "caller"), "stream", g["pubkey"], g["messages"][0], g["signature"]], text=True, timeout=300)
+    kv = dict(p.split("=") for p in out.split())
+    assert kv["steps"] == "5" and kv["all_digests_equal"] == "1" and kv["all_results_equal"] == "1" and kv["result"] == "1"
+    assert [int(kv["digest0"]), int(kv["digest1"])] == pkg.witness_digest_reference(w)
 
 
 def test_gpu_witness_satisfies_product_matrices(pkg, oracle):
