@@ -393,9 +393,10 @@ def main():
     opc = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_opcount.json")))
     # HBM bytes per k_sha_expand launch from the PMC passes committed under profiles/ (rocprofv3 --pmc cannot be combined
     # with the timed run); only quoted for the workload it was collected on
-    traffic, traffic_source = None, None
+    traffic, traffic_source, whole_step = None, None, None
     for name in TRAFFIC_FILES:
         try:
+            whole_step = whole_step or json.load(open(os.path.join(ROOT, "profiles", name))).get("whole_step")
             tr = json.load(open(os.path.join(ROOT, "profiles", name)))["k_sha_expand"]
             if tr["instances_per_launch"] == n and lay["msg_len"] == 32:
                 traffic = (tr["write_kib"] + tr["fetch_kib"]) * 1024.0
@@ -436,6 +437,12 @@ def main():
         "roofline_valu_executed": {"bound": "valu-fp-mul", "executed_fpmul_per_instance": executed_fpmul, "achieved_fpmul_per_s": value / world * executed_fpmul,
                                    "measured_peak_fpmul_per_s": fpmul_peak, "frac": value / world * executed_fpmul / fpmul_peak},
     }
+    if whole_step and whole_step["instances_per_step"] == n and lay["msg_len"] == 32:
+        # every byte the HBM moves per step (PMC, all kernels) over the measured step time: what the memory system delivers to
+        # the path as a whole — the expansion's own figure above is lower because the other kernels' traffic runs beside it
+        tot = whole_step["write_bytes"] + whole_step["fetch_bytes"]
+        out["roofline_hbm_total"] = {"bound": "hbm", "traffic_per_step": tot, "achieved": tot / (dt / args.steps) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                     "frac": tot / (dt / args.steps) / 1e9 / HBM_PEAK_GBPS, "source": "profiles/r02_traffic.json whole_step (rocprofv3 --pmc passes)"}
     if ag:
         ag_dt, ag_steps, ag_info = ag
         if ag_dt:

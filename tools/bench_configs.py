@@ -71,6 +71,28 @@ def main():
     print(json.dumps({"workload": "decode pk48 + sig96 incl. subgroup checks (bls.rs:219-242, 316-339)", "instances": sk.shape[0], "seconds": dt,
                       "value": sk.shape[0] / dt, "unit": "instances/s"}))
 
+    # the single-key path with the steps leaving in compact wire form (bit-packed SHA witnesses + field witnesses, 2.6 MB per
+    # instance; what a sharded job ships): generation without the 34 MB-per-instance expansion
+    nb = 1024
+    cpk, cmsg, csig, cexp = workload.make_batch(pkg, nb, seed=0x5EED, device=dev)
+    eng = pkg.WitnessEngine(nb, 32, max_steps=16, device=dev, n_buffers=3)
+    cbufs = eng.new_compact_buffer(4)
+    cres = [torch.empty(nb, dtype=torch.int32, device=dev) for _ in range(4)]
+
+    def run_compact(k_steps):
+        for k in range(k_steps):
+            eng.submit_compact(cpk, csig, cmsg, cbufs[k % 4], result=cres[k % 4])
+        eng.flush()
+
+    run_compact(48)
+    dt, _ = timed(lambda: run_compact(192))
+    print(json.dumps({"workload": "configs[1] instances leaving in compact wire form (no expansion; groups of 16, 3 in flight, ring of 4 compact buffers, free running)",
+                      "instances": nb * 192, "seconds": dt, "value": nb * 192 / dt, "unit": "instances/s", "compact_bytes_per_instance": eng.compact_bytes() / nb,
+                      "results_ok": bool(np.array_equal(cres[0].cpu().numpy().astype(bool), cexp))}))
+    eng.close()
+    del eng, cbufs
+    torch.cuda.empty_cache()
+
     # config 4 (reference-defined variant): same-message aggregate_verify, K keys, all-ones bitmap
     n, K = args.agg_n, args.agg_keys
     sks = workload.secret_keys(0x5EED, K)

@@ -18,6 +18,18 @@ line = [l for l in open("gpurun_out/r02prof/pmc_hbm.txt") if l.startswith("{")][
 d = json.loads(line)
 old = json.load(open("profiles/r02_traffic.json"))
 d["_comment"] = old["_comment"]
+import re
+rows = []
+for l in open("profiles/r02_pmc_hbm_traffic.txt"):
+    m = re.match(r"(\w+)\s+(\S.*?)\s+launches\s+(\d+)\s+per-launch\s+(\S+)", l)
+    if m:
+        rows.append((m.group(1), m.group(2).strip(), int(m.group(3)), float(m.group(4))))
+steps = [r for r in rows if r[0] == "WRITE_SIZE" and r[1].startswith("k_sha_expand")][0][2]
+prod = lambda name: name.startswith("k_") and not name.startswith("k_bench") and not name.startswith("k_sign")
+w = sum(r[2] * r[3] for r in rows if r[0] == "WRITE_SIZE" and prod(r[1])) * 1024 / steps
+f = sum(r[2] * r[3] for r in rows if r[0] == "FETCH_SIZE" and prod(r[1])) * 1024 / steps
+d["whole_step"] = {"instances_per_step": 1024, "steps_profiled": steps, "write_bytes": w, "fetch_bytes_raw_counter": f, "fetch_bytes": 2 * f,
+                   "comment": "all product kernels of the profiled run (chains, SHA bits, expansion, placement), per 1024-instance step: sum over kernels of per-launch bytes x launches / steps; FETCH_SIZE doubled as for k_sha_expand"}
 json.dump(d, open("profiles/r02_traffic.json", "w"), indent=1)
 print(d["k_sha_expand"])
 PY
