@@ -28,7 +28,7 @@ class blsw_layout_t(ctypes.Structure):
 
 
 class blsw_engine_options_t(ctypes.Structure):
-    _fields_ = [("device", ctypes.c_int32)] + [(n, ctypes.c_uint32) for n in "n_keys pairing_mode g2_mode expand_variant expand_store prio_mode place_lds consumer_mode".split()]
+    _fields_ = [("device", ctypes.c_int32)] + [(n, ctypes.c_uint32) for n in "n_keys pairing_mode g2_mode expand_variant expand_store prio_mode place_lds consumer_mode output_form".split()]
 
 
 class blsw_matrices_info_t(ctypes.Structure):

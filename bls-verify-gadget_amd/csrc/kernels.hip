@@ -246,6 +246,7 @@ struct ExpandArgs {
     uint64_t stride;
     uint32_t K, stride_hash;  // K = 1 for the single-key circuit
     int prio;                 // raise the wave priority (s_setprio 3): wins VALU issue arbitration against the chain waves
+    int canonical;            // elements as canonical integers (true = 1) instead of Montgomery form (true = R mod p)
 };
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 template <int NT>
@@ -265,7 +266,8 @@ __device__ __forceinline__ void expand_store(uint4* dst, const uint4& v) {
         *dst = v;
     }
 }
-__device__ __forceinline__ uint4 expand_column(uint32_t c) {
+__device__ __forceinline__ uint4 expand_column(uint32_t c, int canonical) {
+    if (canonical) return make_uint4(c == 0 ? 1u : 0u, 0u, 0u, 0u);
     constexpr uint32_t R1[12] = BLSW_R1_LIMBS;
     uint4 rc;
     rc.x = c == 0 ? R1[0] : (c == 1 ? R1[4] : R1[8]);
@@ -291,11 +293,11 @@ __device__ __forceinline__ uint32_t expand_word(const uint32_t* b, uint32_t w) {
 }
 // pieces [0, P0) in front of the first boundary: written by workgroup 0 of every variant
 template <int NT>
-__device__ __forceinline__ void expand_head(uint4* out, const uint32_t* b, uint32_t P0, uint32_t n_pieces) {
+__device__ __forceinline__ void expand_head(uint4* out, const uint32_t* b, uint32_t P0, uint32_t n_pieces, int canonical) {
     if (blockIdx.x == 0 && threadIdx.x < P0 && threadIdx.x < n_pieces) {
         const uint32_t e = threadIdx.x / 3, c = threadIdx.x - 3 * e;
         const uint32_t m = 0u - ((expand_word(b, e >> 5) >> (e & 31)) & 1u);
-        const uint4 rc = expand_column(c);
+        const uint4 rc = expand_column(c, canonical);
         expand_store<NT>(&out[threadIdx.x], make_uint4(rc.x & m, rc.y & m, rc.z & m, rc.w & m));
     }
 }
@@ -309,10 +311,10 @@ __global__ __launch_bounds__(THREADS) void k_sha_expand(ExpandArgs a) {
     expand_locate(a, out, b);
     const uint32_t n_pieces = a.sha_bits * 3;
     const uint32_t P0 = (ALIGN_PIECES - (uint32_t)((reinterpret_cast<uintptr_t>(out) >> 4) % ALIGN_PIECES)) % ALIGN_PIECES;
-    expand_head<NT>(out, b, P0, n_pieces);
+    expand_head<NT>(out, b, P0, n_pieces, a.canonical);
     const uint32_t pt = P0 + threadIdx.x, c = pt % 3;
     const uint32_t e0 = blockIdx.x * ((THREADS / 3) * ITERS) + pt / 3;
-    const uint4 rc = expand_column(c);
+    const uint4 rc = expand_column(c, a.canonical);
     // THREADS / 3 is a multiple of 32: the bit position of a thread is a loop invariant too, its word advances by THREADS / 96
     static_assert((THREADS / 3) % 32 == 0, "bit position must be loop invariant");
     const uint32_t sh = e0 & 31, w0 = e0 >> 5;
@@ -348,12 +350,12 @@ __global__ __launch_bounds__(256) void k_sha_expand_chunk(ExpandArgs a) {
     expand_locate(a, out, b);
     const uint32_t n_pieces = a.sha_bits * 3;
     const uint32_t P0 = (256 - (uint32_t)((reinterpret_cast<uintptr_t>(out) >> 4) % 256)) % 256;
-    expand_head<NT>(out, b, P0, n_pieces);
+    expand_head<NT>(out, b, P0, n_pieces, a.canonical);
     const uint32_t p = P0 + blockIdx.x * 256 + threadIdx.x;
     if (p >= n_pieces) return;
     const uint32_t e = p / 3, c = p - 3 * e;
     const uint32_t m = 0u - ((expand_word(b, e >> 5) >> (e & 31)) & 1u);
-    const uint4 rc = expand_column(c);
+    const uint4 rc = expand_column(c, a.canonical);
     expand_store<NT>(&out[p], make_uint4(rc.x & m, rc.y & m, rc.z & m, rc.w & m));
 }
 // variant: low byte 0..3 = geometry, bit 8 = raised wave priority; store: 0 plain, 1 nontemporal, 2 sc1, 3 sc0 sc1 (variant 0 only)
@@ -991,6 +993,14 @@ static void engine_free(blsw_engine* e) {
     delete e;
 }
 
+// options.output_form = 1: the field witnesses of a step, in place, from Montgomery form to canonical integers (what
+// CanonicalSerialize writes for an Fq: 48 bytes little-endian); the SHA segment is written in that form by the expansion itself
+__global__ __launch_bounds__(256) void k_canonical_rows(uint64_t* __restrict__ d_witness, uint64_t stride, uint32_t off_expand, uint32_t sha_bits, uint32_t rows) {
+    const uint32_t idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows) return;
+    Fp* p = reinterpret_cast<Fp*>(d_witness + ((uint64_t)blockIdx.y * stride + (idx < off_expand ? idx : idx + sha_bits)) * 6);
+    st_fp(p, fp_to_canonical(ld_fp(p)));
+}
 // field witnesses of one step: staged rows (lanes first .. first + n of the tiles at `staging` / the rows at `pair`) -> their
 // places around the SHA segment of the step's witness vectors
 static void launch_place(blsw_engine* e, hipStream_t st, const Fp* staging, const Fp* pair, uint32_t split_row, uint64_t first, uint64_t* out, uint64_t out_stride) {
@@ -999,6 +1009,10 @@ static void launch_place(blsw_engine* e, hipStream_t st, const Fp* staging, cons
     dim3 grid2(8 * ((chunks + 7) / 8) * (unsigned)e->n);
     hipLaunchKernelGGL(k_place_field, grid2, dim3(256), 0, st, staging, pair, first, e->L.off_expand, e->L.sha_bits, rows, split_row, out, out_stride, (uint32_t)e->n,
                        e->L.off_sig_alloc, e->modes.g2_team ? e->L.off_pk_not_zero - e->L.off_sig_alloc : 0u, e->LS.off_sig_alloc);
+}
+static void launch_canonical(blsw_engine* e, hipStream_t st, uint64_t* out, uint64_t out_stride) {
+    const uint32_t rows = e->L.n_witness - e->L.sha_bits;
+    hipLaunchKernelGGL(k_canonical_rows, dim3((rows + 255) / 256, (unsigned)e->n), dim3(256), 0, st, out, out_stride, e->L.off_expand, e->L.sha_bits, rows);
 }
 
 #ifdef BLSW_DEBUG_KNOBS  // timing experiments only (wrong witnesses): BLSW_DEBUG_SKIP bit 0 chains, bit 1 placement, bit 2 expansion
@@ -1036,7 +1050,7 @@ static void materialise(blsw_engine* e, int k, uint32_t s) {
         wait_released(e, e->expand, d.out);
         const bool timed = e->n_timed < BLSW_MAX_TIMED;
         if (timed) hipEventRecord(e->ev_exp[2 * e->n_timed], e->expand);
-        ExpandArgs xa = {ws.bits, ws.sha_words, (uint64_t)s * e->n, e->L.sha_bits, e->L.off_expand, d.out, d.out_stride, 1u, 0u, 0};
+        ExpandArgs xa = {ws.bits, ws.sha_words, (uint64_t)s * e->n, e->L.sha_bits, e->L.off_expand, d.out, d.out_stride, 1u, 0u, 0, (int)e->opt.output_form};
         if (!(dbg_skip & 4)) launch_expand(e->opt.expand_variant, e->opt.expand_store, e->opt.place_lds, e->expand, xa, (unsigned)e->n);
         if (timed) {
             hipEventRecord(e->ev_exp[2 * e->n_timed + 1], e->expand);
@@ -1052,6 +1066,7 @@ static void materialise(blsw_engine* e, int k, uint32_t s) {
         if (cf.pair_bytes) hipMemcpyAsync(dst + cf.off_pair, ws.pair + (uint64_t)s * e->n * ws.pair_rows, cf.pair_bytes, hipMemcpyDeviceToDevice, e->place);
     }
     if (d.out && e->staged && !(dbg_skip & 2)) launch_place(e, e->place, ws.staging, ws.pair, ws.split_row, (uint64_t)s * e->n, d.out, d.out_stride);
+    if (d.out && e->opt.output_form) launch_canonical(e, e->place, d.out, d.out_stride);  // direct mode: the chains wrote the rows in place
     hipEventRecord(b.ev_step[s], e->place);
 }
 // Materialises queued steps in submission order. Free-running engines (consumer_mode 0) issue every step as soon as its
@@ -1182,6 +1197,7 @@ int blsw_engine_options_default(blsw_engine_options_t* o) {
     o->prio_mode = env_u32("BLSW_PRIO_MODE", 1);
     o->place_lds = env_u32("BLSW_PLACE_LDS", 0);
     o->consumer_mode = 0;
+    o->output_form = 0;
     return BLSW_OK;
 }
 
@@ -1212,7 +1228,7 @@ int blsw_engine_create_ex(blsw_engine_t** out, uint64_t n, uint32_t msg_len, uin
     if (!out || n == 0 || n > 0x7fffffffu || max_steps == 0 || !d_workspace || n_buffers == 0 || n_buffers > BLSW_MAX_BUFFERS || !options || msg_len > 65535)
         return BLSW_ERR_ARG;
     if (options->pairing_mode > 1 || options->g2_mode > 1 || (options->g2_mode == 1 && options->pairing_mode != 0) || options->expand_store > 3 ||
-        options->prio_mode > 2 || (options->expand_variant & 0xff) > 5 || (options->expand_variant >> 9) || options->n_keys > 65535 ||
+        options->prio_mode > 2 || options->output_form > 1 || (options->expand_variant & 0xff) > 5 || (options->expand_variant >> 9) || options->n_keys > 65535 ||
         (options->n_keys && options->g2_mode))
         return BLSW_ERR_ARG;
     *out = nullptr;
@@ -1390,9 +1406,10 @@ int blsw_engine_expand_compact(blsw_engine_t* e, const void* d_compact, uint64_t
     const Workspace w = carve(nullptr, e->n, e->L, true, e->modes);
     const CompactForm cf = compact_form(e->n, w);
     const char* src = reinterpret_cast<const char*>(d_compact);
-    ExpandArgs xa = {reinterpret_cast<const uint32_t*>(src), w.sha_words, 0, e->L.sha_bits, e->L.off_expand, d_witness, witness_stride, 1u, 0u, 0};
+    ExpandArgs xa = {reinterpret_cast<const uint32_t*>(src), w.sha_words, 0, e->L.sha_bits, e->L.off_expand, d_witness, witness_stride, 1u, 0u, 0, (int)e->opt.output_form};
     launch_expand(e->opt.expand_variant, e->opt.expand_store, e->opt.place_lds, st, xa, (unsigned)e->n);
     launch_place(e, st, reinterpret_cast<const Fp*>(src + cf.off_staging), reinterpret_cast<const Fp*>(src + cf.off_pair), w.split_row, 0, d_witness, witness_stride);
+    if (e->opt.output_form) launch_canonical(e, st, d_witness, witness_stride);
     return hip_ok(hipGetLastError(), "expand compact");
 }
 

@@ -116,6 +116,11 @@ typedef struct {
                               still held is written later, when it is released (outputs can then be a ring much smaller than
                               the number of steps in flight: the chains run ahead into the staging, the 34 MB vectors exist only
                               between expansion and consumption) */
+    uint32_t output_form;  /* witness elements in the output tensors: 0 (default) Montgomery form, 6 little-endian u64 limbs of
+                              a * 2^384 mod p — reinterpretable as arkworks' in-memory Fq; 1: canonical integers, 48 bytes
+                              little-endian — what CanonicalSerialize writes for an Fq (a prover in another process, a file).
+                              The compact wire form is the same for both; blsw_engine_expand_compact follows the expanding
+                              engine's option */
 } blsw_engine_options_t;
 /* defaults; the environment variables BLSW_PAIRING=lane, BLSW_G2=team, BLSW_EXPAND_VARIANT, BLSW_EXPAND_NT, BLSW_PRIO_MODE, BLSW_PLACE_LDS override
  * them HERE (read at every call, nothing is cached per process), so A/B runs need no recompilation */
