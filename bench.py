@@ -448,7 +448,7 @@ def main():
         if ag_dt:
             out["value_with_allgather"] = n * world * ag_steps / ag_dt
         out["allgather"] = dict({"steps": ag_steps, "seconds": ag_dt}, **ag_info)
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only: the other ranks of a multi-GPU run would wait ~15 s in the final barrier
         out["cpu_baseline"] = cpu_baseline(args, d_pk, d_msg, d_sig, n)
     print(json.dumps(out))
 
