@@ -1642,9 +1642,37 @@ int blsw_verify_multi_batch(const uint64_t* d_pks_xy, const uint8_t* d_msgs, uin
     StepDesc h = {d_pks_xy, d_sig_xy, d_msgs, d_witness, witness_stride, d_result, nullptr, nullptr, nullptr};
     if (int rc = put_desc(d_desc, h, st)) return rc;
     const unsigned p1 = (unsigned)((NP + 63) / 64), p2 = (unsigned)((2 * NP + 63) / 64), s1 = (unsigned)((n + 63) / 64);
-    hipLaunchKernelGGL(k_g1, dim3(p1), dim3(64), 0, st, gp);
-    hipLaunchKernelGGL(k_g2_alloc, dim3(s1), dim3(64), 0, st, gs);
-    hipLaunchKernelGGL(k_prepare, dim3(s1), dim3(64), 0, st, gs, 1);
+    // fork: the signature's allocation + prepare (one lane per instance: 57 ms of latency) and the keys' allocation run beside the
+    // hash-to-G2 chains of the pairs; join in front of the Miller product. The two side streams and three events are created once
+    // per host thread and device and kept (an event is re-recorded per call; a wait refers to the record that preceded it).
+    struct Side {
+        int device = -1;
+        hipStream_t aux[2] = {nullptr, nullptr};
+        hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+        bool ok = false;
+    };
+    static thread_local Side sides[16];
+    int dev = 0;
+    hipGetDevice(&dev);
+    Side& sd = sides[dev & 15];
+    if (sd.device != dev) {
+        sd.device = dev;
+        sd.ok = hipStreamCreateWithFlags(&sd.aux[0], hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&sd.aux[1], hipStreamNonBlocking) == hipSuccess &&
+                hipEventCreateWithFlags(&sd.ev_fork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&sd.ev_join[0], hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&sd.ev_join[1], hipEventDisableTiming) == hipSuccess;
+    }
+    const bool forked = sd.ok;
+    hipEvent_t ev_fork = sd.ev_fork;
+    hipEvent_t* ev_join = sd.ev_join;
+    hipStream_t s_sig = forked ? sd.aux[0] : st, s_keys = forked ? sd.aux[1] : st;
+    if (forked) {
+        hipEventRecord(ev_fork, st);  // the descriptor copy
+        hipStreamWaitEvent(s_sig, ev_fork, 0);
+        hipStreamWaitEvent(s_keys, ev_fork, 0);
+    }
+    hipLaunchKernelGGL(k_g2_alloc, dim3(s1), dim3(64), 0, s_sig, gs);
+    hipLaunchKernelGGL(k_prepare, dim3(s1), dim3(64), 0, s_sig, gs, 1);
+    hipLaunchKernelGGL(k_g1, dim3(p1), dim3(64), 0, s_keys, gp);
     hipLaunchKernelGGL(k_sha, dim3(p1), dim3(64), 0, st, gp, d_witness ? 1 : 0, 1);
     if (d_witness) {
         // blockIdx.y = flat (instance, pair); grid.y <= 65535: several launches for larger batches
@@ -1658,6 +1686,12 @@ int blsw_verify_multi_batch(const uint64_t* d_pks_xy, const uint8_t* d_msgs, uin
     hipLaunchKernelGGL(k_map, dim3(p2), dim3(64), 0, st, gp);
     hipLaunchKernelGGL(k_cofactor, dim3(p1), dim3(64), 0, st, gp);
     hipLaunchKernelGGL(k_prepare, dim3(p1), dim3(64), 0, st, gp, 0);
+    if (forked) {
+        hipEventRecord(ev_join[0], s_sig);
+        hipEventRecord(ev_join[1], s_keys);
+        hipStreamWaitEvent(st, ev_join[0], 0);
+        hipStreamWaitEvent(st, ev_join[1], 0);
+    }
     hipLaunchKernelGGL(k_pairing_team_multi, dim3((unsigned)((n + BLSW_TEAMS_PER_WAVE - 1) / BLSW_TEAMS_PER_WAVE)), dim3(64), 0, st, gs, n_pairs, NP);
     return hip_ok(hipGetLastError(), "launch");
 }
