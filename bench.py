@@ -51,7 +51,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=1024)
     ap.add_argument("--warmup", type=int, default=48)
     ap.add_argument("--batch", type=int, default=1024, help="instances per GPU per step (configs[1]: 1024)")
-    ap.add_argument("--coalesce", type=int, default=16, help="max submitted batches fused into one launch group")
+    ap.add_argument("--coalesce", type=int, default=10, help="max submitted batches fused into one launch group")
     ap.add_argument("--buffers", type=int, default=3, help="launch groups in flight (each owns streams + a workspace slice)")
     ap.add_argument("--outputs", type=int, default=2, help="ring of output witness tensors (34 MB x batch each)")
     ap.add_argument("--mem-frac", type=float, default=0.68, help="share of the free HBM the engine workspace and the output ring may take")
@@ -150,7 +150,7 @@ def allgather_leg(args, pkg, sharding, dist, dev, inputs, lay, world):
     d_pk, d_msg, d_sig = inputs
     # consumer mode: groups of chains run ahead into the staging, a step is expanded into its ring tensor when the gather has
     # released that tensor's previous user
-    group = max(1, min(16, steps // 2))
+    group = max(1, min(10, steps // 2))
     eng = pkg.WitnessEngine(n, 32, max_steps=group, device=dev, n_buffers=max(2, min(3, (steps + group - 1) // group)), consumer_mode=1)
     outs = [eng.new_witness_tensor() for _ in range(ring)]
     results = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(ring)]
@@ -216,7 +216,7 @@ def allgather_leg_compact(args, pkg, sharding, dist, dev, inputs, lay, world):
 
     n = args.batch
     steps = min(args.allgather_steps, args.steps)
-    group = max(1, min(16, steps // 2))
+    group = max(1, min(10, steps // 2))
     ring = 4  # compact buffers; consumer mode: a step leaves for its buffer when the gather has released the buffer's previous user
     eng = pkg.WitnessEngine(n, 32, max_steps=group, device=dev, n_buffers=max(2, min(3, (steps + group - 1) // group)), consumer_mode=1)
     cbufs = eng.new_compact_buffer(ring)

@@ -1,7 +1,7 @@
 /* Torch-free benchmark of the grouped engine through the C ABI (include/blsw.h): the same loop as bench.py — K steps of n
  * instances into a ring of output tensors — from a plain C program with hipMalloc'ed buffers. Prints one JSON line.
  *
- *   make -C tools engine_bench && tools/engine_bench [steps 96] [warmup 32] [n 1024] [coalesce 16] [buffers 3] [outputs 2]
+ *   make -C tools engine_bench && tools/engine_bench [steps 96] [warmup 32] [n 1024] [coalesce 10] [buffers 3] [outputs 2]
  *
  * Inputs: n distinct (sk, msg) pairs signed on the GPU by blsw_sign_batch, every 16th message tampered after signing. */
 #include <stdio.h>
@@ -29,7 +29,7 @@ static double now_s(void) {
 int main(int argc, char** argv) {
     const unsigned steps = argc > 1 ? atoi(argv[1]) : 96, warmup = argc > 2 ? atoi(argv[2]) : 32;
     const uint64_t n = argc > 3 ? strtoull(argv[3], NULL, 10) : 1024;
-    const unsigned coalesce = argc > 4 ? atoi(argv[4]) : 16, buffers = argc > 5 ? atoi(argv[5]) : 3, n_out = argc > 6 ? atoi(argv[6]) : 2;
+    const unsigned coalesce = argc > 4 ? atoi(argv[4]) : 10, buffers = argc > 5 ? atoi(argv[5]) : 3, n_out = argc > 6 ? atoi(argv[6]) : 2;
     blsw_layout_t L;
     CHECK(blsw_layout(32, &L));
     /* inputs */
