@@ -88,6 +88,7 @@ def lib():
         L.blsw_engine_compact_bytes.argtypes = [vp, ctypes.POINTER(u64)]
         L.blsw_engine_submit_compact.argtypes = [vp, vp, vp, vp, vp, vp, vp]
         L.blsw_engine_expand_compact.argtypes = [vp, vp, vp, u64, vp]
+        L.blsw_engine_submit_aggregate_compact.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.blsw_witness_digest.argtypes = [vp, u64, u64, u32, vp, vp]
         L.blsw_matrices_info.argtypes = [u32, u32, u32, ctypes.POINTER(blsw_matrices_info_t)]
         L.blsw_matrices_fill.argtypes = [u32, u32, u32, ctypes.POINTER(blsw_matrices_info_t), ctypes.POINTER(blsw_matrices_t)]
@@ -112,7 +113,7 @@ def lib():
 
 EXPORTED_SYMBOLS = ["blsw_version", "blsw_layout", "blsw_engine_options_default", "blsw_engine_workspace_bytes", "blsw_engine_workspace_bytes_ex", "blsw_engine_create",
                     "blsw_engine_create_ex", "blsw_engine_destroy", "blsw_engine_submit", "blsw_engine_submit_aggregate", "blsw_engine_flush", "blsw_engine_submitted", "blsw_engine_launched", "blsw_engine_materialised", "blsw_engine_wait_step",
-                    "blsw_engine_output_consumed", "blsw_engine_compact_bytes", "blsw_engine_submit_compact", "blsw_engine_expand_compact", "blsw_engine_expand_stats", "blsw_witness_digest", "blsw_hash_to_g2_workspace_bytes", "blsw_hash_to_g2_batch",
+                    "blsw_engine_output_consumed", "blsw_engine_compact_bytes", "blsw_engine_submit_compact", "blsw_engine_submit_aggregate_compact", "blsw_engine_expand_compact", "blsw_engine_expand_stats", "blsw_witness_digest", "blsw_hash_to_g2_workspace_bytes", "blsw_hash_to_g2_batch",
                     "blsw_decode_batch", "blsw_layout_aggregate", "blsw_aggregate_workspace_bytes", "blsw_aggregate_verify_batch", "blsw_layout_multi",
                     "blsw_verify_multi_workspace_bytes", "blsw_verify_multi_batch", "blsw_matrices_info", "blsw_matrices_fill", "blsw_sign_batch", "blsw_microbench"]
 
@@ -261,6 +262,22 @@ class WitnessEngine:
         if rc:
             raise (BlswBusy if rc == ERR_BUSY else BlswError)("blsw_engine_submit_compact failed: %d" % rc)
         self._keep.append((pk_xy, sig_xy, msg, compact, result))
+        self._keep = self._keep[-(self.n_buffers + 1) * self.max_steps:]
+        return seq
+
+    def submit_aggregate_compact(self, pks_xy, bitmap, sig_xy, msg, compact, result=None, count=None, stream=None):
+        """submit_aggregate with the step's compact wire form in `compact` as its output -> step number"""
+        K = self.n_keys
+        assert K and pks_xy.shape == (self.n, K, 12) and bitmap.shape == (self.n, K) and sig_xy.shape == (self.n, 24) and msg.shape == (self.n, self.msg_len)
+        assert pks_xy.is_contiguous() and bitmap.is_contiguous() and sig_xy.is_contiguous() and msg.is_contiguous()
+        assert compact.is_cuda and compact.is_contiguous() and compact.dtype.itemsize == 1 and compact.numel() >= self.compact_bytes()
+        seq = self.submitted()
+        rc = lib().blsw_engine_submit_aggregate_compact(self._e, pks_xy.data_ptr(), bitmap.data_ptr(), sig_xy.data_ptr(), msg.data_ptr() if self.msg_len else None,
+                                                        compact.data_ptr(), result.data_ptr() if result is not None else None,
+                                                        count.data_ptr() if count is not None else None, self._stream(stream))
+        if rc:
+            raise (BlswBusy if rc == ERR_BUSY else BlswError)("blsw_engine_submit_aggregate_compact failed: %d" % rc)
+        self._keep.append((pks_xy, bitmap, sig_xy, msg, compact, result, count))
         self._keep = self._keep[-(self.n_buffers + 1) * self.max_steps:]
         return seq
 

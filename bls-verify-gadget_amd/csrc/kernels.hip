@@ -1397,6 +1397,12 @@ int blsw_engine_submit_compact(blsw_engine_t* e, const uint64_t* d_pk_xy, const 
     StepDesc d = {d_pk_xy, d_sig_xy, d_msg, nullptr, 0, d_result, nullptr, nullptr, nullptr, d_compact};
     return engine_submit(e, d, stream_);
 }
+int blsw_engine_submit_aggregate_compact(blsw_engine_t* e, const uint64_t* d_pks_xy, const uint8_t* d_bitmap, const uint64_t* d_sig_xy, const uint8_t* d_msg,
+                                         void* d_compact, int32_t* d_result, uint32_t* d_count, void* stream_) {
+    if (!e || !e->L.n_keys || !e->staged || e->n % 64 || !d_compact || !d_pks_xy || !d_bitmap || !d_sig_xy || (!d_msg && e->msg_len)) return BLSW_ERR_ARG;
+    StepDesc d = {nullptr, d_sig_xy, d_msg, nullptr, 0, d_result, d_pks_xy, d_bitmap, d_count, d_compact};
+    return engine_submit(e, d, stream_);
+}
 // receiver side: one batch in compact form -> its n witness vectors, on `stream` (the expansion and placement kernels of the
 // engine's own steps, pointed at the compact buffer)
 int blsw_engine_expand_compact(blsw_engine_t* e, const void* d_compact, uint64_t* d_witness, uint64_t witness_stride, void* stream_) {

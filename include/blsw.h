@@ -179,7 +179,7 @@ int blsw_engine_output_consumed(blsw_engine_t* e, const void* d_output, void* st
  * 8-GPU job far below the generation rate. In compact form a batch is its bit-packed SHA witnesses plus its field witnesses as
  * 48-byte elements (2.6 MB per instance: blsw_engine_compact_bytes per batch); that is what travels, and the receiver turns it
  * into the n witness vectors — bit-exact what blsw_engine_submit writes — with blsw_engine_expand_compact. Engines with
- * n % 64 == 0 and (max_steps > 1 or n_buffers > 1), single-key circuit.
+ * n % 64 == 0 and (max_steps > 1 or n_buffers > 1).
  *   blsw_engine_submit_compact: as blsw_engine_submit, the step's output is d_compact (compact_bytes bytes) instead of d_witness;
  *     blsw_engine_wait_step / _output_consumed (with the d_compact pointer) work as for witness tensors;
  *   blsw_engine_expand_compact: enqueues on `stream` the expansion of one compact batch (produced by ANY engine of the same
@@ -187,6 +187,9 @@ int blsw_engine_output_consumed(blsw_engine_t* e, const void* d_output, void* st
 int blsw_engine_compact_bytes(blsw_engine_t* e, uint64_t* bytes);
 int blsw_engine_submit_compact(blsw_engine_t* e, const uint64_t* d_pk_xy, const uint64_t* d_sig_xy, const uint8_t* d_msg, void* d_compact, int32_t* d_result,
                                void* stream);
+/* the same for an aggregate_verify engine (options.n_keys = K): arguments of blsw_engine_submit_aggregate, output d_compact */
+int blsw_engine_submit_aggregate_compact(blsw_engine_t* e, const uint64_t* d_pks_xy, const uint8_t* d_bitmap, const uint64_t* d_sig_xy, const uint8_t* d_msg,
+                                         void* d_compact, int32_t* d_result, uint32_t* d_count, void* stream);
 int blsw_engine_expand_compact(blsw_engine_t* e, const void* d_compact, uint64_t* d_witness, uint64_t witness_stride, void* stream);
 /* average duration (ms) of the bit->Fp expansion kernel launches issued since the previous call (HIP events on the stream they
  * ran on, at most 1024 launches); blocks until they have finished and resets the statistics */
