@@ -322,6 +322,11 @@ __global__ __launch_bounds__(THREADS) void k_sha_expand(ExpandArgs a) {
     if (blockIdx.x * ((THREADS / 3) * ITERS) + (P0 + THREADS - 1) / 3 + (THREADS / 3) * (ITERS - 1) < a.sha_bits) {
         // whole workgroup in range (all but the last one or two of an instance): all bit words first, then the stores back to
         // back — no bounds checks, no wait between a store and the next load
+#ifdef BLSW_DEBUG_EXPAND_CONST  // timing experiment: the stores without the bit logic (wrong witnesses)
+#pragma unroll
+        for (int k = 0; k < ITERS; k++) expand_store<NT>(dst + (uint64_t)k * THREADS, rc);
+        return;
+#endif
         uint32_t w[ITERS];
 #pragma unroll
         for (int k = 0; k < ITERS; k++) w[k] = expand_word(b, w0 + k * (THREADS / 96));
