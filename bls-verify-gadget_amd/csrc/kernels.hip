@@ -532,6 +532,44 @@ __global__ __launch_bounds__(64) void k_cofactor(Group g) {
     st_fp(o + 5 * N, h.z.c1);
 }
 
+// Value-only entry points (hash_to_g2 batch, signer): the same group element without the circuit's witness structure — the
+// in-circuit clear_cofactor2 is an AFFINE double-and-add with one slope inversion per step (939 Fp2 inversions, App. A.5);
+// here it is a Jacobian ladder over the 636 bits of h_eff with two inversions in all. Output as k_cofactor's: homogeneous (x, y, z).
+__global__ __launch_bounds__(64) void k_cofactor_values(Group g) {
+    uint64_t I = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (I >= g.N) return;
+    constexpr uint32_t HE[20] = BLSW_H_EFF_WORDS;
+    const uint64_t N = g.N;
+    Proj<OpsFp2> q0 = ld_proj2(g.ws.q + I, N), q1 = ld_proj2(g.ws.q + 6 * N + I, N);
+    Emitter none;
+    none.base = nullptr;
+    none.pos = 0;
+    Proj<OpsFp2> r = proj_add_w<OpsFp2, 0>(none, q0, q1);  // hasher.rs:656, complete addition (value-only cursor)
+    Proj<OpsFp2> h = {fp2_zero(), fp2_one(), fp2_zero()};
+    if (!fp2_is_zero(r.z)) {
+        const Fp2 zi = fp2_inv(r.z);
+        const Fp2 ax = fp2_mul(r.x, zi), ay = fp2_mul(r.y, zi);
+        Jac2 acc = {ax, ay, fp2_one()};
+#pragma unroll 1
+        for (int i = BLSW_H_EFF_NBITS - 2; i >= 0; i--) {
+            acc = jac2_dbl(acc);
+            if (bit_of(HE, i)) acc = jac2_add_mixed(acc, ax, ay);
+        }
+        if (!fp2_is_zero(acc.z)) {  // (X / Z^2, Y / Z^3) as homogeneous (X Z, Y, Z^3)
+            h.x = fp2_mul(acc.x, acc.z);
+            h.y = acc.y;
+            h.z = fp2_mul(fp2_sqr(acc.z), acc.z);
+        }
+    }
+    Fp* o = g.ws.h + I;
+    st_fp(o, h.x.c0);
+    st_fp(o + N, h.x.c1);
+    st_fp(o + 2 * N, h.y.c0);
+    st_fp(o + 3 * N, h.y.c1);
+    st_fp(o + 4 * N, h.z.c0);
+    st_fp(o + 5 * N, h.z.c1);
+}
+
 // line coefficients, element-major: coefficient idx of instance I at p[idx * N]
 struct CoeffStrided {
     Fp* p;
@@ -1543,7 +1581,7 @@ int blsw_hash_to_g2_batch(const uint8_t* d_msg, uint32_t msg_len, uint64_t n, ui
     const unsigned g1 = (unsigned)((n + 63) / 64), g2 = (unsigned)((2 * n + 63) / 64);
     hipLaunchKernelGGL(k_sha_values, dim3(g1), dim3(64), 0, st, g);
     hipLaunchKernelGGL(k_map, dim3(g2), dim3(64), 0, st, g);
-    hipLaunchKernelGGL(k_cofactor, dim3(g1), dim3(64), 0, st, g);
+    hipLaunchKernelGGL(k_cofactor_values, dim3(g1), dim3(64), 0, st, g);
     hipLaunchKernelGGL(k_h_to_affine, dim3(g1), dim3(64), 0, st, n, g.ws, d_out_affine);
     return hip_ok(hipGetLastError(), "launch");
 }
@@ -1563,7 +1601,7 @@ int blsw_sign_batch(const uint8_t* d_sk32_le, const uint8_t* d_msg, uint32_t msg
     const unsigned g1 = (unsigned)((n + 63) / 64), g2 = (unsigned)((2 * n + 63) / 64);
     hipLaunchKernelGGL(k_sha_values, dim3(g1), dim3(64), 0, st, g);
     hipLaunchKernelGGL(k_map, dim3(g2), dim3(64), 0, st, g);
-    hipLaunchKernelGGL(k_cofactor, dim3(g1), dim3(64), 0, st, g);
+    hipLaunchKernelGGL(k_cofactor_values, dim3(g1), dim3(64), 0, st, g);
     hipLaunchKernelGGL(k_sign, dim3(g2), dim3(64), 0, st, n, g.ws, d_sk32_le, d_sig96, d_sig_xy, d_pk48, d_pk_xy, d_status);
     return hip_ok(hipGetLastError(), "launch");
 }

@@ -420,30 +420,6 @@ def _grouped(pkg, oracle, n, steps, max_steps, check_idx, tamper_every=3, n_buff
             bad = np.nonzero((ow != w[a]).any(axis=1))[0]
             assert len(bad) == 0, "step %d instance %d: first mismatching witness index %d" % (k, i, bad[0])
     eng.close()
-    # the aggregate engine's compact wire form: 64 instances (copies of step 0's six), compact submit + expansion on a second
-    # engine == plain submit, every element
-    n2 = 64
-    rep = lambda t: t.repeat((n2 + n - 1) // n, *([1] * (t.dim() - 1)))[:n2].contiguous()
-    batch = cases[0]
-    pks = rep(torch.from_numpy(np.stack([c[0] for c in batch]).view(np.int64)).to(dev))
-    bmt = rep(torch.from_numpy(np.stack([c[1] for c in batch])).to(dev))
-    msg = rep(torch.from_numpy(np.stack([c[2] for c in batch])).to(dev))
-    sig = rep(torch.from_numpy(np.stack([c[3] for c in batch]).view(np.int64)).to(dev))
-    e2 = pkg.WitnessEngine(n2, 32, max_steps=2, device=dev, n_buffers=2, n_keys=K)
-    e3 = pkg.WitnessEngine(n2, 32, max_steps=2, device=dev, n_buffers=1, n_keys=K)
-    plain, cb, back = e2.new_witness_tensor(), e2.new_compact_buffer(1), e3.new_witness_tensor()
-    r1, r2 = torch.empty(n2, dtype=torch.int32, device=dev), torch.empty(n2, dtype=torch.int32, device=dev)
-    c1, c2 = torch.empty(n2, dtype=torch.int32, device=dev), torch.empty(n2, dtype=torch.int32, device=dev)
-    e2.submit_aggregate(pks, bmt, sig, msg, witness=plain, result=r1, count=c1)
-    e2.submit_aggregate_compact(pks, bmt, sig, msg, cb[0], result=r2, count=c2)
-    e2.flush()
-    torch.cuda.synchronize()
-    e3.expand_compact(cb[0], back)
-    torch.cuda.synchronize()
-    assert torch.equal(back, plain) and torch.equal(r1, r2) and torch.equal(c1, c2)
-    assert torch.equal(plain[:n], outs[0][0]) and torch.equal(plain[60], outs[0][0][60 % n])
-    e2.close()
-    e3.close()
 
 
 @pytest.mark.parametrize("options", [dict(g2_mode="team"), dict(pairing_mode="lane"), dict(expand_store=1, prio_mode=0)])
@@ -835,3 +811,27 @@ def test_engine_aggregate_grouped(pkg, oracle):
             bad = np.nonzero((ow != wh[i]).any(axis=1))[0]
             assert len(bad) == 0, "step %d instance %d: first mismatching witness index %d" % (k, i, bad[0])
     eng.close()
+    # the aggregate engine's compact wire form: 64 instances (copies of step 0's six), compact submit + expansion on a second
+    # engine == plain submit, every element
+    n2 = 64
+    rep = lambda t: t.repeat((n2 + n - 1) // n, *([1] * (t.dim() - 1)))[:n2].contiguous()
+    batch = cases[0]
+    pks = rep(torch.from_numpy(np.stack([c[0] for c in batch]).view(np.int64)).to(dev))
+    bmt = rep(torch.from_numpy(np.stack([c[1] for c in batch])).to(dev))
+    msg = rep(torch.from_numpy(np.stack([c[2] for c in batch])).to(dev))
+    sig = rep(torch.from_numpy(np.stack([c[3] for c in batch]).view(np.int64)).to(dev))
+    e2 = pkg.WitnessEngine(n2, 32, max_steps=2, device=dev, n_buffers=2, n_keys=K)
+    e3 = pkg.WitnessEngine(n2, 32, max_steps=2, device=dev, n_buffers=1, n_keys=K)
+    plain, cb, back = e2.new_witness_tensor(), e2.new_compact_buffer(1), e3.new_witness_tensor()
+    r1, r2 = torch.empty(n2, dtype=torch.int32, device=dev), torch.empty(n2, dtype=torch.int32, device=dev)
+    c1, c2 = torch.empty(n2, dtype=torch.int32, device=dev), torch.empty(n2, dtype=torch.int32, device=dev)
+    e2.submit_aggregate(pks, bmt, sig, msg, witness=plain, result=r1, count=c1)
+    e2.submit_aggregate_compact(pks, bmt, sig, msg, cb[0], result=r2, count=c2)
+    e2.flush()
+    torch.cuda.synchronize()
+    e3.expand_compact(cb[0], back)
+    torch.cuda.synchronize()
+    assert torch.equal(back, plain) and torch.equal(r1, r2) and torch.equal(c1, c2)
+    assert torch.equal(plain[:n], outs[0][0]) and torch.equal(plain[60], outs[0][0][60 % n])
+    e2.close()
+    e3.close()
