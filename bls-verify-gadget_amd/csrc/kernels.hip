@@ -535,30 +535,74 @@ __global__ __launch_bounds__(64) void k_cofactor(Group g) {
 // Value-only entry points (hash_to_g2 batch, signer): the same group element without the circuit's witness structure — the
 // in-circuit clear_cofactor2 is an AFFINE double-and-add with one slope inversion per step (939 Fp2 inversions, App. A.5);
 // here it is a Jacobian ladder over the 636 bits of h_eff with two inversions in all. Output as k_cofactor's: homogeneous (x, y, z).
-__global__ __launch_bounds__(64) void k_cofactor_values(Group g) {
+// The ladder is written out with inlined Fp2 operations (only the Fp product and the inversion are calls), so that the kernel
+// fits two waves per SIMD: the shared jac2_dbl / jac2_add_mixed are separate functions that take 248 VGPRs + 32 AGPRs each.
+namespace {
+__device__ __forceinline__ Fp2 v_sqr(const Fp2& a) {
+    Fp v = fp_mul(a.c0, a.c1);
+    Fp t = fp_mul(fp_sub(a.c0, a.c1), fp_add(a.c0, a.c1));
+    return {t, fp_dbl(v)};
+}
+__device__ __forceinline__ Jac2 v_dbl(const Jac2& p) {  // dbl-2009-l, a = 0
+    Fp2 A = v_sqr(p.x), B = v_sqr(p.y), C = v_sqr(B);
+    Fp2 D = fp2_dbl(fp2_sub(fp2_sub(v_sqr(fp2_add(p.x, B)), A), C));
+    Fp2 E = fp2_add(fp2_dbl(A), A);
+    Fp2 x3 = fp2_sub(v_sqr(E), fp2_dbl(D));
+    Fp2 y3 = fp2_sub(fp2_mul_inl(E, fp2_sub(D, x3)), fp2_dbl(fp2_dbl(fp2_dbl(C))));
+    Fp2 z3 = fp2_dbl(fp2_mul_inl(p.y, p.z));
+    return {x3, y3, z3};
+}
+__device__ __forceinline__ Jac2 v_add_mixed(const Jac2& p, const Fp2& qx, const Fp2& qy) {  // madd-2007-bl; p = 0, p = +-q handled
+    if (fp2_is_zero(p.z)) return {qx, qy, fp2_one()};
+    Fp2 z1z1 = v_sqr(p.z);
+    Fp2 u2 = fp2_mul_inl(qx, z1z1);
+    Fp2 s2 = fp2_mul_inl(fp2_mul_inl(qy, p.z), z1z1);
+    Fp2 h = fp2_sub(u2, p.x);
+    Fp2 rr = fp2_dbl(fp2_sub(s2, p.y));
+    if (fp2_is_zero(h)) {
+        if (fp2_is_zero(rr)) return v_dbl(p);
+        return {fp2_one(), fp2_one(), fp2_zero()};
+    }
+    Fp2 hh = v_sqr(h);
+    Fp2 i = fp2_dbl(fp2_dbl(hh));
+    Fp2 j = fp2_mul_inl(h, i);
+    Fp2 v = fp2_mul_inl(p.x, i);
+    Fp2 x3 = fp2_sub(fp2_sub(v_sqr(rr), j), fp2_dbl(v));
+    Fp2 y3 = fp2_sub(fp2_mul_inl(rr, fp2_sub(v, x3)), fp2_dbl(fp2_mul_inl(p.y, j)));
+    Fp2 z3 = fp2_sub(fp2_sub(v_sqr(fp2_add(p.z, h)), z1z1), hh);
+    return {x3, y3, z3};
+}
+}  // namespace
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_cofactor_values(Group g) {
     uint64_t I = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (I >= g.N) return;
     constexpr uint32_t HE[20] = BLSW_H_EFF_WORDS;
     const uint64_t N = g.N;
-    Proj<OpsFp2> q0 = ld_proj2(g.ws.q + I, N), q1 = ld_proj2(g.ws.q + 6 * N + I, N);
-    Emitter none;
-    none.base = nullptr;
-    none.pos = 0;
-    Proj<OpsFp2> r = proj_add_w<OpsFp2, 0>(none, q0, q1);  // hasher.rs:656, complete addition (value-only cursor)
+    // Q0, Q1 leave the isogeny as (x, y, 1) or (0, 0, 0) (hasher.rs:339-345): affine points or the identity
+    Jac2 r;
+    {
+        const Proj<OpsFp2> q0 = ld_proj2(g.ws.q + I, N);
+        r = {q0.x, q0.y, q0.z};
+        if (fp2_is_zero(q0.z)) r = {fp2_one(), fp2_one(), fp2_zero()};
+    }
+    {
+        const Proj<OpsFp2> q1 = ld_proj2(g.ws.q + 6 * N + I, N);
+        if (!fp2_is_zero(q1.z)) r = v_add_mixed(r, q1.x, q1.y);  // hasher.rs:656 (handles Q0 = +-Q1 and Q0 = 0)
+    }
     Proj<OpsFp2> h = {fp2_zero(), fp2_one(), fp2_zero()};
     if (!fp2_is_zero(r.z)) {
-        const Fp2 zi = fp2_inv(r.z);
-        const Fp2 ax = fp2_mul(r.x, zi), ay = fp2_mul(r.y, zi);
+        const Fp2 zi = fp2_inv_inl(r.z), zi2 = v_sqr(zi);
+        const Fp2 ax = fp2_mul_inl(r.x, zi2), ay = fp2_mul_inl(r.y, fp2_mul_inl(zi2, zi));
         Jac2 acc = {ax, ay, fp2_one()};
 #pragma unroll 1
         for (int i = BLSW_H_EFF_NBITS - 2; i >= 0; i--) {
-            acc = jac2_dbl(acc);
-            if (bit_of(HE, i)) acc = jac2_add_mixed(acc, ax, ay);
+            acc = v_dbl(acc);
+            if (bit_of(HE, i)) acc = v_add_mixed(acc, ax, ay);
         }
         if (!fp2_is_zero(acc.z)) {  // (X / Z^2, Y / Z^3) as homogeneous (X Z, Y, Z^3)
-            h.x = fp2_mul(acc.x, acc.z);
+            h.x = fp2_mul_inl(acc.x, acc.z);
             h.y = acc.y;
-            h.z = fp2_mul(fp2_sqr(acc.z), acc.z);
+            h.z = fp2_mul_inl(v_sqr(acc.z), acc.z);
         }
     }
     Fp* o = g.ws.h + I;

@@ -17,7 +17,7 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--hash-n", type=int, default=1 << 20)
-    ap.add_argument("--hash-chunk", type=int, default=1 << 16)
+    ap.add_argument("--hash-chunk", type=int, default=1 << 18)  # >= 2 waves per SIMD for the value-only cofactor ladder
     ap.add_argument("--agg-n", type=int, default=1024)
     ap.add_argument("--agg-keys", type=int, default=128)
     ap.add_argument("--sign-n", type=int, default=16384)
