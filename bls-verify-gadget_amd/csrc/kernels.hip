@@ -573,6 +573,110 @@ __device__ __forceinline__ Jac2 v_add_mixed(const Jac2& p, const Fp2& qx, const 
     return {x3, y3, z3};
 }
 }  // namespace
+// map_to_curve_9mod16 + isogeny_map (hasher.rs:352-502, 294-348) for the value-only entries: the statements of
+// chain_map_to_curve without the witness cursor, on the inlined Fp2 operations above (two waves per SIMD). Same field
+// operations in the same order, so the result is the same element bit for bit.
+namespace {
+__device__ __forceinline__ bool v_eq(const Fp2& a, const Fp2& b) { return fp_eq(a.c0, b.c0) && fp_eq(a.c1, b.c1); }
+__device__ __forceinline__ Fp2 v_sel(bool c, const Fp2& a, const Fp2& b) { return c ? a : b; }
+__device__ __forceinline__ bool v_sgn0(const Fp2& v) {  // hasher.rs:520-530
+    const Fp c0 = fp_to_canonical(v.c0), c1 = fp_to_canonical(v.c1);
+    return (c0.l[0] & 1) || (fp_is_zero(v.c0) && (c1.l[0] & 1));
+}
+__device__ __forceinline__ Fp2 v_poly(const Fp2* k, int n, const Fp2& x) {  // sum k[i] x^i, powers as DensePolynomialVar::evaluate builds them
+    Fp2 result = k[0], cp = x;
+    for (int i = 1; i < n; i++) {
+        result = fp2_add(result, fp2_mul_inl(cp, k[i]));
+        if (i + 1 < n) cp = fp2_mul_inl(cp, x);
+    }
+    return result;
+}
+__device__ __forceinline__ Proj<OpsFp2> v_map_to_curve(const Fp2& u) {
+    constexpr uint32_t C1[24] = BLSW_SSWU_C1_WORDS;
+    const Fp2 Z = K_SSWU_Z(), A = K_SSWU_A(), B = K_SSWU_B(), C2 = K_SSWU_C2(), C3 = K_SSWU_C3(), C4 = K_SSWU_C4(), C5 = K_SSWU_C5();
+    Fp2 tv1 = v_sqr(u);
+    Fp2 tv3 = fp2_mul_inl(Z, tv1);
+    Fp2 tv5 = v_sqr(tv3);
+    Fp2 xd = fp2_add(tv5, tv3);
+    Fp2 x1n = fp2_mul_inl(fp2_add(xd, fp2_one()), B);
+    xd = fp2_mul_inl(K_SSWU_NEG_A(), xd);
+    xd = v_sel(fp2_is_zero(xd), K_SSWU_ZA(), xd);
+    Fp2 tv2 = v_sqr(xd);
+    Fp2 gxd = fp2_mul_inl(tv2, xd);
+    tv2 = fp2_mul_inl(A, tv2);
+    Fp2 gx1 = fp2_add(v_sqr(x1n), tv2);
+    gx1 = fp2_mul_inl(gx1, x1n);
+    gx1 = fp2_add(gx1, fp2_mul_inl(B, gxd));
+    Fp2 tv4 = v_sqr(gxd);
+    tv2 = fp2_mul_inl(tv4, gxd);
+    tv4 = v_sqr(tv4);
+    tv2 = fp2_mul_inl(tv2, tv4);
+    tv2 = fp2_mul_inl(tv2, gx1);
+    tv4 = v_sqr(tv4);
+    tv4 = fp2_mul_inl(tv2, tv4);
+    Fp2 y = tv4;  // y = tv4 ^ c1 (bits 759, 758 are zero, bit 757 is the leading one)
+#pragma unroll 1
+    for (int i = BLSW_SSWU_C1_NBITS - 4; i >= 0; i--) {
+        y = v_sqr(y);
+        if (bit_of(C1, i)) y = fp2_mul_inl(y, tv4);
+    }
+    y = fp2_mul_inl(y, tv2);
+    tv4 = fp2_mul_inl(y, C2);
+    y = v_sel(v_eq(fp2_mul_inl(v_sqr(tv4), gxd), gx1), tv4, y);
+    tv4 = fp2_mul_inl(y, C3);
+    y = v_sel(v_eq(fp2_mul_inl(v_sqr(tv4), gxd), gx1), tv4, y);
+    tv4 = fp2_mul_inl(tv4, C2);
+    y = v_sel(v_eq(fp2_mul_inl(v_sqr(tv4), gxd), gx1), tv4, y);
+    Fp2 gx2 = fp2_mul_inl(fp2_mul_inl(gx1, tv5), tv3);
+    tv5 = fp2_mul_inl(fp2_mul_inl(y, tv1), u);
+    tv1 = fp2_mul_inl(tv5, C4);
+    tv4 = fp2_mul_inl(tv1, C2);
+    tv1 = v_sel(v_eq(fp2_mul_inl(v_sqr(tv4), gxd), gx2), tv4, tv1);
+    tv4 = fp2_mul_inl(tv5, C5);
+    tv1 = v_sel(v_eq(fp2_mul_inl(v_sqr(tv4), gxd), gx2), tv4, tv1);
+    tv4 = fp2_mul_inl(tv4, C2);
+    tv1 = v_sel(v_eq(fp2_mul_inl(v_sqr(tv4), gxd), gx2), tv4, tv1);
+    const bool e8 = v_eq(fp2_mul_inl(v_sqr(y), gxd), gx1);
+    y = v_sel(e8, y, tv1);
+    const Fp2 xn = v_sel(e8, x1n, fp2_mul_inl(tv3, x1n));
+    const bool e9 = !(v_sgn0(u) ^ v_sgn0(y));
+    y = v_sel(e9, y, fp2_neg(y));
+    // to_projective_short (hasher.rs:551-559), to_affine_unchecked (:569-583), isogeny_map (:294-348)
+    const Fp2 xd3 = fp2_mul_inl(v_sqr(xd), xd);
+    const Fp2 jx = fp2_mul_inl(xn, xd), jy = fp2_mul_inl(y, xd3);
+    const bool is_infinity = fp2_is_zero(xd);
+    const Fp2 zi = fp2_inv_inl(xd), zi2 = v_sqr(zi);
+    const Fp2 ax = fp2_mul_inl(jx, zi2), ay = fp2_mul_inl(jy, fp2_mul_inl(zi2, zi));
+    const Fp2 kxd[3] = {K_ISO_XDEN0(), K_ISO_XDEN1(), K_ISO_XDEN2()};
+    const Fp2 kyd[4] = {K_ISO_YDEN0(), K_ISO_YDEN1(), K_ISO_YDEN2(), K_ISO_YDEN3()};
+    const Fp2 kxn[4] = {K_ISO_XNUM0(), K_ISO_XNUM1(), K_ISO_XNUM2(), K_ISO_XNUM3()};
+    const Fp2 kyn[4] = {K_ISO_YNUM0(), K_ISO_YNUM1(), K_ISO_YNUM2(), K_ISO_YNUM3()};
+    const Fp2 x_den_inv = fp2_inv_inl(v_poly(kxd, 3, ax));
+    const Fp2 y_den_inv = fp2_inv_inl(v_poly(kyd, 4, ax));
+    const Fp2 img_x = fp2_mul_inl(v_poly(kxn, 4, ax), x_den_inv);
+    const Fp2 img_y = fp2_mul_inl(fp2_mul_inl(v_poly(kyn, 4, ax), ay), y_den_inv);
+    Proj<OpsFp2> q;
+    q.x = v_sel(is_infinity, fp2_zero(), img_x);
+    q.y = v_sel(is_infinity, fp2_zero(), img_y);
+    q.z = is_infinity ? fp2_zero() : fp2_one();
+    return q;
+}
+}  // namespace
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_map_values(Group g) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 2 * g.N) return;
+    const uint32_t which = t >= g.N;
+    const uint64_t I = which ? t - g.N : t, N = g.N;
+    const Proj<OpsFp2> q = v_map_to_curve(ld_fp2(g.ws.u + (uint64_t)(2 * which) * N + I, N));
+    Fp* o = g.ws.q + (uint64_t)(6 * which) * N + I;
+    st_fp(o, q.x.c0);
+    st_fp(o + N, q.x.c1);
+    st_fp(o + 2 * N, q.y.c0);
+    st_fp(o + 3 * N, q.y.c1);
+    st_fp(o + 4 * N, q.z.c0);
+    st_fp(o + 5 * N, q.z.c1);
+}
+
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_cofactor_values(Group g) {
     uint64_t I = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (I >= g.N) return;
@@ -1624,7 +1728,7 @@ int blsw_hash_to_g2_batch(const uint8_t* d_msg, uint32_t msg_len, uint64_t n, ui
     if (int rc = put_desc(d_desc, h, st)) return rc;
     const unsigned g1 = (unsigned)((n + 63) / 64), g2 = (unsigned)((2 * n + 63) / 64);
     hipLaunchKernelGGL(k_sha_values, dim3(g1), dim3(64), 0, st, g);
-    hipLaunchKernelGGL(k_map, dim3(g2), dim3(64), 0, st, g);
+    hipLaunchKernelGGL(k_map_values, dim3(g2), dim3(64), 0, st, g);
     hipLaunchKernelGGL(k_cofactor_values, dim3(g1), dim3(64), 0, st, g);
     hipLaunchKernelGGL(k_h_to_affine, dim3(g1), dim3(64), 0, st, n, g.ws, d_out_affine);
     return hip_ok(hipGetLastError(), "launch");
@@ -1644,7 +1748,7 @@ int blsw_sign_batch(const uint8_t* d_sk32_le, const uint8_t* d_msg, uint32_t msg
     if (int rc = put_desc(d_desc, h, st)) return rc;
     const unsigned g1 = (unsigned)((n + 63) / 64), g2 = (unsigned)((2 * n + 63) / 64);
     hipLaunchKernelGGL(k_sha_values, dim3(g1), dim3(64), 0, st, g);
-    hipLaunchKernelGGL(k_map, dim3(g2), dim3(64), 0, st, g);
+    hipLaunchKernelGGL(k_map_values, dim3(g2), dim3(64), 0, st, g);
     hipLaunchKernelGGL(k_cofactor_values, dim3(g1), dim3(64), 0, st, g);
     hipLaunchKernelGGL(k_sign, dim3(g2), dim3(64), 0, st, n, g.ws, d_sk32_le, d_sig96, d_sig_xy, d_pk48, d_pk_xy, d_status);
     return hip_ok(hipGetLastError(), "launch");
