@@ -84,7 +84,7 @@ def spawn_ranks(args):
 
 
 def balanced_coalesce(steps, max_group):
-    """Equal launch groups: 20 steps with groups of at most 16 run as 10 + 10 rather than 16 + 4."""
+    """Equal launch groups: 25 steps with groups of at most 10 run as 9 + 8 + 8 rather than 10 + 10 + 5."""
     groups = (steps + max_group - 1) // max_group
     return max(1, (steps + groups - 1) // groups)
 
