@@ -66,7 +66,7 @@ BLSW_FN int fp_cmp_canonical(const Fp& a, const Fp& b) {
     }
     return 0;
 }
-BLSW_FN bool fp2_lex_largest(const Fp2& a) {  // c1 is the most significant component
+BLSW_HD bool fp2_lex_largest(const Fp2& a) {  // c1 is the most significant component
     Fp2 n = fp2_neg(a);
     int c = fp_cmp_canonical(a.c1, n.c1);
     if (c != 0) return c > 0;

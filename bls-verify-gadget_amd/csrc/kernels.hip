@@ -552,6 +552,35 @@ __device__ __forceinline__ Jac2 v_dbl(const Jac2& p) {  // dbl-2009-l, a = 0
     Fp2 z3 = fp2_dbl(fp2_mul_inl(p.y, p.z));
     return {x3, y3, z3};
 }
+__device__ __forceinline__ Jac1v v1_dbl(const Jac1v& p) {
+    Fp A = fp_sqr(p.x), B = fp_sqr(p.y), C = fp_sqr(B);
+    Fp D = fp_dbl(fp_sub(fp_sub(fp_sqr(fp_add(p.x, B)), A), C));
+    Fp E = fp_add(fp_dbl(A), A);
+    Fp x3 = fp_sub(fp_sqr(E), fp_dbl(D));
+    Fp y3 = fp_sub(fp_mul(E, fp_sub(D, x3)), fp_dbl(fp_dbl(fp_dbl(C))));
+    Fp z3 = fp_dbl(fp_mul(p.y, p.z));
+    return {x3, y3, z3};
+}
+__device__ __forceinline__ Jac1v v1_add_mixed(const Jac1v& p, const Fp& qx, const Fp& qy) {
+    if (fp_is_zero(p.z)) return {qx, qy, fp_one()};
+    Fp z1z1 = fp_sqr(p.z);
+    Fp u2 = fp_mul(qx, z1z1);
+    Fp s2 = fp_mul(fp_mul(qy, p.z), z1z1);
+    Fp h = fp_sub(u2, p.x);
+    Fp rr = fp_dbl(fp_sub(s2, p.y));
+    if (fp_is_zero(h)) {
+        if (fp_is_zero(rr)) return v1_dbl(p);
+        return {fp_one(), fp_one(), fp_zero()};
+    }
+    Fp hh = fp_sqr(h);
+    Fp i = fp_dbl(fp_dbl(hh));
+    Fp j = fp_mul(h, i);
+    Fp v = fp_mul(p.x, i);
+    Fp x3 = fp_sub(fp_sub(fp_sqr(rr), j), fp_dbl(v));
+    Fp y3 = fp_sub(fp_mul(rr, fp_sub(v, x3)), fp_dbl(fp_mul(p.y, j)));
+    Fp z3 = fp_sub(fp_sub(fp_sqr(fp_add(p.z, h)), z1z1), hh);
+    return {x3, y3, z3};
+}
 __device__ __forceinline__ Jac2 v_add_mixed(const Jac2& p, const Fp2& qx, const Fp2& qy) {  // madd-2007-bl; p = 0, p = +-q handled
     if (fp2_is_zero(p.z)) return {qx, qy, fp2_one()};
     Fp2 z1z1 = v_sqr(p.z);
@@ -962,7 +991,7 @@ __global__ __launch_bounds__(64) void k_h_to_affine(uint64_t n, Workspace ws, ui
 
 // native signer (bls.rs:411-425, 183-195): lanes [0, n) sig_i = sk_i * H(msg_i) (H projective in ws.h), lanes [n, 2n)
 // pk_i = sk_i * g1. Outputs (each optional): compressed bytes and affine Montgomery limbs; status[i] (SIGN_*)
-__global__ __launch_bounds__(64) void k_sign(uint64_t n, Workspace ws, const uint8_t* __restrict__ sk32, uint8_t* sig96, uint64_t* sig_xy, uint8_t* pk48,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_sign(uint64_t n, Workspace ws, const uint8_t* __restrict__ sk32, uint8_t* sig96, uint64_t* sig_xy, uint8_t* pk48,
                                              uint64_t* pk_xy, int32_t* status) {
     uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= 2 * n) return;
@@ -974,10 +1003,21 @@ __global__ __launch_bounds__(64) void k_sign(uint64_t n, Workspace ws, const uin
         bool inf = true;
         if (st == SIGN_OK) {
             Proj<OpsFp2> h = ld_proj2(ws.h + i, n);
-            if (!fp2_is_zero(h.z)) {
-                Fp2 zi = fp2_inv(h.z);
-                Fp2 hx = fp2_mul(h.x, zi), hy = fp2_mul(h.y, zi);
-                inf = !g2_mul_affine(hx, hy, k, x, y);
+            if (!fp2_is_zero(h.z)) {  // sig = sk * H(m): inlined Jacobian ladder (two waves per SIMD, as k_cofactor_values)
+                const Fp2 zi = fp2_inv_inl(h.z);
+                const Fp2 hx = fp2_mul_inl(h.x, zi), hy = fp2_mul_inl(h.y, zi);
+                Jac2 acc = {fp2_one(), fp2_one(), fp2_zero()};
+#pragma unroll 1
+                for (int b = 254; b >= 0; b--) {
+                    acc = v_dbl(acc);
+                    if ((k[b >> 5] >> (b & 31)) & 1) acc = v_add_mixed(acc, hx, hy);
+                }
+                if (!fp2_is_zero(acc.z)) {
+                    const Fp2 ai = fp2_inv_inl(acc.z), ai2 = v_sqr(ai);
+                    x = fp2_mul_inl(acc.x, ai2);
+                    y = fp2_mul_inl(acc.y, fp2_mul_inl(ai2, ai));
+                    inf = false;
+                }
             }
         }
         if (sig_xy) {
@@ -992,7 +1032,21 @@ __global__ __launch_bounds__(64) void k_sign(uint64_t n, Workspace ws, const uin
     } else {
         Fp x = fp_zero(), y = fp_zero();
         bool inf = true;
-        if (st == SIGN_OK) inf = !g1_mul_affine(K_G1_GEN_X(), fp_neg(K_G1_GEN_NEG_Y()), k, x, y);
+        if (st == SIGN_OK) {  // pk = sk * g1, the same ladder over Fp
+            const Fp gx = K_G1_GEN_X(), gy = fp_neg(K_G1_GEN_NEG_Y());
+            Jac1v acc = {fp_one(), fp_one(), fp_zero()};
+#pragma unroll 1
+            for (int b = 254; b >= 0; b--) {
+                acc = v1_dbl(acc);
+                if ((k[b >> 5] >> (b & 31)) & 1) acc = v1_add_mixed(acc, gx, gy);
+            }
+            if (!fp_is_zero(acc.z)) {
+                const Fp ai = fp_inv(acc.z), ai2 = fp_sqr(ai);
+                x = fp_mul(acc.x, ai2);
+                y = fp_mul(acc.y, fp_mul(ai2, ai));
+                inf = false;
+            }
+        }
         if (pk_xy) {
             Fp* o = reinterpret_cast<Fp*>(pk_xy + i * 12);
             st_fp(o, x);
