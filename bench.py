@@ -59,6 +59,7 @@ def parse_args():
     ap.add_argument("--cpu-sample", type=int, default=256, help="instances of the batch timed on the host (all cores, and one thread)")
     ap.add_argument("--allgather-steps", type=int, default=32, help="steps of the generation + all-gather leg (0 = skip; runs when a process group exists)")
     ap.add_argument("--allgather-chunk", type=int, default=64, help="instances per rank in one all-gathered micro-batch (form full)")
+    ap.add_argument("--allgather-group", type=int, default=16, help="steps per launch group in the all-gather leg (consumer-mode engine)")
     ap.add_argument("--allgather-form", choices=("compact", "full"), default="compact",
                     help="what travels in the all-gather leg: the compact wire form, expanded by every receiver, or the full witness tensors")
     return ap.parse_args()
@@ -150,7 +151,7 @@ def allgather_leg(args, pkg, sharding, dist, dev, inputs, lay, world):
     d_pk, d_msg, d_sig = inputs
     # consumer mode: groups of chains run ahead into the staging, a step is expanded into its ring tensor when the gather has
     # released that tensor's previous user
-    group = max(1, min(10, steps // 2))
+    group = max(1, min(args.allgather_group, steps // 2))
     eng = pkg.WitnessEngine(n, 32, max_steps=group, device=dev, n_buffers=max(2, min(3, (steps + group - 1) // group)), consumer_mode=1)
     outs = [eng.new_witness_tensor() for _ in range(ring)]
     results = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(ring)]
@@ -216,7 +217,7 @@ def allgather_leg_compact(args, pkg, sharding, dist, dev, inputs, lay, world):
 
     n = args.batch
     steps = min(args.allgather_steps, args.steps)
-    group = max(1, min(10, steps // 2))
+    group = max(1, min(args.allgather_group, steps // 2))
     ring = 4  # compact buffers; consumer mode: a step leaves for its buffer when the gather has released the buffer's previous user
     eng = pkg.WitnessEngine(n, 32, max_steps=group, device=dev, n_buffers=max(2, min(3, (steps + group - 1) // group)), consumer_mode=1)
     cbufs = eng.new_compact_buffer(ring)

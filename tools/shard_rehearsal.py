@@ -39,7 +39,7 @@ def run_shard(pkg, n_shard=8192, batch=1024, ring=2, rank=0, world=8, buffers=6,
     assert hi - lo == n_shard and n_shard % batch == 0
     steps = n_shard // batch
     if group is None:
-        group = max(1, min(10, steps // 2))
+        group = max(1, min(16, steps // 2))
     if group:
         eng = pkg.WitnessEngine(batch, 32, max_steps=group, device=dev, n_buffers=max(2, min(3, (steps + group - 1) // group)), consumer_mode=1)
     else:
@@ -123,7 +123,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--ring", type=int, default=2)
     ap.add_argument("--buffers", type=int, default=6)
-    ap.add_argument("--group", type=int, default=None, help="steps per launch group in consumer mode (default min(10, steps / 2); 0 = free-running engine with groups of `ring`)")
+    ap.add_argument("--group", type=int, default=None, help="steps per launch group in consumer mode (default min(16, steps / 2); 0 = free-running engine with groups of `ring`)")
     ap.add_argument("--no-check", action="store_true")
     args = ap.parse_args()
     pkg = importlib.import_module("bls-verify-gadget_amd")
