@@ -1,4 +1,9 @@
-"""Builds libblsw.so (HIP, gfx950) in-tree. hipcc cross-compiles without a GPU."""
+"""Builds libblsw.so (HIP, gfx950) in-tree. hipcc cross-compiles without a GPU.
+
+One translation unit per kernel family (csrc/k_*.hip) plus the engine / C ABI (csrc/engine.hip) and the host-only constraint-matrix
+emitter (csrc/r1cs.cpp, g++); the units are compiled in parallel and linked into one shared library."""
+import concurrent.futures
+import hashlib
 import os
 import subprocess
 import sys
@@ -6,9 +11,11 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libblsw.so")
-SOURCES = ["kernels.hip"]
-HOST_SOURCES = ["r1cs.cpp"]  # host-only C++ (the constraint-matrix emitter): compiled by g++, linked into the same library
+OBJ = os.path.join(HERE, "build_obj")
+SOURCES = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+HOST_SOURCES = ["r1cs.cpp"]  # host-only C++: compiled by g++, linked into the same library
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith((".cuh", ".h")))
+HIP_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 
 
 def needs_build():
@@ -19,25 +26,78 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False, out=None, defines=()):
-    """out / defines: an alternative build next to the shipped one (A/B runs: BLSW_LIB=<out> selects it at import)"""
+def _compile(job):
+    cmd, log = job
+    p = subprocess.run(cmd, cwd=CSRC, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if log:
+        open(log, "w").write(p.stdout)
+    if p.returncode:
+        sys.stderr.write(p.stdout)
+        raise subprocess.CalledProcessError(p.returncode, cmd)
+    return p.stdout
+
+
+def build(force=False, verbose=False, out=None, defines=(), only=None):
+    """out / defines: an alternative build next to the shipped one (A/B runs: BLSW_LIB=<out> selects it at import).
+    Objects are cached per (source, flags): a unit is recompiled when it, a header or its flags changed."""
     if out is None and not force and not needs_build():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objs = []
-    for src in HOST_SOURCES:
-        obj = os.path.join(HERE, "build_" + os.path.splitext(src)[0] + ".o")
-        subprocess.check_call([os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas", "-c", os.path.join(CSRC, src), "-o", obj], cwd=CSRC)
+    os.makedirs(OBJ, exist_ok=True)
+    tag = hashlib.sha1(" ".join(defines).encode()).hexdigest()[:8] if defines else "std"
+    hdr_time = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
+    hdr_time = max(hdr_time, os.path.getmtime(os.path.join(HERE, "..", "include", "blsw.h")))
+    jobs, objs = [], []
+    for src in HOST_SOURCES + SOURCES:
+        obj = os.path.join(OBJ, "%s.%s.o" % (os.path.splitext(src)[0], tag))
         objs.append(obj)
-    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-o", out or OUT] + list(defines) + [os.path.join(CSRC, s) for s in SOURCES] + ["-Wl," + o for o in objs]  # objects go straight to the linker (hipcc would read them as HIP source)
+        path = os.path.join(CSRC, src)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), hdr_time):
+            continue
+        if src.endswith(".cpp"):
+            cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas", "-c", path, "-o", obj]
+            jobs.append((cmd, None))
+        else:
+            cmd = [hipcc] + HIP_FLAGS + list(defines) + ["-c", path, "-o", obj, "-Rpass-analysis=kernel-resource-usage"]
+            jobs.append((cmd, obj + ".log"))
     if verbose:
-        cmd.append("-Rpass-analysis=kernel-resource-usage")
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd, cwd=CSRC)
-    return OUT
+        print("compiling %d units" % len(jobs), file=sys.stderr)
+    with concurrent.futures.ThreadPoolExecutor(max_workers=max(1, min(8, os.cpu_count() or 1))) as ex:
+        list(ex.map(_compile, jobs))
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out or OUT] + objs, cwd=CSRC)
+    return out or OUT
+
+
+def resource_table(tag="std"):
+    """kernel -> registers / scratch / occupancy, from the compile logs (-Rpass-analysis=kernel-resource-usage)"""
+    import re
+
+    rows = []
+    for f in sorted(os.listdir(OBJ)):
+        if not f.endswith(".%s.o.log" % tag):
+            continue
+        cur = None
+        for ln in open(os.path.join(OBJ, f)):
+            m = re.search(r"Function Name: (\S+)", ln)
+            if m:
+                cur = {"name": m.group(1)}
+                rows.append(cur)
+                continue
+            m = re.search(r"remark: .*?    (VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|VGPRs Spill|LDS Size \[bytes/block\]): (\S+)", ln)
+            if m and cur is not None:
+                cur[m.group(1).split(" [")[0]] = int(m.group(2))
+    return rows
 
 
 if __name__ == "__main__":
-    # python build.py [--force] [--out <file.so> -DNAME=VALUE ...]
+    # python build.py [--force] [--table] [--out <file.so> -DNAME=VALUE ...]
     out = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else None
-    build(force="--force" in sys.argv, verbose=out is None, out=out, defines=[a for a in sys.argv[1:] if a.startswith("-D")])
+    defs = [a for a in sys.argv[1:] if a.startswith("-D")]
+    build(force="--force" in sys.argv, verbose=True, out=out, defines=defs)
+    if "--table" in sys.argv:
+        tag = hashlib.sha1(" ".join(defs).encode()).hexdigest()[:8] if defs else "std"
+        for r in resource_table(tag):
+            name = r["name"]
+            if "k_sha_expand" in name and "ILi384ELi8ELi16ELi0" not in name:
+                continue
+            print("%-60s VGPR %3d AGPR %3d scratch %5d occupancy %d spilled %4d LDS %5d" % (name[:60], r.get("VGPRs", 0), r.get("AGPRs", 0), r.get("ScratchSize", 0), r.get("Occupancy", 0), r.get("VGPRs Spill", 0), r.get("LDS Size", 0)))

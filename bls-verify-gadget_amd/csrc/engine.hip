@@ -1,0 +1,881 @@
+// libblsw.so — the execution engine and the C ABI of include/blsw.h (host code; the kernels are in k_*.hip).
+#include <deque>
+#include "kcommon.cuh"
+
+using namespace blsw;
+
+namespace {
+
+inline int hip_ok(hipError_t e, const char* what) {
+    if (e != hipSuccess) {
+        fprintf(stderr, "[blsw] %s: %s\n", what, hipGetErrorString(e));
+        return BLSW_ERR_HIP;
+    }
+    return BLSW_OK;
+}
+
+// RAII: every ABI entry point of an engine runs on the engine's device and restores the caller's
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int dev) {
+        if (dev < 0) return;
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (switched) hipSetDevice(prev);
+    }
+};
+
+}  // namespace
+
+// Execution engine. Batches ("steps") are SUBMITTED with their input/output pointers and processed in GROUPS of up
+// to max_steps batches by one set of launches (N = steps * n lanes per chain kernel), which is what fills the chip:
+// one batch of 1024 instances is only 16 waves per chain. Streams (the runtime backs the streams of ONE priority level
+// with four hardware queues; streams that share a queue serialise, so the engine uses three levels and few streams):
+//   engine-wide, high priority:  sha    : SHA witness bits of every group, in order (needs only msg)  -> ev_sha per group
+//                                expand : k_sha_expand per step (bit -> Fp, 31 MB of the 34 MB per instance, the HBM-bound
+//                                         kernel), as soon as the group's SHA bits exist: it never waits for the curve /
+//                                         pairing chains, so a short job does not pay their latency before its HBM stream
+//                                place  : k_place_field per step (staging -> its place around the SHA segment), once the
+//                                         group's chains are done and the step's expansion has finished
+//   per group buffer:   normal   main : sha_values -> map -> cofactor -> prepare(H) .......... -> pairing   -> ev_chains
+//                       low      aux  : prepare(sig), g1_alloc, g2_alloc  (need only pk / sig)   -> ev_aux
+// Field witnesses go to a staging area (coalesced stores). n_buffers group buffers rotate, so the next groups' chains
+// overlap the previous groups' placement.
+// Materialisation (expand + place of a step into its output) is a queue of jobs in submission order (pump): a free-running
+// engine issues a group's jobs when the group is launched; in consumer mode (options.consumer_mode) a job waits until the
+// consumer has released its output's previous user, so the 34 MB vectors exist only between expansion and consumption and
+// the output ring can be smaller than a group. A step can also leave in compact form (its slices of the staging, copied).
+#define BLSW_MAX_BUFFERS 32
+#define BLSW_DEFAULT_EXPAND_VARIANT 0  // 384 x 8: the geometry that stays fast beside every chain build (profiles/r02_ab_fpmul_expand.txt)
+#define BLSW_MAX_TIMED 1024
+#define BLSW_MAX_CONSUMED 64
+struct GroupBuf {
+    void* base = nullptr;
+    StepDesc* h_desc = nullptr;  // pinned host
+    StepDesc* d_desc = nullptr;
+    hipStream_t st[2] = {nullptr, nullptr};  // main, aux
+    hipEvent_t ev_start = nullptr, ev_aux = nullptr, ev_sha = nullptr, ev_chains = nullptr, ev_done = nullptr;
+    hipEvent_t* ev_in = nullptr;    // [max_steps] inputs of step s valid (recorded on the submitting stream)
+    hipEvent_t* ev_x = nullptr;     // [max_steps] expansion of step s issued and finished
+    hipEvent_t* ev_step = nullptr;  // [max_steps] step s complete (witness tensor + results)
+    uint64_t first_seq = 0;
+    uint32_t steps = 0;
+    bool used = false;
+    Workspace ws;            // of the group launched last from this buffer
+    uint32_t jobs_left = 0;  // its steps whose expansion / placement has not been issued yet
+};
+struct Job {  // materialisation of one step: bit expansion + field placement into its output (or its compact form)
+    int buf;
+    uint32_t s;
+};
+struct blsw_engine {
+    uint64_t n = 0;
+    uint32_t msg_len = 0, max_steps = 0;
+    blsw_layout_t L, LS;
+    Modes modes = DEFAULT_MODES;
+    blsw_engine_options_t opt;
+    int device = -1;
+    GroupBuf buf[BLSW_MAX_BUFFERS];
+    int nbuf = 0;
+    int cur = 0;
+    uint32_t pending = 0;
+    uint64_t submitted = 0, launched = 0, materialised = 0;
+    std::deque<Job> jobs;  // steps whose chains are issued, in submission order, waiting for their output to be free (consumer mode)
+    hipStream_t sha = nullptr, expand = nullptr, place = nullptr;
+    // HIP event pairs around every k_sha_expand launch since the last stats reset (live roofline measurement)
+    hipEvent_t* ev_exp = nullptr;  // 2 * BLSW_MAX_TIMED events
+    uint32_t n_timed = 0;
+    // consumer releases: output tensor pointer -> event after which it may be overwritten
+    const void* consumed_ptr[BLSW_MAX_CONSUMED];
+    hipEvent_t consumed_ev[BLSW_MAX_CONSUMED];
+    bool consumed_live[BLSW_MAX_CONSUMED];  // a release has been recorded and not yet waited for
+    bool held[BLSW_MAX_CONSUMED];           // consumer mode: a step was materialised into this output and it has not been released
+    bool staged = false;  // false: direct mode (max_steps == 1, no staging; witnesses written in place by the chains)
+};
+
+static void engine_free(blsw_engine* e) {
+    if (!e) return;
+    for (int k = 0; k < BLSW_MAX_BUFFERS; k++) {
+        GroupBuf& b = e->buf[k];
+        if (b.h_desc) hipHostFree(b.h_desc);
+        if (b.d_desc) hipFree(b.d_desc);
+        for (int i = 0; i < 2; i++)
+            if (b.st[i]) hipStreamDestroy(b.st[i]);
+        hipEvent_t single[] = {b.ev_start, b.ev_aux, b.ev_sha, b.ev_chains, b.ev_done};
+        for (hipEvent_t ev : single)
+            if (ev) hipEventDestroy(ev);
+        hipEvent_t* arrays[] = {b.ev_in, b.ev_x, b.ev_step};
+        for (hipEvent_t* arr : arrays) {
+            if (!arr) continue;
+            for (uint32_t s = 0; s < e->max_steps; s++)
+                if (arr[s]) hipEventDestroy(arr[s]);
+            delete[] arr;
+        }
+    }
+    if (e->sha) hipStreamDestroy(e->sha);
+    if (e->expand) hipStreamDestroy(e->expand);
+    if (e->place) hipStreamDestroy(e->place);
+    if (e->ev_exp) {
+        for (int i = 0; i < 2 * BLSW_MAX_TIMED; i++)
+            if (e->ev_exp[i]) hipEventDestroy(e->ev_exp[i]);
+        delete[] e->ev_exp;
+    }
+    for (int i = 0; i < BLSW_MAX_CONSUMED; i++)
+        if (e->consumed_ev[i]) hipEventDestroy(e->consumed_ev[i]);
+    delete e;
+}
+
+// field witnesses of one step: staged rows (lanes first .. first + n of the tiles at `staging` / the rows at `pair`) -> their
+// places around the SHA segment of the step's witness vectors
+static void launch_place(blsw_engine* e, hipStream_t st, const Fp* staging, const Fp* pair, uint32_t split_row, uint64_t first, uint64_t* out, uint64_t out_stride) {
+    const uint32_t rows = e->L.n_witness - e->L.sha_bits;
+    const unsigned chunks = (rows * 3 + 256 * BLSW_PLACE_ITERS - 1) / (256 * BLSW_PLACE_ITERS);
+    dim3 grid2(8 * ((chunks + 7) / 8) * (unsigned)e->n);
+    hipLaunchKernelGGL(k_place_field, grid2, dim3(256), 0, st, staging, pair, first, e->L.off_expand, e->L.sha_bits, rows, split_row, out, out_stride, (uint32_t)e->n,
+                       e->L.off_sig_alloc, e->modes.g2_team ? e->L.off_pk_not_zero - e->L.off_sig_alloc : 0u, e->LS.off_sig_alloc);
+}
+static void launch_canonical(blsw_engine* e, hipStream_t st, uint64_t* out, uint64_t out_stride) {
+    const uint32_t rows = e->L.n_witness - e->L.sha_bits;
+    hipLaunchKernelGGL(k_canonical_rows, dim3((rows + 255) / 256, (unsigned)e->n), dim3(256), 0, st, out, out_stride, e->L.off_expand, e->L.sha_bits, rows);
+}
+
+#ifdef BLSW_DEBUG_KNOBS  // timing experiments only (wrong witnesses): BLSW_DEBUG_SKIP bit 0 chains, bit 1 placement, bit 2 expansion
+static const uint32_t dbg_skip = getenv("BLSW_DEBUG_SKIP") ? (uint32_t)atoi(getenv("BLSW_DEBUG_SKIP")) : 0u;
+#else
+constexpr uint32_t dbg_skip = 0;
+#endif
+
+static int consumed_slot(blsw_engine* e, const void* ptr) {
+    for (int c = 0; c < BLSW_MAX_CONSUMED; c++)
+        if (e->consumed_ptr[c] == ptr && (e->consumed_live[c] || e->held[c])) return c;
+    return -1;
+}
+// a consumer's release of an output (blsw_engine_output_consumed): the stream that is about to overwrite it waits for it
+static void wait_released(blsw_engine* e, hipStream_t stream, const void* ptr) {
+    const int c = consumed_slot(e, ptr);
+    if (c >= 0 && e->consumed_live[c]) {
+        hipStreamWaitEvent(stream, e->consumed_ev[c], 0);
+        e->consumed_live[c] = false;
+    }
+}
+// Issues the expansion (expansion stream: needs the group's SHA bits) and the field placement (placement stream: needs the
+// group's chains) of step s of buffer k. A step is complete after both.
+static void materialise(blsw_engine* e, int k, uint32_t s) {
+    GroupBuf& b = e->buf[k];
+    const StepDesc& d = b.h_desc[s];
+    const Workspace& ws = b.ws;
+    const CompactForm cf = compact_form(e->n, ws);
+    hipStreamWaitEvent(e->expand, b.ev_sha, 0);
+    if (d.compact) {  // the step's bit words leave as they are
+        wait_released(e, e->expand, d.compact);
+        hipMemcpyAsync(d.compact, ws.bits + (uint64_t)s * (e->n / 64) * bits_tile_words(ws.sha_words), cf.bits_bytes, hipMemcpyDeviceToDevice, e->expand);
+    }
+    if (d.out) {
+        wait_released(e, e->expand, d.out);
+        const bool timed = e->n_timed < BLSW_MAX_TIMED;
+        if (timed) hipEventRecord(e->ev_exp[2 * e->n_timed], e->expand);
+        ExpandArgs xa = {ws.bits, ws.sha_words, (uint64_t)s * e->n, e->L.sha_bits, e->L.off_expand, d.out, d.out_stride, 1u, 0u, 0, (int)e->opt.output_form};
+        if (!(dbg_skip & 4)) launch_expand(e->opt.expand_variant, e->opt.expand_store, e->opt.place_lds, e->expand, xa, (unsigned)e->n);
+        if (timed) {
+            hipEventRecord(e->ev_exp[2 * e->n_timed + 1], e->expand);
+            e->n_timed++;
+        }
+    }
+    hipEventRecord(b.ev_x[s], e->expand);
+    hipStreamWaitEvent(e->place, b.ev_chains, 0);
+    hipStreamWaitEvent(e->place, b.ev_x[s], 0);
+    if (d.compact) {  // and so do its staged field witnesses
+        char* dst = reinterpret_cast<char*>(d.compact);
+        hipMemcpyAsync(dst + cf.off_staging, ws.staging + (uint64_t)s * (e->n / 64) * ws.split_row * 64, cf.staging_bytes, hipMemcpyDeviceToDevice, e->place);
+        if (cf.pair_bytes) hipMemcpyAsync(dst + cf.off_pair, ws.pair + (uint64_t)s * e->n * ws.pair_rows, cf.pair_bytes, hipMemcpyDeviceToDevice, e->place);
+    }
+    if (d.out && e->staged && !(dbg_skip & 2)) launch_place(e, e->place, ws.staging, ws.pair, ws.split_row, (uint64_t)s * e->n, d.out, d.out_stride);
+    if (d.out && e->opt.output_form) launch_canonical(e, e->place, d.out, d.out_stride);  // direct mode: the chains wrote the rows in place
+    hipEventRecord(b.ev_step[s], e->place);
+}
+// Materialises queued steps in submission order. Free-running engines (consumer_mode 0) issue every step as soon as its
+// group is launched; in consumer mode a step whose output still holds an unreleased earlier step stops the queue until
+// blsw_engine_output_consumed names that output.
+static int pump(blsw_engine* e) {
+    while (!e->jobs.empty()) {
+        const Job j = e->jobs.front();
+        GroupBuf& b = e->buf[j.buf];
+        const StepDesc& d = b.h_desc[j.s];
+        const void* ptr = d.out ? static_cast<const void*>(d.out) : d.compact;
+        const bool track = e->opt.consumer_mode && e->staged && ptr;
+        if (track) {
+            const int c = consumed_slot(e, ptr);
+            if (c >= 0 && e->held[c]) break;
+        }
+        materialise(e, j.buf, j.s);
+        if (track) {
+            int c = consumed_slot(e, ptr);
+            for (int i = 0; i < BLSW_MAX_CONSUMED && c < 0; i++)
+                if (!e->consumed_live[i] && !e->held[i]) c = i;
+            if (c < 0) return BLSW_ERR_ARG;  // more than BLSW_MAX_CONSUMED outputs in use
+            e->consumed_ptr[c] = ptr;
+            e->held[c] = true;
+        }
+        e->jobs.pop_front();
+        e->materialised++;
+        if (--b.jobs_left == 0) hipEventRecord(b.ev_done, e->place);
+    }
+    return hip_ok(hipGetLastError(), "materialise");
+}
+
+static int launch_group(blsw_engine* e) {
+    GroupBuf& b = e->buf[e->cur];
+    const uint32_t steps = e->pending;
+    if (steps == 0) return BLSW_OK;
+    Group g;
+    g.N = (uint64_t)steps * e->n;
+    g.n = (uint32_t)e->n;
+    g.K = 1;
+    g.msg_len = e->msg_len;
+    g.desc = b.d_desc;
+    g.L = e->L;
+    g.LS = e->LS;
+    g.ws = carve(b.base, g.N, e->L, e->staged, e->modes);
+    g.chain_prio = e->opt.prio_mode == 0;
+    const unsigned g1 = (unsigned)((g.N + 63) / 64), g2 = (unsigned)((2 * g.N + 63) / 64);
+    const unsigned gt = (unsigned)((g.N + BLSW_TEAMS_PER_WAVE - 1) / BLSW_TEAMS_PER_WAVE);
+    hipStream_t st = b.st[0];
+    // inputs of every step are ready once its submitting stream reached the point of the submit
+    for (uint32_t s = 0; s < steps; s++) hipStreamWaitEvent(st, b.ev_in[s], 0);
+    bool any_out = false;
+    for (uint32_t s = 0; s < steps; s++) any_out = any_out || b.h_desc[s].out != nullptr || b.h_desc[s].compact != nullptr;
+    // direct mode: the chains themselves write into the output tensors, so they wait for the consumer's release
+    if (!e->staged)
+        for (uint32_t s = 0; s < steps; s++)
+            if (b.h_desc[s].out) wait_released(e, st, b.h_desc[s].out);
+    hipMemcpyAsync(b.d_desc, b.h_desc, sizeof(StepDesc) * steps, hipMemcpyHostToDevice, st);
+    hipEventRecord(b.ev_start, st);
+    hipStreamWaitEvent(b.st[1], b.ev_start, 0);
+    // sha: the witness bits of the in-circuit SHA-256 (first: the expansion stream is waiting for them)
+    hipStreamWaitEvent(e->sha, b.ev_start, 0);
+    if (any_out) hipLaunchKernelGGL(k_sha, dim3(g1), dim3(64), 0, e->sha, g, 1, 0);
+    hipEventRecord(b.ev_sha, e->sha);
+    // main, first part: the hash-to-G2 critical path
+    if (!(dbg_skip & 1)) {
+    hipLaunchKernelGGL(k_sha_values, dim3(g1), dim3(64), 0, st, g);
+    hipLaunchKernelGGL(k_map, dim3(g2), dim3(64), 0, st, g);
+    hipLaunchKernelGGL(k_cofactor, dim3(g1), dim3(64), 0, st, g);
+    hipLaunchKernelGGL(k_prepare, dim3(g1), dim3(64), 0, st, g, 0);
+    // aux: prepare_g2(sig) and the group allocations (53 ms alone beside the 86 ms of the main stream's first part)
+    hipLaunchKernelGGL(k_prepare, dim3(g1), dim3(64), 0, b.st[1], g, 1);
+    if (e->L.n_keys) {  // aggregate_verify: one lane per (instance, key) allocates, then mapped_aggregate + pk != 0 + prepare_g1 per instance
+        hipLaunchKernelGGL(k_agg_keys, dim3((unsigned)((g.N * e->L.n_keys + 63) / 64)), dim3(64), 0, b.st[1], g, g.ws.keyproj);
+        hipLaunchKernelGGL(k_agg_sum, dim3(g1), dim3(64), 0, b.st[1], g, (const Fp*)g.ws.keyproj);
+    } else
+        hipLaunchKernelGGL(k_g1, dim3(g1), dim3(64), 0, b.st[1], g);
+    if (e->modes.g2_team)
+        hipLaunchKernelGGL(k_g2_alloc_team, dim3(gt), dim3(64), 0, b.st[1], g);
+    else
+        hipLaunchKernelGGL(k_g2_alloc, dim3(g1), dim3(64), 0, b.st[1], g);
+    }
+    hipEventRecord(b.ev_aux, b.st[1]);
+    // main, second part: the pairing
+    hipStreamWaitEvent(st, b.ev_aux, 0);
+    if (!(dbg_skip & 1)) launch_pairing(g, e->modes, st);
+    hipStreamWaitEvent(st, b.ev_sha, 0);
+    hipEventRecord(b.ev_chains, st);
+    // expansion + placement of the group's steps: queued, issued in submission order (at once unless a consumer holds an output)
+    b.ws = g.ws;
+    b.jobs_left = steps;
+    for (uint32_t s = 0; s < steps; s++) e->jobs.push_back({e->cur, s});
+    b.used = true;
+    b.first_seq = e->launched;
+    b.steps = steps;
+    e->launched += steps;
+    e->pending = 0;
+    e->cur = (e->cur + 1) % e->nbuf;
+    if (hip_ok(hipGetLastError(), "launch")) return BLSW_ERR_HIP;
+    return pump(e);
+}
+
+static uint32_t env_u32(const char* name, uint32_t dflt) {
+    const char* s = getenv(name);
+    return s && *s ? (uint32_t)strtoul(s, nullptr, 10) : dflt;
+}
+
+extern "C" {
+
+int blsw_version(void) { return BLSW_ABI_VERSION; }
+
+int blsw_layout(uint32_t msg_len, blsw_layout_t* out) {
+    if (!out || msg_len > 65535) return BLSW_ERR_ARG;
+    make_layout(msg_len, out);
+    return BLSW_OK;
+}
+
+int blsw_engine_options_default(blsw_engine_options_t* o) {
+    if (!o) return BLSW_ERR_ARG;
+    const char* p = getenv("BLSW_PAIRING");
+    const char* g2 = getenv("BLSW_G2");
+    o->device = -1;
+    o->n_keys = 0;
+    o->pairing_mode = (p && p[0] == 'l') ? 1u : 0u;
+    o->g2_mode = (g2 && g2[0] == 't' && o->pairing_mode == 0) ? 1u : 0u;
+    o->expand_variant = env_u32("BLSW_EXPAND_VARIANT", BLSW_DEFAULT_EXPAND_VARIANT);
+    o->expand_store = env_u32("BLSW_EXPAND_NT", 0);  // plain stores: nontemporal ones cost 8-10 % since the chains' stack traffic was cut
+    o->prio_mode = env_u32("BLSW_PRIO_MODE", 1);
+    o->place_lds = env_u32("BLSW_PLACE_LDS", 0);
+    o->consumer_mode = 0;
+    o->output_form = 0;
+    return BLSW_OK;
+}
+
+int blsw_engine_workspace_bytes_ex(uint64_t n, uint32_t msg_len, uint32_t max_steps, uint32_t n_buffers, const blsw_engine_options_t* options, uint64_t* bytes) {
+    if (!bytes || n == 0 || max_steps == 0 || n_buffers == 0 || n_buffers > BLSW_MAX_BUFFERS || msg_len > 65535 || !options || options->n_keys > 65535)
+        return BLSW_ERR_ARG;
+    blsw_layout_t L;
+    make_layout(msg_len, &L, options->n_keys);
+    const bool staged = max_steps > 1 || n_buffers > 1;
+    // the same workspace serves every kernel variant: the largest carve of the three mode combinations
+    uint64_t need = 0;
+    const Modes all[3] = {{true, false}, {true, true}, {false, false}};
+    for (const Modes& m : all) {
+        uint64_t t = carve(nullptr, n * max_steps, L, staged, m).total_bytes;
+        need = t > need ? t : need;
+    }
+    *bytes = (uint64_t)n_buffers * align_up(need, 4096);
+    return BLSW_OK;
+}
+int blsw_engine_workspace_bytes(uint64_t n, uint32_t msg_len, uint32_t max_steps, uint32_t n_buffers, uint64_t* bytes) {
+    blsw_engine_options_t o;
+    blsw_engine_options_default(&o);
+    return blsw_engine_workspace_bytes_ex(n, msg_len, max_steps, n_buffers, &o, bytes);
+}
+
+int blsw_engine_create_ex(blsw_engine_t** out, uint64_t n, uint32_t msg_len, uint32_t max_steps, uint32_t n_buffers, const blsw_engine_options_t* options,
+                          void* d_workspace, uint64_t workspace_bytes) {
+    if (!out || n == 0 || n > 0x7fffffffu || max_steps == 0 || !d_workspace || n_buffers == 0 || n_buffers > BLSW_MAX_BUFFERS || !options || msg_len > 65535)
+        return BLSW_ERR_ARG;
+    if (options->pairing_mode > 1 || options->g2_mode > 1 || (options->g2_mode == 1 && options->pairing_mode != 0) || options->expand_store > 3 ||
+        options->prio_mode > 2 || options->output_form > 1 || (options->expand_variant & 0xff) > 5 || (options->expand_variant >> 9) || options->n_keys > 65535 ||
+        (options->n_keys && options->g2_mode))
+        return BLSW_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return BLSW_ERR_NO_DEVICE;
+    int dev = options->device;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return BLSW_ERR_NO_DEVICE;
+    if (dev >= ndev) return BLSW_ERR_ARG;
+    DeviceGuard guard(dev);
+    uint64_t need = 0;
+    if (blsw_engine_workspace_bytes_ex(n, msg_len, max_steps, n_buffers, options, &need)) return BLSW_ERR_ARG;
+    if (workspace_bytes < need) return BLSW_ERR_WORKSPACE;
+    // Scratch guard. ROCr backs a queue's scratch for full-device occupancy: stack bytes per lane x 64 lanes x wave slots
+    // (CUs x 32), per queue that runs the kernel. The single-lane pairing kernel (9.7 KB of stack) on four or more group
+    // buffers made the runtime abort with HSA_STATUS_ERROR_OUT_OF_RESOURCES; refuse instead.
+    if (options->pairing_mode == 1) {
+        hipFuncAttributes fa;
+        int cus = 256;
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        uint64_t stack = 10240;
+        if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_pairing)) == hipSuccess && fa.localSizeBytes) stack = fa.localSizeBytes;
+        const uint64_t projected = stack * 64ull * (uint64_t)cus * 32ull * n_buffers;
+        if (projected > (16ull << 30)) {
+            fprintf(stderr, "[blsw] pairing_mode 1 with %u group buffers needs about %.1f GB of per-queue scratch: refused (use pairing_mode 0 or n_buffers <= 3)\n",
+                    n_buffers, projected / 1e9);
+            return BLSW_ERR_SCRATCH;
+        }
+    }
+    blsw_engine* e = new blsw_engine();
+    e->n = n;
+    e->msg_len = msg_len;
+    e->max_steps = max_steps;
+    e->opt = *options;
+    e->opt.device = dev;
+    e->device = dev;
+    e->modes = {options->pairing_mode == 0, options->g2_mode == 1};
+    e->staged = max_steps > 1 || n_buffers > 1;
+    make_layout(msg_len, &e->L, options->n_keys);
+    e->LS = staging_layout(e->L, e->modes);
+    for (int i = 0; i < BLSW_MAX_CONSUMED; i++) {
+        e->consumed_ptr[i] = nullptr;
+        e->consumed_ev[i] = nullptr;
+        e->consumed_live[i] = false;
+        e->held[i] = false;
+    }
+    e->nbuf = (int)n_buffers;
+    int rc = BLSW_OK;
+    auto chk = [&](hipError_t err, const char* what) {
+        if (rc == BLSW_OK && hip_ok(err, what)) rc = BLSW_ERR_HIP;
+        return rc == BLSW_OK;
+    };
+    e->ev_exp = new hipEvent_t[2 * BLSW_MAX_TIMED]();
+    for (int i = 0; i < 2 * BLSW_MAX_TIMED && rc == BLSW_OK; i++) chk(hipEventCreate(&e->ev_exp[i]), "event create");
+    int prio_lo = 0, prio_hi = 0;
+    chk(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi), "priority range");  // (least, greatest): numerically lower = higher priority
+    // three priority levels = three pools of hardware queues: [placement, main chains, aux chains] from high to low
+    // (prio_mode 1, default), [main, aux, placement] (prio_mode 0) or everything at the middle level (prio_mode 2)
+    const int prio_mid = (prio_hi + 1 <= prio_lo) ? prio_hi + 1 : prio_lo;  // -1 high, 0 normal, 1 low on this runtime
+    int place_prio = prio_hi, main_prio = prio_mid, aux_prio = prio_lo;
+    if (e->opt.prio_mode == 0) place_prio = prio_lo, main_prio = prio_hi, aux_prio = prio_mid;
+    if (e->opt.prio_mode == 2) place_prio = main_prio = aux_prio = prio_mid;
+    for (int k = 0; k < e->nbuf && rc == BLSW_OK; k++) {
+        GroupBuf& b = e->buf[k];
+        b.base = reinterpret_cast<char*>(d_workspace) + (uint64_t)k * (need / e->nbuf);
+        chk(hipHostMalloc(reinterpret_cast<void**>(&b.h_desc), sizeof(StepDesc) * max_steps, hipHostMallocDefault), "host alloc");
+        chk(hipMalloc(reinterpret_cast<void**>(&b.d_desc), sizeof(StepDesc) * max_steps), "desc alloc");
+        chk(hipStreamCreateWithPriority(&b.st[0], hipStreamNonBlocking, main_prio), "stream create");
+        chk(hipStreamCreateWithPriority(&b.st[1], hipStreamNonBlocking, aux_prio), "stream create");
+        hipEvent_t* single[] = {&b.ev_start, &b.ev_aux, &b.ev_sha, &b.ev_chains, &b.ev_done};
+        for (hipEvent_t* ev : single) chk(hipEventCreateWithFlags(ev, hipEventDisableTiming), "event create");
+        b.ev_in = new hipEvent_t[max_steps]();
+        b.ev_x = new hipEvent_t[max_steps]();
+        b.ev_step = new hipEvent_t[max_steps]();
+        for (uint32_t s = 0; s < max_steps && rc == BLSW_OK; s++) {
+            chk(hipEventCreateWithFlags(&b.ev_in[s], hipEventDisableTiming), "event create");
+            chk(hipEventCreateWithFlags(&b.ev_x[s], hipEventDisableTiming), "event create");
+            chk(hipEventCreateWithFlags(&b.ev_step[s], hipEventDisableTiming), "event create");
+        }
+    }
+    chk(hipStreamCreateWithPriority(&e->sha, hipStreamNonBlocking, place_prio), "stream create");
+    chk(hipStreamCreateWithPriority(&e->expand, hipStreamNonBlocking, place_prio), "stream create");
+    chk(hipStreamCreateWithPriority(&e->place, hipStreamNonBlocking, place_prio), "stream create");
+    // Scratch pre-warm. The pairing kernel has the largest stack (4.5 KB per lane): the first launch of a full-size group on
+    // a queue makes the runtime grow that queue's scratch, which stalls the queue for ~60 ms (measured: the pairing of the
+    // first group of every buffer started 60 ms late). One launch of the same grid with N = 0 (every wave exits at once)
+    // per main stream pays that here instead of in the caller's first groups.
+    if (rc == BLSW_OK) {
+        Group g0;
+        memset(&g0, 0, sizeof(g0));
+        g0.n = (uint32_t)n;
+        g0.K = 1;
+        const uint64_t Nmax = n * max_steps;
+        for (int k = 0; k < e->nbuf; k++) {
+            if (e->modes.pairing_team)
+                hipLaunchKernelGGL(k_pairing_team, dim3((unsigned)((Nmax + BLSW_TEAMS_PER_WAVE - 1) / BLSW_TEAMS_PER_WAVE)), dim3(64), 0, e->buf[k].st[0], g0);
+            else
+                hipLaunchKernelGGL(k_pairing, dim3((unsigned)((Nmax + 63) / 64)), dim3(64), 0, e->buf[k].st[0], g0);
+        }
+        for (int k = 0; k < e->nbuf; k++) chk(hipStreamSynchronize(e->buf[k].st[0]), "scratch pre-warm");
+    }
+    if (rc != BLSW_OK) {
+        engine_free(e);
+        return rc;
+    }
+    *out = e;
+    return BLSW_OK;
+}
+
+int blsw_engine_create(blsw_engine_t** out, uint64_t n, uint32_t msg_len, uint32_t max_steps, uint32_t n_buffers, void* d_workspace,
+                       uint64_t workspace_bytes) {
+    blsw_engine_options_t o;
+    blsw_engine_options_default(&o);
+    return blsw_engine_create_ex(out, n, msg_len, max_steps, n_buffers, &o, d_workspace, workspace_bytes);
+}
+
+int blsw_engine_destroy(blsw_engine_t* e) {
+    if (!e) return BLSW_ERR_ARG;
+    DeviceGuard guard(e->device);
+    hipDeviceSynchronize();
+    engine_free(e);
+    return BLSW_OK;
+}
+
+static int engine_submit(blsw_engine_t* e, const StepDesc& step, void* stream_) {
+    if (step.out && step.out_stride < e->L.n_witness) return BLSW_ERR_ARG;
+    DeviceGuard guard(e->device);
+    GroupBuf& b = e->buf[e->cur];
+    if (e->pending == 0 && b.used) {
+        // the buffer's previous group must have been fully placed before its staging is overwritten; in consumer mode some of
+        // its steps may still wait for their outputs: the caller has to drain (wait_step / output_consumed) first
+        if (b.jobs_left) return BLSW_ERR_BUSY;
+        if (hip_ok(hipEventSynchronize(b.ev_done), "event sync")) return BLSW_ERR_HIP;
+        b.used = false;
+    }
+    if (hip_ok(hipEventRecord(b.ev_in[e->pending], reinterpret_cast<hipStream_t>(stream_)), "event record")) return BLSW_ERR_HIP;
+    b.h_desc[e->pending] = step;
+    e->pending++;
+    e->submitted++;
+    if (e->pending == e->max_steps) return launch_group(e);
+    return BLSW_OK;
+}
+int blsw_engine_submit(blsw_engine_t* e, const uint64_t* d_pk_xy, const uint64_t* d_sig_xy, const uint8_t* d_msg, uint64_t* d_witness,
+                       uint64_t witness_stride, int32_t* d_result, void* stream_) {
+    if (!e || e->L.n_keys || !d_pk_xy || !d_sig_xy || (!d_msg && e->msg_len)) return BLSW_ERR_ARG;
+    StepDesc d = {d_pk_xy, d_sig_xy, d_msg, d_witness, witness_stride, d_result, nullptr, nullptr, nullptr, nullptr};
+    return engine_submit(e, d, stream_);
+}
+// aggregate_verify through the engine (an engine created with options.n_keys = K): one batch of n instances of K keys each
+int blsw_engine_submit_aggregate(blsw_engine_t* e, const uint64_t* d_pks_xy, const uint8_t* d_bitmap, const uint64_t* d_sig_xy, const uint8_t* d_msg,
+                                 uint64_t* d_witness, uint64_t witness_stride, int32_t* d_result, uint32_t* d_count, void* stream_) {
+    if (!e || !e->L.n_keys || !d_pks_xy || !d_bitmap || !d_sig_xy || (!d_msg && e->msg_len)) return BLSW_ERR_ARG;
+    StepDesc d = {nullptr, d_sig_xy, d_msg, d_witness, witness_stride, d_result, d_pks_xy, d_bitmap, d_count, nullptr};
+    return engine_submit(e, d, stream_);
+}
+
+// Compact wire form (the all-gather of full witness vectors is capped by xGMI at a fraction of the generation
+// rate; 2.6 MB per instance travel instead of 34 MB and the receiver expands them).
+int blsw_engine_compact_bytes(blsw_engine_t* e, uint64_t* bytes) {
+    if (!e || !bytes || !e->staged || e->n % 64) return BLSW_ERR_ARG;
+    *bytes = compact_form(e->n, carve(nullptr, e->n, e->L, true, e->modes)).total;
+    return BLSW_OK;
+}
+int blsw_engine_submit_compact(blsw_engine_t* e, const uint64_t* d_pk_xy, const uint64_t* d_sig_xy, const uint8_t* d_msg, void* d_compact, int32_t* d_result,
+                               void* stream_) {
+    if (!e || e->L.n_keys || !e->staged || e->n % 64 || !d_compact || !d_pk_xy || !d_sig_xy || (!d_msg && e->msg_len)) return BLSW_ERR_ARG;
+    StepDesc d = {d_pk_xy, d_sig_xy, d_msg, nullptr, 0, d_result, nullptr, nullptr, nullptr, d_compact};
+    return engine_submit(e, d, stream_);
+}
+int blsw_engine_submit_aggregate_compact(blsw_engine_t* e, const uint64_t* d_pks_xy, const uint8_t* d_bitmap, const uint64_t* d_sig_xy, const uint8_t* d_msg,
+                                         void* d_compact, int32_t* d_result, uint32_t* d_count, void* stream_) {
+    if (!e || !e->L.n_keys || !e->staged || e->n % 64 || !d_compact || !d_pks_xy || !d_bitmap || !d_sig_xy || (!d_msg && e->msg_len)) return BLSW_ERR_ARG;
+    StepDesc d = {nullptr, d_sig_xy, d_msg, nullptr, 0, d_result, d_pks_xy, d_bitmap, d_count, d_compact};
+    return engine_submit(e, d, stream_);
+}
+// receiver side: one batch in compact form -> its n witness vectors, on `stream` (the expansion and placement kernels of the
+// engine's own steps, pointed at the compact buffer)
+int blsw_engine_expand_compact(blsw_engine_t* e, const void* d_compact, uint64_t* d_witness, uint64_t witness_stride, void* stream_) {
+    if (!e || !e->staged || e->n % 64 || !d_compact || !d_witness || witness_stride < e->L.n_witness) return BLSW_ERR_ARG;
+    DeviceGuard guard(e->device);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream_);
+    const Workspace w = carve(nullptr, e->n, e->L, true, e->modes);
+    const CompactForm cf = compact_form(e->n, w);
+    const char* src = reinterpret_cast<const char*>(d_compact);
+    ExpandArgs xa = {reinterpret_cast<const uint32_t*>(src), w.sha_words, 0, e->L.sha_bits, e->L.off_expand, d_witness, witness_stride, 1u, 0u, 0, (int)e->opt.output_form};
+    launch_expand(e->opt.expand_variant, e->opt.expand_store, e->opt.place_lds, st, xa, (unsigned)e->n);
+    launch_place(e, st, reinterpret_cast<const Fp*>(src + cf.off_staging), reinterpret_cast<const Fp*>(src + cf.off_pair), w.split_row, 0, d_witness, witness_stride);
+    if (e->opt.output_form) launch_canonical(e, st, d_witness, witness_stride);
+    return hip_ok(hipGetLastError(), "expand compact");
+}
+
+// launches whatever is pending and makes `stream` wait for every group issued so far
+int blsw_engine_flush(blsw_engine_t* e, void* stream_) {
+    if (!e) return BLSW_ERR_ARG;
+    DeviceGuard guard(e->device);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream_);
+    int rc = launch_group(e);
+    if (rc) return rc;
+    if ((rc = pump(e))) return rc;
+    for (int k = 0; k < e->nbuf; k++)
+        if (e->buf[k].used && e->buf[k].jobs_left == 0) hipStreamWaitEvent(st, e->buf[k].ev_done, 0);
+    return hip_ok(hipGetLastError(), "flush");
+}
+
+int blsw_engine_submitted(blsw_engine_t* e, uint64_t* seq) {
+    if (!e || !seq) return BLSW_ERR_ARG;
+    *seq = e->submitted;
+    return BLSW_OK;
+}
+int blsw_engine_launched(blsw_engine_t* e, uint64_t* seq) {
+    if (!e || !seq) return BLSW_ERR_ARG;
+    *seq = e->launched;
+    return BLSW_OK;
+}
+int blsw_engine_materialised(blsw_engine_t* e, uint64_t* seq) {
+    if (!e || !seq) return BLSW_ERR_ARG;
+    *seq = e->materialised;
+    return BLSW_OK;
+}
+// Step `seq` must have been issued (seq < launched) and its group buffer not yet recycled (at most n_buffers groups back:
+// older steps completed before their buffer was reused, so there is nothing to wait for).
+int blsw_engine_wait_step(blsw_engine_t* e, uint64_t seq, void* stream_) {
+    if (!e || seq >= e->launched) return BLSW_ERR_ARG;
+    if (seq >= e->materialised) return BLSW_ERR_BUSY;  // consumer mode: its output is still held by an earlier step
+    DeviceGuard guard(e->device);
+    for (int k = 0; k < e->nbuf; k++) {
+        GroupBuf& b = e->buf[k];
+        if (b.used && seq >= b.first_seq && seq < b.first_seq + b.steps)
+            return hip_ok(hipStreamWaitEvent(reinterpret_cast<hipStream_t>(stream_), b.ev_step[seq - b.first_seq], 0), "wait step");
+    }
+    return BLSW_OK;
+}
+int blsw_engine_output_consumed(blsw_engine_t* e, const void* d_output, void* stream_) {
+    if (!e || !d_output) return BLSW_ERR_ARG;
+    DeviceGuard guard(e->device);
+    int slot = consumed_slot(e, d_output);
+    for (int c = 0; c < BLSW_MAX_CONSUMED && slot < 0; c++)
+        if (!e->consumed_live[c] && !e->held[c]) slot = c;
+    if (slot < 0) return BLSW_ERR_ARG;  // more than BLSW_MAX_CONSUMED distinct outputs in use
+    if (!e->consumed_ev[slot] && hip_ok(hipEventCreateWithFlags(&e->consumed_ev[slot], hipEventDisableTiming), "event create")) return BLSW_ERR_HIP;
+    if (hip_ok(hipEventRecord(e->consumed_ev[slot], reinterpret_cast<hipStream_t>(stream_)), "event record")) return BLSW_ERR_HIP;
+    e->consumed_ptr[slot] = d_output;
+    e->consumed_live[slot] = true;
+    e->held[slot] = false;
+    return pump(e);  // consumer mode: steps that waited for this output go out now
+}
+
+// Average duration (ms) of the k_sha_expand launches issued since the last call (HIP events recorded on the stream the
+// kernel ran on); blocks until they have finished, then resets the statistics. count may be 0.
+int blsw_engine_expand_stats(blsw_engine_t* e, uint32_t* count, float* avg_ms) {
+    if (!e || !count || !avg_ms) return BLSW_ERR_ARG;
+    DeviceGuard guard(e->device);
+    double sum = 0;
+    for (uint32_t i = 0; i < e->n_timed; i++) {
+        if (hip_ok(hipEventSynchronize(e->ev_exp[2 * i + 1]), "event sync")) return BLSW_ERR_HIP;
+        float ms = 0;
+        if (hip_ok(hipEventElapsedTime(&ms, e->ev_exp[2 * i], e->ev_exp[2 * i + 1]), "event elapsed")) return BLSW_ERR_HIP;
+        sum += ms;
+    }
+    *count = e->n_timed;
+    *avg_ms = e->n_timed ? (float)(sum / e->n_timed) : 0.f;
+    e->n_timed = 0;
+    return BLSW_OK;
+}
+
+int blsw_witness_digest(const uint64_t* d_witness, uint64_t witness_stride, uint64_t n, uint32_t n_witness, uint64_t* d_digest, void* stream_) {
+    if (!d_witness || !d_digest || n == 0 || n > 65535 || n_witness == 0 || witness_stride < n_witness) return BLSW_ERR_ARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream_);
+    if (hip_ok(hipMemsetAsync(d_digest, 0, n * 2 * sizeof(uint64_t), st), "memset")) return BLSW_ERR_HIP;
+    const uint64_t n_words = (uint64_t)n_witness * 6, per_block = 2ull * 256 * BLSW_DIGEST_ITERS;
+    dim3 grid((unsigned)((n_words + per_block - 1) / per_block), (unsigned)n);
+    hipLaunchKernelGGL(k_digest, grid, dim3(256), 0, st, d_witness, witness_stride, n_words, d_digest);
+    return hip_ok(hipGetLastError(), "launch");
+}
+
+// one-step descriptor at the head of a caller workspace (direct-mode entry points); `h` is copied before returning
+static int put_desc(StepDesc* d_desc, const StepDesc& h, hipStream_t st) {
+    if (hip_ok(hipMemcpyAsync(d_desc, &h, sizeof(h), hipMemcpyHostToDevice, st), "memcpy")) return BLSW_ERR_HIP;
+    return hip_ok(hipStreamSynchronize(st), "sync");  // `h` is a stack object
+}
+static Group direct_group(uint64_t n, uint32_t K, uint32_t msg_len, const blsw_layout_t& L, StepDesc* d_desc, const Workspace& ws) {
+    Group g;
+    g.N = n * K;
+    g.n = (uint32_t)n;
+    g.K = K;
+    g.msg_len = msg_len;
+    g.desc = d_desc;
+    g.L = L;
+    g.LS = L;
+    g.ws = ws;
+    g.chain_prio = 0;
+    return g;
+}
+
+int blsw_hash_to_g2_batch(const uint8_t* d_msg, uint32_t msg_len, uint64_t n, uint64_t* d_out_affine, void* d_workspace, uint64_t workspace_bytes,
+                          void* stream_) {
+    if ((!d_msg && msg_len) || n == 0 || n > 0x7fffffffu || !d_workspace || !d_out_affine || msg_len > 65535) return BLSW_ERR_ARG;
+    blsw_layout_t L;
+    make_layout(msg_len, &L);
+    // the step descriptor lives at the head of the workspace
+    StepDesc* d_desc = reinterpret_cast<StepDesc*>(d_workspace);
+    Workspace ws = carve(reinterpret_cast<char*>(d_workspace) + 256, n, L, false, DEFAULT_MODES);
+    if (ws.total_bytes + 256 > workspace_bytes) return BLSW_ERR_WORKSPACE;
+    Group g = direct_group(n, 1, msg_len, L, d_desc, ws);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream_);
+    StepDesc h = {nullptr, nullptr, d_msg, nullptr, 0, nullptr, nullptr, nullptr, nullptr};
+    if (int rc = put_desc(d_desc, h, st)) return rc;
+    const unsigned g1 = (unsigned)((n + 63) / 64), g2 = (unsigned)((2 * n + 63) / 64);
+    hipLaunchKernelGGL(k_sha_values, dim3(g1), dim3(64), 0, st, g);
+    hipLaunchKernelGGL(k_map_values, dim3(g2), dim3(64), 0, st, g);
+    hipLaunchKernelGGL(k_cofactor_values, dim3(g1), dim3(64), 0, st, g);
+    hipLaunchKernelGGL(k_h_to_affine, dim3(g1), dim3(64), 0, st, n, g.ws, d_out_affine);
+    return hip_ok(hipGetLastError(), "launch");
+}
+// BLS::sign + PublicKey::from(&sk) for a batch (bls.rs:411-425, 183-195). Workspace: blsw_hash_to_g2_workspace_bytes.
+int blsw_sign_batch(const uint8_t* d_sk32_le, const uint8_t* d_msg, uint32_t msg_len, uint64_t n, uint8_t* d_sig96, uint64_t* d_sig_xy, uint8_t* d_pk48,
+                    uint64_t* d_pk_xy, int32_t* d_status, void* d_workspace, uint64_t workspace_bytes, void* stream_) {
+    if (!d_sk32_le || (!d_msg && msg_len) || n == 0 || n > 0x7fffffffu || !d_workspace || !d_status || msg_len > 65535) return BLSW_ERR_ARG;
+    blsw_layout_t L;
+    make_layout(msg_len, &L);
+    StepDesc* d_desc = reinterpret_cast<StepDesc*>(d_workspace);
+    Workspace ws = carve(reinterpret_cast<char*>(d_workspace) + 256, n, L, false, DEFAULT_MODES);
+    if (ws.total_bytes + 256 > workspace_bytes) return BLSW_ERR_WORKSPACE;
+    Group g = direct_group(n, 1, msg_len, L, d_desc, ws);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream_);
+    StepDesc h = {nullptr, nullptr, d_msg, nullptr, 0, nullptr, nullptr, nullptr, nullptr};
+    if (int rc = put_desc(d_desc, h, st)) return rc;
+    const unsigned g1 = (unsigned)((n + 63) / 64), g2 = (unsigned)((2 * n + 63) / 64);
+    hipLaunchKernelGGL(k_sha_values, dim3(g1), dim3(64), 0, st, g);
+    hipLaunchKernelGGL(k_map_values, dim3(g2), dim3(64), 0, st, g);
+    hipLaunchKernelGGL(k_cofactor_values, dim3(g1), dim3(64), 0, st, g);
+    hipLaunchKernelGGL(k_sign, dim3(g2), dim3(64), 0, st, n, g.ws, d_sk32_le, d_sig96, d_sig_xy, d_pk48, d_pk_xy, d_status);
+    return hip_ok(hipGetLastError(), "launch");
+}
+int blsw_layout_aggregate(uint32_t msg_len, uint32_t n_keys, blsw_layout_t* out) {
+    if (!out || msg_len > 65535) return BLSW_ERR_ARG;
+    make_layout(msg_len, out, n_keys);
+    return BLSW_OK;
+}
+static uint64_t agg_workspace(uint64_t n, const blsw_layout_t& L, uint64_t* off_desc, uint64_t* off_keyproj, uint64_t* off_ws) {
+    uint64_t o = 0;
+    *off_desc = o;
+    o = align_up(o + sizeof(StepDesc), 256);
+    *off_keyproj = o;
+    o = align_up(o + 3ull * n * L.n_keys * sizeof(Fp), 256);
+    *off_ws = o;
+    return o + carve(nullptr, n, L, false, DEFAULT_MODES).total_bytes;
+}
+int blsw_aggregate_workspace_bytes(uint64_t n, uint32_t msg_len, uint32_t n_keys, uint64_t* bytes) {
+    if (!bytes || n == 0 || n_keys == 0 || msg_len > 65535) return BLSW_ERR_ARG;
+    blsw_layout_t L;
+    make_layout(msg_len, &L, n_keys);
+    uint64_t a, b, c;
+    *bytes = agg_workspace(n, L, &a, &b, &c);
+    return BLSW_OK;
+}
+int blsw_aggregate_verify_batch(const uint64_t* d_pks_xy, const uint8_t* d_bitmap, uint32_t n_keys, const uint64_t* d_sig_xy, const uint8_t* d_msg,
+                                uint32_t msg_len, uint64_t n, uint64_t* d_witness, uint64_t witness_stride, int32_t* d_result, uint32_t* d_count,
+                                void* d_workspace, uint64_t workspace_bytes, void* stream_) {
+    if (!d_pks_xy || !d_bitmap || n_keys == 0 || !d_sig_xy || (!d_msg && msg_len) || n == 0 || n > 65535 || !d_workspace || msg_len > 65535) return BLSW_ERR_ARG;
+    blsw_layout_t L;
+    make_layout(msg_len, &L, n_keys);
+    if (d_witness && witness_stride < L.n_witness) return BLSW_ERR_ARG;
+    uint64_t off_desc, off_keyproj, off_ws;
+    if (agg_workspace(n, L, &off_desc, &off_keyproj, &off_ws) > workspace_bytes) return BLSW_ERR_WORKSPACE;
+    char* base = reinterpret_cast<char*>(d_workspace);
+    StepDesc* d_desc = reinterpret_cast<StepDesc*>(base + off_desc);
+    Fp* keyproj = reinterpret_cast<Fp*>(base + off_keyproj);
+    Group g = direct_group(n, 1, msg_len, L, d_desc, carve(base + off_ws, n, L, false, DEFAULT_MODES));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream_);
+    StepDesc h = {nullptr, d_sig_xy, d_msg, d_witness, witness_stride, d_result, d_pks_xy, d_bitmap, d_count};
+    if (int rc = put_desc(d_desc, h, st)) return rc;
+    const unsigned g1 = (unsigned)((n + 63) / 64), g2 = (unsigned)((2 * n + 63) / 64), gk = (unsigned)((n * n_keys + 63) / 64);
+    hipLaunchKernelGGL(k_agg_keys, dim3(gk), dim3(64), 0, st, g, keyproj);
+    hipLaunchKernelGGL(k_agg_sum, dim3(g1), dim3(64), 0, st, g, (const Fp*)keyproj);
+    hipLaunchKernelGGL(k_g2_alloc, dim3(g1), dim3(64), 0, st, g);
+    hipLaunchKernelGGL(k_prepare, dim3(g1), dim3(64), 0, st, g, 1);
+    hipLaunchKernelGGL(k_sha, dim3(g1), dim3(64), 0, st, g, d_witness ? 1 : 0, 1);
+    if (d_witness) {
+        ExpandArgs xa = {g.ws.bits, g.ws.sha_words, 0, g.L.sha_bits, g.L.off_expand, d_witness, witness_stride, 1u, 0u, 0};
+        launch_expand(BLSW_DEFAULT_EXPAND_VARIANT, 0, 0, st, xa, (unsigned)n);
+    }
+    hipLaunchKernelGGL(k_map, dim3(g2), dim3(64), 0, st, g);
+    hipLaunchKernelGGL(k_cofactor, dim3(g1), dim3(64), 0, st, g);
+    hipLaunchKernelGGL(k_prepare, dim3(g1), dim3(64), 0, st, g, 0);
+    launch_pairing(g, DEFAULT_MODES, st);
+    return hip_ok(hipGetLastError(), "launch");
+}
+
+// ---- N+1-pair product of pairings (one signature over n_pairs (pk, msg) pairs)
+int blsw_layout_multi(uint32_t msg_len, uint32_t n_pairs, blsw_layout_t* out) {
+    if (!out || msg_len > 65535 || n_pairs == 0 || n_pairs > 4096) return BLSW_ERR_ARG;
+    make_layout(msg_len, out, 0, n_pairs);
+    // the witness vector must stay addressable with 32-bit element offsets
+    const uint64_t total = (uint64_t)out->off_prep_h - out->off_expand;  // n_pairs * stride_hash
+    if (total / n_pairs != out->stride_hash) return BLSW_ERR_ARG;
+    return BLSW_OK;
+}
+int blsw_verify_multi_workspace_bytes(uint64_t n, uint32_t msg_len, uint32_t n_pairs, uint64_t* bytes) {
+    blsw_layout_t L;
+    if (!bytes || n == 0 || blsw_layout_multi(msg_len, n_pairs, &L)) return BLSW_ERR_ARG;
+    *bytes = 256 + carve(nullptr, n * n_pairs, L, false, DEFAULT_MODES, n).total_bytes;
+    return BLSW_OK;
+}
+int blsw_verify_multi_batch(const uint64_t* d_pks_xy, const uint8_t* d_msgs, uint32_t msg_len, uint32_t n_pairs, const uint64_t* d_sig_xy, uint64_t n,
+                            uint64_t* d_witness, uint64_t witness_stride, int32_t* d_result, void* d_workspace, uint64_t workspace_bytes, void* stream_) {
+    blsw_layout_t L;
+    if (!d_pks_xy || (!d_msgs && msg_len) || !d_sig_xy || n == 0 || !d_workspace || blsw_layout_multi(msg_len, n_pairs, &L)) return BLSW_ERR_ARG;
+    const uint64_t NP = n * n_pairs;  // per-pair lanes
+    if (NP > 65535 * 16ull || n > 65535) return BLSW_ERR_ARG;
+    if (d_witness && witness_stride < L.n_witness) return BLSW_ERR_ARG;
+    StepDesc* d_desc = reinterpret_cast<StepDesc*>(d_workspace);
+    Workspace ws = carve(reinterpret_cast<char*>(d_workspace) + 256, NP, L, false, DEFAULT_MODES, n);
+    if (ws.total_bytes + 256 > workspace_bytes) return BLSW_ERR_WORKSPACE;
+    Group gp = direct_group(n, n_pairs, msg_len, L, d_desc, ws);  // per-pair work: N = n * n_pairs lanes
+    Group gs = direct_group(n, 1, msg_len, L, d_desc, ws);        // per-signature work: N = n lanes
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream_);
+    StepDesc h = {d_pks_xy, d_sig_xy, d_msgs, d_witness, witness_stride, d_result, nullptr, nullptr, nullptr};
+    if (int rc = put_desc(d_desc, h, st)) return rc;
+    const unsigned p1 = (unsigned)((NP + 63) / 64), p2 = (unsigned)((2 * NP + 63) / 64), s1 = (unsigned)((n + 63) / 64);
+    // fork: the signature's allocation + prepare (one lane per instance: 57 ms of latency) and the keys' allocation run beside the
+    // hash-to-G2 chains of the pairs; join in front of the Miller product. The two side streams and three events are created once
+    // per host thread and device and kept (an event is re-recorded per call; a wait refers to the record that preceded it).
+    struct Side {
+        int device = -1;
+        hipStream_t aux[2] = {nullptr, nullptr};
+        hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+        bool ok = false;
+    };
+    static thread_local Side sides[16];
+    int dev = 0;
+    hipGetDevice(&dev);
+    Side& sd = sides[dev & 15];
+    if (sd.device != dev) {
+        sd.device = dev;
+        sd.ok = hipStreamCreateWithFlags(&sd.aux[0], hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&sd.aux[1], hipStreamNonBlocking) == hipSuccess &&
+                hipEventCreateWithFlags(&sd.ev_fork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&sd.ev_join[0], hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&sd.ev_join[1], hipEventDisableTiming) == hipSuccess;
+    }
+    const bool forked = sd.ok;
+    hipEvent_t ev_fork = sd.ev_fork;
+    hipEvent_t* ev_join = sd.ev_join;
+    hipStream_t s_sig = forked ? sd.aux[0] : st, s_keys = forked ? sd.aux[1] : st;
+    if (forked) {
+        hipEventRecord(ev_fork, st);  // the descriptor copy
+        hipStreamWaitEvent(s_sig, ev_fork, 0);
+        hipStreamWaitEvent(s_keys, ev_fork, 0);
+    }
+    hipLaunchKernelGGL(k_g2_alloc, dim3(s1), dim3(64), 0, s_sig, gs);
+    hipLaunchKernelGGL(k_prepare, dim3(s1), dim3(64), 0, s_sig, gs, 1);
+    hipLaunchKernelGGL(k_g1, dim3(p1), dim3(64), 0, s_keys, gp);
+    hipLaunchKernelGGL(k_sha, dim3(p1), dim3(64), 0, st, gp, d_witness ? 1 : 0, 1);
+    if (d_witness) {
+        // blockIdx.y = flat (instance, pair); grid.y <= 65535: several launches for larger batches
+        const uint64_t per_launch = (65535 / n_pairs) * (uint64_t)n_pairs;
+        for (uint64_t first = 0; first < NP; first += per_launch) {
+            const uint64_t cnt = NP - first < per_launch ? NP - first : per_launch;
+            ExpandArgs xa = {ws.bits, ws.sha_words, first, L.sha_bits, L.off_expand, d_witness + (first / n_pairs) * witness_stride * 6, witness_stride, n_pairs, L.stride_hash, 0};
+            launch_expand(BLSW_DEFAULT_EXPAND_VARIANT, 0, 0, st, xa, (unsigned)cnt);
+        }
+    }
+    hipLaunchKernelGGL(k_map, dim3(p2), dim3(64), 0, st, gp);
+    hipLaunchKernelGGL(k_cofactor, dim3(p1), dim3(64), 0, st, gp);
+    hipLaunchKernelGGL(k_prepare, dim3(p1), dim3(64), 0, st, gp, 0);
+    if (forked) {
+        hipEventRecord(ev_join[0], s_sig);
+        hipEventRecord(ev_join[1], s_keys);
+        hipStreamWaitEvent(st, ev_join[0], 0);
+        hipStreamWaitEvent(st, ev_join[1], 0);
+    }
+    hipLaunchKernelGGL(k_pairing_team_multi, dim3((unsigned)((n + BLSW_TEAMS_PER_WAVE - 1) / BLSW_TEAMS_PER_WAVE)), dim3(64), 0, st, gs, n_pairs, NP);
+    return hip_ok(hipGetLastError(), "launch");
+}
+
+int blsw_decode_batch(const uint8_t* d_pk48, const uint8_t* d_sig96, uint64_t n, uint64_t* d_pk_xy, uint64_t* d_sig_xy, int32_t* d_status, void* stream_) {
+    if (!d_pk48 || !d_sig96 || !d_pk_xy || !d_sig_xy || !d_status || n == 0 || n > 0x3fffffffu) return BLSW_ERR_ARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream_);
+    hipLaunchKernelGGL(k_decode, dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, st, d_pk48, d_sig96, n, d_pk_xy, d_sig_xy, d_status);
+    return hip_ok(hipGetLastError(), "launch");
+}
+int blsw_hash_to_g2_workspace_bytes(uint64_t n, uint32_t msg_len, uint64_t* bytes) {
+    if (!bytes || n == 0 || msg_len > 65535) return BLSW_ERR_ARG;
+    blsw_layout_t L;
+    make_layout(msg_len, &L);
+    *bytes = carve(nullptr, n, L, false, DEFAULT_MODES).total_bytes + 256;
+    return BLSW_OK;
+}
+
+// which = 0: v_mad_u64_u32 issue rate (multiply-adds/s); 1: fp_mul (Fp products/s); 2: fp_inv (inversions/s); 3: Fp products/s inside
+// witness-emitting Fp2 mul + sqr. Synchronous, on the current device.
+int blsw_microbench(int which, uint32_t iters, uint32_t blocks, double* ops_per_s) {
+    if (!ops_per_s || iters == 0 || blocks == 0 || which < 0 || which > 4) return BLSW_ERR_ARG;
+    uint32_t* d = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = hip_ok(hipMalloc(&d, 4), "malloc");
+    if (!rc) rc = hip_ok(hipEventCreate(&e0), "event create");
+    if (!rc) rc = hip_ok(hipEventCreate(&e1), "event create");
+    const int threads = which == 0 ? 256 : 64;
+    const double per_iter[5] = {8.0, 2.0, 1.0, 5.0, 2.0};  // MADs, fp products, fp inversions, fp products (one Fp2 mul + one Fp2 sqr), fp products (32-bit CIOS)
+    for (int rep = 0; rep < 2 && !rc; rep++) {        // first pass warms up
+        hipEventRecord(e0, 0);
+        if (which == 0)
+            hipLaunchKernelGGL(k_bench_mad, dim3(blocks), dim3(threads), 0, 0, iters, d);
+        else if (which == 1)
+            hipLaunchKernelGGL(k_bench_fpmul, dim3(blocks), dim3(threads), 0, 0, iters, d);
+        else if (which == 2)
+            hipLaunchKernelGGL(k_bench_fpinv, dim3(blocks), dim3(threads), 0, 0, iters, d);
+        else if (which == 3)
+            hipLaunchKernelGGL(k_bench_fp2mulw, dim3(blocks), dim3(threads), 0, 0, iters, d);
+        else
+            hipLaunchKernelGGL(k_bench_fpmul32, dim3(blocks), dim3(threads), 0, 0, iters, d);
+        hipEventRecord(e1, 0);
+        rc = hip_ok(hipEventSynchronize(e1), "event sync");
+    }
+    if (!rc) {
+        float ms = 0;
+        rc = hip_ok(hipEventElapsedTime(&ms, e0, e1), "event elapsed");
+        if (!rc) *ops_per_s = per_iter[which] * iters * blocks * threads / (ms * 1e-3);
+    }
+    if (e0) hipEventDestroy(e0);
+    if (e1) hipEventDestroy(e1);
+    if (d) hipFree(d);
+    return rc;
+}
+}

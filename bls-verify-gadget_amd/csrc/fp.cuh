@@ -9,8 +9,8 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define BLSW_HD __host__ __device__ __forceinline__
-#define BLSW_HD_NOINLINE __host__ __device__ __noinline__
-#define BLSW_FN __host__ __device__ __noinline__
+#define BLSW_HD_NOINLINE inline __host__ __device__ __noinline__  // `inline`: one definition per program across the translation units
+#define BLSW_FN inline __host__ __device__ __noinline__
 #else
 #define BLSW_HD inline
 #define BLSW_HD_NOINLINE inline  // host-only translation units (test harness, csrc/r1cs.cpp): no second strong definition

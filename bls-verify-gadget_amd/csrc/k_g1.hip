@@ -1,0 +1,61 @@
+// libblsw.so, one translation unit per kernel family (see kcommon.cuh, build.py).
+#include "kcommon.cuh"
+
+namespace blsw {
+
+__global__ __launch_bounds__(64) void k_g1(Group g) {
+    if (g.chain_prio) __builtin_amdgcn_s_setprio(3);  // latency-critical chain: win VALU issue arbitration against the streaming placement waves
+    uint64_t I = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (I >= g.N) return;
+    LaneId id = lane_id(g, I);
+    const Fp* p = reinterpret_cast<const Fp*>(g.desc[id.s].pk + (uint64_t)id.f * 12);
+    G1ChainOut o = chain_g1_alloc(EMITJ(g, id, off_pk_alloc, stride_pk_alloc), EMITJ(g, id, off_pk_not_zero, stride_pk_not_zero),
+                                  EMITJ(g, id, off_prep_pk, stride_prep_pk), ld_fp(p), ld_fp(p + 1));
+    st_fp(g.ws.pkaff + I, o.ax);
+    st_fp(g.ws.pkaff + g.N + I, o.ay);
+}
+
+// aggregate_verify: lane t = k * N + I allocates key k of instance I (N * n_keys lanes), result to ws.keyproj
+__global__ __launch_bounds__(64) void k_agg_keys(Group g, Fp* keyproj) {
+    if (g.chain_prio) __builtin_amdgcn_s_setprio(3);
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t N = g.N, nk = g.L.n_keys;
+    if (t >= N * nk) return;
+    uint32_t k = (uint32_t)(t / N);
+    LaneId id = lane_id(g, t - (uint64_t)k * N);
+    const Fp* p = reinterpret_cast<const Fp*>(g.desc[id.s].keys + ((uint64_t)id.i * nk + k) * 12);
+    Proj<OpsFp> r = chain_g1_alloc_only(emitter(g, id, g.L.off_keys + k * SEG_PK_ALLOC, g.LS.off_keys + k * SEG_PK_ALLOC), ld_fp(p), ld_fp(p + 1));
+    Fp* o = keyproj + t;
+    st_fp(o, r.x);
+    st_fp(o + N * nk, r.y);
+    st_fp(o + 2 * N * nk, r.z);
+}
+struct KeyProjSrc {
+    const Fp* p;  // keyproj + I
+    uint64_t N, total;
+    __device__ __forceinline__ Proj<OpsFp> ld(uint32_t k) const {
+        const Fp* q = p + (uint64_t)k * N;
+        return {ld_fp(q), ld_fp(q + total), ld_fp(q + 2 * total)};
+    }
+};
+// aggregate_verify: bitmap booleans, mapped_aggregate, then pk != 0 and prepare_g1 on the aggregated key
+__global__ __launch_bounds__(64) void k_agg_sum(Group g, const Fp* keyproj) {
+    if (g.chain_prio) __builtin_amdgcn_s_setprio(3);
+    uint64_t I = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (I >= g.N) return;
+    LaneId id = lane_id(g, I);
+    const uint32_t nk = g.L.n_keys;
+    const uint8_t* bm = g.desc[id.s].bitmap + (uint64_t)id.i * nk;
+    Emitter eb = EMIT(g, id, off_bitmap);
+    for (uint32_t k = 0; k < nk; k++) eb.put_bool(bm[k] != 0);  // Boolean::new_witness per key (constraints.rs:414-419)
+    KeyProjSrc src = {keyproj + I, g.N, g.N * nk};
+    uint32_t count = 0;
+    Proj<OpsFp> pk = chain_mapped_aggregate(EMIT(g, id, off_count), EMIT(g, id, off_agg), src, bm, nk, &count);
+    G1ChainOut o = chain_g1_post(EMIT(g, id, off_pk_not_zero), EMIT(g, id, off_prep_pk), pk);
+    st_fp(g.ws.pkaff + I, o.ax);
+    st_fp(g.ws.pkaff + g.N + I, o.ay);
+    uint32_t* c = g.desc[id.s].count;
+    if (c) c[id.i] = count;
+}
+
+}  // namespace blsw

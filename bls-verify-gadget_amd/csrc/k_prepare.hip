@@ -1,0 +1,28 @@
+// libblsw.so, one translation unit per kernel family (see kcommon.cuh, build.py).
+#include "kcommon.cuh"
+
+namespace blsw {
+
+// which = 0: prepare_g2(H(m)) ; which = 1: prepare_g2(sig)
+__global__ __launch_bounds__(64) void k_prepare(Group g, int which) {
+    if (g.chain_prio) __builtin_amdgcn_s_setprio(3);  // latency-critical chain: win VALU issue arbitration against the streaming placement waves
+    uint64_t I = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (I >= g.N) return;
+    LaneId id = lane_id(g, I);
+    const uint64_t N = g.N;
+    Proj<OpsFp2> q;
+    if (which == 0) {
+        q = ld_proj2(g.ws.h + I, N);
+    } else {
+        const Fp* p = reinterpret_cast<const Fp*>(g.desc[id.s].sig + (uint64_t)id.i * 24);
+        Fp2 sx = {ld_fp(p), ld_fp(p + 1)}, sy = {ld_fp(p + 2), ld_fp(p + 3)};
+        bool inf = fp2_is_zero(sx) && fp2_is_zero(sy);
+        q.x = inf ? fp2_zero() : sx;
+        q.y = inf ? fp2_one() : sy;
+        q.z = inf ? fp2_zero() : fp2_one();
+    }
+    CoeffStrided out = which == 0 ? CoeffStrided{g.ws.coeff_h + I, N} : CoeffStrided{g.ws.coeff_sig + I, g.ws.n_sig};
+    chain_prepare_g2(which == 0 ? EMITJ(g, id, off_prep_h, stride_prep_h) : EMIT(g, id, off_prep_sig), q, out);
+}
+
+}  // namespace blsw

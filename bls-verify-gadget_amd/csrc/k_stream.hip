@@ -1,0 +1,223 @@
+// libblsw.so, one translation unit per kernel family (see kcommon.cuh, build.py).
+#include "kcommon.cuh"
+
+namespace blsw {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <int NT>
+__device__ __forceinline__ void expand_store(uint4* dst, const uint4& v) {
+    if (NT == 2) {
+        u32x4 vv = {v.x, v.y, v.z, v.w};
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(vv) : "memory");
+    } else if (NT == 3) {
+        u32x4 vv = {v.x, v.y, v.z, v.w};
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(vv) : "memory");
+    } else if (NT == 1) {
+        __builtin_nontemporal_store(v.x, &dst->x);
+        __builtin_nontemporal_store(v.y, &dst->y);
+        __builtin_nontemporal_store(v.z, &dst->z);
+        __builtin_nontemporal_store(v.w, &dst->w);
+    } else {
+        *dst = v;
+    }
+}
+__device__ __forceinline__ uint4 expand_column(uint32_t c, int canonical) {
+    if (canonical) return make_uint4(c == 0 ? 1u : 0u, 0u, 0u, 0u);
+    constexpr uint32_t R1[12] = BLSW_R1_LIMBS;
+    uint4 rc;
+    rc.x = c == 0 ? R1[0] : (c == 1 ? R1[4] : R1[8]);
+    rc.y = c == 0 ? R1[1] : (c == 1 ? R1[5] : R1[9]);
+    rc.z = c == 0 ? R1[2] : (c == 1 ? R1[6] : R1[10]);
+    rc.w = c == 0 ? R1[3] : (c == 1 ? R1[7] : R1[11]);
+    return rc;
+}
+// instance / pair of this workgroup: where its segment starts and where its bit words are
+__device__ __forceinline__ void expand_locate(const ExpandArgs& a, uint4*& out, const uint32_t*& b) {
+    const uint64_t inst = a.K == 1 ? blockIdx.y : blockIdx.y / a.K;
+    const uint32_t pair = a.K == 1 ? 0u : blockIdx.y - (uint32_t)inst * a.K;
+    out = reinterpret_cast<uint4*>(a.d_witness + (inst * a.stride + a.off_expand + (uint64_t)pair * a.stride_hash) * 6);
+    const uint64_t lane = a.first + blockIdx.y;
+    b = a.bits + (lane >> 6) * bits_tile_words(a.sha_words) + (lane & 63) * BLSW_BITS_CHUNK_WORDS;
+}
+// word w of the instance whose stream starts at b (64-byte runs of 16 words, 64 instances interleaved per chunk)
+__device__ __forceinline__ uint32_t expand_word(const uint32_t* b, uint32_t w) {
+    #ifdef BLSW_DEBUG_EXPAND_NOREAD  // timing experiment
+    return 0x55555555u + w;
+#endif
+    return b[(uint64_t)(w / BLSW_BITS_CHUNK_WORDS) * (64 * BLSW_BITS_CHUNK_WORDS) + (w % BLSW_BITS_CHUNK_WORDS)];
+}
+// pieces [0, P0) in front of the first boundary: written by workgroup 0 of every variant
+template <int NT>
+__device__ __forceinline__ void expand_head(uint4* out, const uint32_t* b, uint32_t P0, uint32_t n_pieces, int canonical) {
+    if (blockIdx.x == 0 && threadIdx.x < P0 && threadIdx.x < n_pieces) {
+        const uint32_t e = threadIdx.x / 3, c = threadIdx.x - 3 * e;
+        const uint32_t m = 0u - ((expand_word(b, e >> 5) >> (e & 31)) & 1u);
+        const uint4 rc = expand_column(c, canonical);
+        expand_store<NT>(&out[threadIdx.x], make_uint4(rc.x & m, rc.y & m, rc.z & m, rc.w & m));
+    }
+}
+// variant 0 (and, with THREADS = 768 and 4 KiB alignment, variants 2 / 3): THREADS is a multiple of 192, so a thread's column is a
+// loop invariant; a workgroup writes THREADS * ITERS consecutive pieces, THREADS of them per iteration
+template <int THREADS, int ITERS, int ALIGN_PIECES, int NT>
+__global__ __launch_bounds__(THREADS) void k_sha_expand(ExpandArgs a) {
+    if (a.prio) __builtin_amdgcn_s_setprio(3);
+    uint4* out;
+    const uint32_t* b;
+    expand_locate(a, out, b);
+    const uint32_t n_pieces = a.sha_bits * 3;
+    const uint32_t P0 = (ALIGN_PIECES - (uint32_t)((reinterpret_cast<uintptr_t>(out) >> 4) % ALIGN_PIECES)) % ALIGN_PIECES;
+    expand_head<NT>(out, b, P0, n_pieces, a.canonical);
+    const uint32_t pt = P0 + threadIdx.x, c = pt % 3;
+    const uint32_t e0 = blockIdx.x * ((THREADS / 3) * ITERS) + pt / 3;
+    const uint4 rc = expand_column(c, a.canonical);
+    // THREADS / 3 is a multiple of 32: the bit position of a thread is a loop invariant too, its word advances by THREADS / 96
+    static_assert((THREADS / 3) % 32 == 0, "bit position must be loop invariant");
+    const uint32_t sh = e0 & 31, w0 = e0 >> 5;
+    uint4* dst = out + (uint64_t)e0 * 3 + c;
+    if (blockIdx.x * ((THREADS / 3) * ITERS) + (P0 + THREADS - 1) / 3 + (THREADS / 3) * (ITERS - 1) < a.sha_bits) {
+        // whole workgroup in range (all but the last one or two of an instance): all bit words first, then the stores back to
+        // back — no bounds checks, no wait between a store and the next load
+#ifdef BLSW_DEBUG_EXPAND_CONST  // timing experiment: the stores without the bit logic (wrong witnesses)
+#pragma unroll
+        for (int k = 0; k < ITERS; k++) expand_store<NT>(dst + (uint64_t)k * THREADS, rc);
+        return;
+#endif
+        uint32_t w[ITERS];
+#pragma unroll
+        for (int k = 0; k < ITERS; k++) w[k] = expand_word(b, w0 + k * (THREADS / 96));
+#pragma unroll
+        for (int k = 0; k < ITERS; k++) {
+            const uint32_t m = 0u - ((w[k] >> sh) & 1u);
+            expand_store<NT>(dst + (uint64_t)k * THREADS, make_uint4(rc.x & m, rc.y & m, rc.z & m, rc.w & m));
+        }
+        return;
+    }
+#pragma unroll 1
+    for (int k = 0; k < ITERS; k++) {
+        const uint32_t e = e0 + (THREADS / 3) * k;
+        if (e < a.sha_bits) {
+            const uint32_t m = 0u - ((expand_word(b, w0 + k * (THREADS / 96)) >> sh) & 1u);
+            expand_store<NT>(dst + (uint64_t)k * THREADS, make_uint4(rc.x & m, rc.y & m, rc.z & m, rc.w & m));
+        }
+    }
+}
+// variant 1: one piece per thread, workgroup b >= 1 writes exactly one 4 KiB-aligned chunk
+template <int NT>
+__global__ __launch_bounds__(256) void k_sha_expand_chunk(ExpandArgs a) {
+    if (a.prio) __builtin_amdgcn_s_setprio(3);
+    uint4* out;
+    const uint32_t* b;
+    expand_locate(a, out, b);
+    const uint32_t n_pieces = a.sha_bits * 3;
+    const uint32_t P0 = (256 - (uint32_t)((reinterpret_cast<uintptr_t>(out) >> 4) % 256)) % 256;
+    expand_head<NT>(out, b, P0, n_pieces, a.canonical);
+    const uint32_t p = P0 + blockIdx.x * 256 + threadIdx.x;
+    if (p >= n_pieces) return;
+    const uint32_t e = p / 3, c = p - 3 * e;
+    const uint32_t m = 0u - ((expand_word(b, e >> 5) >> (e & 31)) & 1u);
+    const uint4 rc = expand_column(c, a.canonical);
+    expand_store<NT>(&out[p], make_uint4(rc.x & m, rc.y & m, rc.z & m, rc.w & m));
+}
+// variant: low byte 0..3 = geometry, bit 8 = raised wave priority; store: 0 plain, 1 nontemporal, 2 sc1, 3 sc0 sc1 (variant 0 only)
+void launch_expand(uint32_t variant, uint32_t store, unsigned lds, hipStream_t st, ExpandArgs a, unsigned n_y) {
+    a.prio = (variant >> 8) & 1;
+    const uint32_t n_pieces = a.sha_bits * 3;
+    auto grid = [&](uint32_t per_wg) { return dim3((n_pieces + per_wg - 1) / per_wg + 1, n_y); };
+    switch (variant & 0xff) {
+        case 1: hipLaunchKernelGGL(k_sha_expand_chunk<0>, grid(256), dim3(256), lds, st, a); break;
+        case 2: hipLaunchKernelGGL((k_sha_expand<768, 8, 256, 0>), grid(768 * 8), dim3(768), lds, st, a); break;
+        case 3: hipLaunchKernelGGL((k_sha_expand<768, 4, 256, 0>), grid(768 * 4), dim3(768), lds, st, a); break;
+        case 4: hipLaunchKernelGGL((k_sha_expand<768, 16, 256, 0>), grid(768 * 16), dim3(768), lds, st, a); break;
+        case 5: hipLaunchKernelGGL((k_sha_expand<384, 16, 256, 0>), grid(384 * 16), dim3(384), lds, st, a); break;
+        default:
+            switch (store) {
+                case 1: hipLaunchKernelGGL((k_sha_expand<384, 8, 16, 1>), grid(384 * 8), dim3(384), lds, st, a); break;
+                case 2: hipLaunchKernelGGL((k_sha_expand<384, 8, 16, 2>), grid(384 * 8), dim3(384), lds, st, a); break;
+                case 3: hipLaunchKernelGGL((k_sha_expand<384, 8, 16, 3>), grid(384 * 8), dim3(384), lds, st, a); break;
+                default: hipLaunchKernelGGL((k_sha_expand<384, 8, 16, 0>), grid(384 * 8), dim3(384), lds, st, a); break;
+            }
+    }
+}
+// Engine mode: the field witnesses of one step are moved into place around the SHA segment. Rows below split_row are staged
+// in 64-instance tiles ([tile][row][64]: 48-byte gathers), the pairing rows instance-major (contiguous copies).
+// 16-byte chunk q of instance i covers elements [0, off_expand) and [off_expand + sha_bits, n_witness). Every block
+// writes 32 KiB contiguous of ONE instance's vector (16 and 64 KiB measure the same). An LDS-transposed variant with contiguous reads and 384-byte
+// writes was measured slower (3.8 ms vs 1.8 ms per 1024 instances).
+__global__ __launch_bounds__(256) void k_place_field(const Fp* __restrict__ staging, const Fp* __restrict__ pair, uint64_t first, uint32_t off_expand,
+                                                     uint32_t sha_bits, uint32_t staging_rows, uint32_t split_row, uint64_t* __restrict__ d_witness,
+                                                     uint64_t stride, uint32_t n_inst, uint32_t moved_lo, uint32_t moved_len, uint32_t moved_at) {
+    // XCD-aware block order: workgroups go round-robin to the 8 XCDs (each with its own L2). The 64 instances of a tile read
+    // neighbouring 48-byte pieces of the same staging lines, so all instances of one chunk of rows run back to back on ONE
+    // XCD: linear id L -> xcd = L % 8, chunk = xcd + 8 * ((L / 8) / n_inst), instance = (L / 8) % n_inst.
+    const uint32_t L = blockIdx.x, s_in_xcd = L >> 3;
+    const uint32_t chunk = (L & 7) + 8 * (s_in_xcd / n_inst);
+    const uint64_t inst = s_in_xcd % n_inst;
+    const uint32_t nchunks = staging_rows * 3;
+    if (chunk * (256u * BLSW_PLACE_ITERS) >= nchunks) return;
+    const uint64_t lane = first + inst;
+    const uint4* src = reinterpret_cast<const uint4*>(staging + (lane >> 6) * (uint64_t)split_row * 64 + (lane & 63));
+    const uint4* src2 = reinterpret_cast<const uint4*>(pair + lane * (uint64_t)(staging_rows - split_row));
+    uint4* out = reinterpret_cast<uint4*>(d_witness + inst * stride * 6);
+    uint32_t q0 = chunk * (256 * BLSW_PLACE_ITERS) + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < BLSW_PLACE_ITERS; k++) {
+        uint32_t q = q0 + k * 256;
+        if (q < nchunks) {
+            uint32_t e = q / 3, c = q - e * 3;
+            uint4 v = e < split_row ? src[(uint64_t)e * 64 * 3 + c] : src2[(uint64_t)(e - split_row) * 3 + c];
+            // staging row -> witness index: the SHA segment is cut out; a segment staged at the end (moved_len rows that belong
+            // at moved_lo, staged from row moved_at on) goes back to its place
+            uint32_t t = e;
+            if (moved_len) t = e >= moved_at ? moved_lo + (e - moved_at) : (e >= moved_lo ? e + moved_len : e);
+            uint32_t dst_e = (moved_len && e >= moved_at) ? t : (t < off_expand ? t : t + sha_bits);
+            out[(uint64_t)dst_e * 3 + c] = v;
+        }
+    }
+}
+
+// Digest of witness vectors (blsw_witness_digest): d[c] = sum_k mix64(w_k + (k + 1) * C_c) over the instance's u64 words.
+// grid (chunks, n); 256 threads, each 16 bytes per iteration; block partial sums -> two atomics per block.
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z ^= z >> 30;
+    z *= 0xbf58476d1ce4e5b9ull;
+    z ^= z >> 27;
+    z *= 0x94d049bb133111ebull;
+    z ^= z >> 31;
+    return z;
+}
+__global__ __launch_bounds__(256) void k_digest(const uint64_t* __restrict__ w, uint64_t stride, uint64_t n_words, uint64_t* __restrict__ digest) {
+    const uint64_t inst = blockIdx.y;
+    const ulonglong2* src = reinterpret_cast<const ulonglong2*>(w + inst * stride * 6);
+    const uint64_t n_pairs = n_words / 2;  // n_witness * 6 is even
+    uint64_t q = ((uint64_t)blockIdx.x * BLSW_DIGEST_ITERS) * 256 + threadIdx.x;
+    uint64_t d0 = 0, d1 = 0;
+#pragma unroll 4
+    for (int it = 0; it < BLSW_DIGEST_ITERS; it++, q += 256) {
+        if (q < n_pairs) {
+            ulonglong2 v = src[q];
+            const uint64_t k = 2 * q + 1;  // (index of v.x) + 1
+            d0 += mix64(v.x + k * 0x9E3779B97F4A7C15ull) + mix64(v.y + (k + 1) * 0x9E3779B97F4A7C15ull);
+            d1 += mix64(v.x + k * 0xC2B2AE3D27D4EB4Full) + mix64(v.y + (k + 1) * 0xC2B2AE3D27D4EB4Full);
+        }
+    }
+    // wave reduction, then one atomic pair per wave
+    for (int off = 32; off > 0; off >>= 1) {
+        d0 += __shfl_down(d0, off, 64);
+        d1 += __shfl_down(d1, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(digest + inst * 2), (unsigned long long)d0);
+        atomicAdd(reinterpret_cast<unsigned long long*>(digest + inst * 2 + 1), (unsigned long long)d1);
+    }
+}
+
+// options.output_form = 1: the field witnesses of a step, in place, from Montgomery form to canonical integers (what
+// CanonicalSerialize writes for an Fq: 48 bytes little-endian); the SHA segment is written in that form by the expansion itself
+__global__ __launch_bounds__(256) void k_canonical_rows(uint64_t* __restrict__ d_witness, uint64_t stride, uint32_t off_expand, uint32_t sha_bits, uint32_t rows) {
+    const uint32_t idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows) return;
+    Fp* p = reinterpret_cast<Fp*>(d_witness + ((uint64_t)blockIdx.y * stride + (idx < off_expand ? idx : idx + sha_bits)) * 6);
+    st_fp(p, fp_to_canonical(ld_fp(p)));
+}
+
+}  // namespace blsw

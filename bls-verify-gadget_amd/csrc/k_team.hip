@@ -1,0 +1,127 @@
+// libblsw.so, one translation unit per kernel family (see kcommon.cuh, build.py).
+#include "kcommon.cuh"
+#include "team.cuh"
+
+namespace blsw {
+
+// Miller loop + final exponentiation + is_one, SIX LANES PER INSTANCE (team.cuh): ten instances per wave, every Fp12
+// value distributed over the team's registers, operands and products exchanged through the team's 3.5 KB slot file in LDS
+__global__ __launch_bounds__(64) void k_pairing_team(Group g) {
+    __shared__ Fp2 lds[BLSW_TEAMS_PER_WAVE * TS_NSLOTS];
+    if ((uint64_t)blockIdx.x * BLSW_TEAMS_PER_WAVE >= g.N) return;  // a wave without instances (the scratch pre-warm launch)
+    if (g.chain_prio) __builtin_amdgcn_s_setprio(3);
+    const uint32_t team = threadIdx.x / 6, j = threadIdx.x % 6;
+    const uint64_t I0 = (uint64_t)blockIdx.x * BLSW_TEAMS_PER_WAVE + team;
+    const bool active = team < BLSW_TEAMS_PER_WAVE && I0 < g.N;
+    const uint64_t I = active ? I0 : 0, N = g.N;  // idle lanes only take part in the barriers
+    LaneId id = lane_id(g, I);
+    TeamLanes<CoeffStrided> t;
+    t.slots = lds + (active ? team : 0) * TS_NSLOTS;
+    t.j = j;
+    t.active = active;
+    t.coeff_h = {g.ws.coeff_h + I, N};
+    t.coeff_sig = {g.ws.coeff_sig + I, g.ws.n_sig};
+    t.e = EMIT(g, id, off_miller);
+    if (!active) t.e.base = nullptr;
+    t.set_consts(ld_fp(g.ws.pkaff + I), ld_fp(g.ws.pkaff + N + I));
+    Fp2 f = team_miller(t);
+    Emitter e_one = EMIT(g, id, off_is_one);
+    if (!active) e_one.base = nullptr;
+    bool res = team_final_exp_is_one(t, f, e_one);
+    int32_t* r = g.desc[id.s].result;
+    if (active && j == 0 && r) r[id.i] = res ? 1 : 0;
+}
+// G2 allocation, six lanes per instance: the (r - 1) * sig chain of the subgroup check runs on the team machinery (points on
+// lanes 0..2), the allocation witnesses and the enforce_equal tail are single-lane work of lane 0
+__global__ __launch_bounds__(64) void k_g2_alloc_team(Group g) {
+    // the G2 op tables use the operand slots and 12 product slots only: 24 slots = 23 KB per wave, six waves per CU
+    constexpr uint32_t G2_SLOTS = TS_P + 12;
+    __shared__ Fp2 lds[BLSW_TEAMS_PER_WAVE * G2_SLOTS];
+    if (g.chain_prio) __builtin_amdgcn_s_setprio(3);
+    constexpr uint32_t RM1[8] = BLSW_RM1_WORDS;
+    const uint32_t team = threadIdx.x / 6, j = threadIdx.x % 6;
+    const uint64_t I0 = (uint64_t)blockIdx.x * BLSW_TEAMS_PER_WAVE + team;
+    const bool active = team < BLSW_TEAMS_PER_WAVE && I0 < g.N;
+    const uint64_t I = active ? I0 : 0;
+    LaneId id = lane_id(g, I);
+    const Fp* p = reinterpret_cast<const Fp*>(g.desc[id.s].sig + (uint64_t)id.i * 24);
+    Fp2 sx = {ld_fp(p), ld_fp(p + 1)}, sy = {ld_fp(p + 2), ld_fp(p + 3)};
+    const bool inf = fp2_is_zero(sx) && fp2_is_zero(sy);
+    Proj<OpsFp2> ge = {inf ? fp2_zero() : sx, inf ? fp2_one() : sy, inf ? fp2_zero() : fp2_one()};
+    TeamLanes<CoeffStrided> t;
+    t.slots = lds + (active ? team : 0) * G2_SLOTS;
+    t.j = j;
+    t.active = active;
+    t.coeff_h = {nullptr, 0};
+    t.coeff_sig = {nullptr, 0};
+    t.e = EMIT(g, id, off_sig_alloc);
+    if (!active) t.e.base = nullptr;
+    Fp2 mine = j == 0 ? ge.x : (j == 1 ? ge.y : (j == 2 ? ge.z : fp2_zero()));
+    if (j < 3) {  // the six allocation witnesses: x.c0, x.c1, y.c0, y.c1, z.c0, z.c1
+        Emitter w = t.e;
+        w.pos += 2 * j;
+        w.put(mine.c0);
+        w.put(mine.c1);
+    }
+    t.e.pos += 6;
+    (void)team_g2_mul_bits(t, mine, RM1, BLSW_RM1_NBITS);
+    if (active && j == 0) chain_g2_alloc_tail(t.e, ge);
+}
+// N+1-pair product (blsw_verify_multi_batch): one team per instance, K pairs per instance. `gs` is the per-signature view
+// (N = instances), the per-pair values (prepare_g1(pk_j), line coefficients of H(m_j)) live at flat index I * K + j of the
+// per-pair launch of n_h = N * K lanes.
+struct TeamLanesMulti : TeamLanes<CoeffStrided> {
+    const Fp* coeff_h_all;
+    const Fp* pkaff;
+    uint64_t n_h, flat0;
+    BLSW_TEAM_DEV void load_coeff_sig(uint32_t k) {
+        if (active) team_load_coeff_sig_lane(j, slots, coeff_sig, k);
+        team_sync();
+    }
+    BLSW_TEAM_DEV void load_pair(uint32_t jp, uint32_t k) {
+        if (active) {
+            const uint64_t t = flat0 + jp;
+            Fp px = fp_zero(), py = fp_zero();
+            if (j == 5) px = ld_fp(pkaff + t);
+            if (j == 4) py = ld_fp(pkaff + n_h + t);
+            team_load_pair_lane(j, slots, CoeffStrided{const_cast<Fp*>(coeff_h_all) + t, n_h}, k, px, py);
+        }
+        team_sync();
+    }
+};
+__global__ __launch_bounds__(64) void k_pairing_team_multi(Group gs, uint32_t K, uint64_t n_h) {
+    __shared__ Fp2 lds[BLSW_TEAMS_PER_WAVE * TS_NSLOTS];
+    const uint32_t team = threadIdx.x / 6, j = threadIdx.x % 6;
+    const uint64_t I0 = (uint64_t)blockIdx.x * BLSW_TEAMS_PER_WAVE + team;
+    const bool active = team < BLSW_TEAMS_PER_WAVE && I0 < gs.N;
+    const uint64_t I = active ? I0 : 0;
+    LaneId id = lane_id(gs, I);
+    TeamLanesMulti t;
+    t.slots = lds + (active ? team : 0) * TS_NSLOTS;
+    t.j = j;
+    t.active = active;
+    t.coeff_h = {nullptr, 0};
+    t.coeff_sig = {gs.ws.coeff_sig + I, gs.ws.n_sig};
+    t.coeff_h_all = gs.ws.coeff_h;
+    t.pkaff = gs.ws.pkaff;
+    t.n_h = n_h;
+    t.flat0 = I * K;
+    t.e = EMIT(gs, id, off_miller);
+    if (!active) t.e.base = nullptr;
+    if (active && j == 0) team_st(t.slots, TS_XYC, {K_G1_GEN_NEG_Y(), fp_zero()});
+    team_sync();
+    Fp2 f = team_miller_multi(t, K);
+    Emitter e_one = EMIT(gs, id, off_is_one);
+    if (!active) e_one.base = nullptr;
+    bool res = team_final_exp_is_one(t, f, e_one);
+    int32_t* r = gs.desc[id.s].result;
+    if (active && j == 0 && r) r[id.i] = res ? 1 : 0;
+}
+void launch_pairing(const Group& g, const Modes& m, hipStream_t st) {
+    if (!m.pairing_team)
+        hipLaunchKernelGGL(k_pairing, dim3((unsigned)((g.N + 63) / 64)), dim3(64), 0, st, g);
+    else
+        hipLaunchKernelGGL(k_pairing_team, dim3((unsigned)((g.N + BLSW_TEAMS_PER_WAVE - 1) / BLSW_TEAMS_PER_WAVE)), dim3(64), 0, st, g);
+}
+
+}  // namespace blsw

@@ -1,0 +1,102 @@
+// libblsw.so, one translation unit per kernel family (see kcommon.cuh, build.py).
+#include "kcommon.cuh"
+#include "values.cuh"
+
+namespace blsw {
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_map_values(Group g) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 2 * g.N) return;
+    const uint32_t which = t >= g.N;
+    const uint64_t I = which ? t - g.N : t, N = g.N;
+    const Proj<OpsFp2> q = v_map_to_curve(ld_fp2(g.ws.u + (uint64_t)(2 * which) * N + I, N));
+    Fp* o = g.ws.q + (uint64_t)(6 * which) * N + I;
+    st_fp(o, q.x.c0);
+    st_fp(o + N, q.x.c1);
+    st_fp(o + 2 * N, q.y.c0);
+    st_fp(o + 3 * N, q.y.c1);
+    st_fp(o + 4 * N, q.z.c0);
+    st_fp(o + 5 * N, q.z.c1);
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_cofactor_values(Group g) {
+    uint64_t I = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (I >= g.N) return;
+    constexpr uint32_t HE[20] = BLSW_H_EFF_WORDS;
+    const uint64_t N = g.N;
+    // Q0, Q1 leave the isogeny as (x, y, 1) or (0, 0, 0) (hasher.rs:339-345): affine points or the identity
+    Jac2 r;
+    {
+        const Proj<OpsFp2> q0 = ld_proj2(g.ws.q + I, N);
+        r = {q0.x, q0.y, q0.z};
+        if (fp2_is_zero(q0.z)) r = {fp2_one(), fp2_one(), fp2_zero()};
+    }
+    {
+        const Proj<OpsFp2> q1 = ld_proj2(g.ws.q + 6 * N + I, N);
+        if (!fp2_is_zero(q1.z)) r = v_add_mixed(r, q1.x, q1.y);  // hasher.rs:656 (handles Q0 = +-Q1 and Q0 = 0)
+    }
+    Proj<OpsFp2> h = {fp2_zero(), fp2_one(), fp2_zero()};
+    if (!fp2_is_zero(r.z)) {
+        const Fp2 zi = fp2_inv_inl(r.z), zi2 = v_sqr(zi);
+        const Fp2 ax = fp2_mul_inl(r.x, zi2), ay = fp2_mul_inl(r.y, fp2_mul_inl(zi2, zi));
+        Jac2 acc = {ax, ay, fp2_one()};
+#pragma unroll 1
+        for (int i = BLSW_H_EFF_NBITS - 2; i >= 0; i--) {
+            acc = v_dbl(acc);
+            if (bit_of(HE, i)) acc = v_add_mixed(acc, ax, ay);
+        }
+        if (!fp2_is_zero(acc.z)) {  // (X / Z^2, Y / Z^3) as homogeneous (X Z, Y, Z^3)
+            h.x = fp2_mul_inl(acc.x, acc.z);
+            h.y = acc.y;
+            h.z = fp2_mul_inl(v_sqr(acc.z), acc.z);
+        }
+    }
+    Fp* o = g.ws.h + I;
+    st_fp(o, h.x.c0);
+    st_fp(o + N, h.x.c1);
+    st_fp(o + 2 * N, h.y.c0);
+    st_fp(o + 3 * N, h.y.c1);
+    st_fp(o + 4 * N, h.z.c0);
+    st_fp(o + 5 * N, h.z.c1);
+}
+
+// input decode: lanes [0, n) decompress pk (48 B), lanes [n, 2n) decompress sig (96 B); status[i][0] / status[i][1]
+__global__ __launch_bounds__(64) void k_decode(const uint8_t* __restrict__ pk48, const uint8_t* __restrict__ sig96, uint64_t n, uint64_t* pk_xy,
+                                               uint64_t* sig_xy, int32_t* status) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 2 * n) return;
+    if (t < n) {
+        Fp x, y;
+        int st = g1_decode(pk48 + t * 48, x, y);
+        Fp* o = reinterpret_cast<Fp*>(pk_xy + t * 12);
+        st_fp(o, x);
+        st_fp(o + 1, y);
+        status[2 * t] = st;
+    } else {
+        uint64_t i = t - n;
+        Fp2 x, y;
+        int st = g2_decode(sig96 + i * 96, x, y);
+        Fp* o = reinterpret_cast<Fp*>(sig_xy + i * 24);
+        st_fp(o, x.c0);
+        st_fp(o + 1, x.c1);
+        st_fp(o + 2, y.c0);
+        st_fp(o + 3, y.c1);
+        status[2 * i + 1] = st;
+    }
+}
+
+// H(m) projective -> affine (hash_to_g2 batch output)
+__global__ __launch_bounds__(64) void k_h_to_affine(uint64_t n, Workspace ws, uint64_t* d_out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Proj<OpsFp2> h = ld_proj2(ws.h + i, n);
+    Fp2 zi = fp2_inv(h.z);
+    Fp2 x = fp2_mul(h.x, zi), y = fp2_mul(h.y, zi);
+    Fp* o = reinterpret_cast<Fp*>(d_out + i * 24);
+    st_fp(o, x.c0);
+    st_fp(o + 1, x.c1);
+    st_fp(o + 2, y.c0);
+    st_fp(o + 3, y.c1);
+}
+
+}  // namespace blsw

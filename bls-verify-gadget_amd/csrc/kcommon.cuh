@@ -1,0 +1,263 @@
+// Shared by every translation unit of libblsw.so: the group / workspace / step descriptors, the witness cursor of the one-instance-per-lane
+// kernels, and the declarations of the kernels (each family is compiled as its own translation unit, in parallel: build.py).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "chains.cuh"
+#include "layout.h"
+
+namespace blsw {
+
+// ---------------------------------------------------------------- workspace
+// All per-instance scratch is stored element-major: element e of instance I lives at index e*N + I, so that the
+// 64 lanes of a wave touch one contiguous 3 KiB window per element (48 B per lane).
+struct Workspace {
+    uint32_t* bits;  // [N/64][sha_words/16][64][16] u32: SHA witness bitstream in 64-instance tiles; a wave appends 4 KiB rows
+                     // (one 64-byte run of 16 words per instance) to its own tile; sha_words is a multiple of 16
+    Fp* u;           // [4][N]   hash_to_field output u0.c0,u0.c1,u1.c0,u1.c1
+    Fp* q;           // [12][N]  Q0 (x.c0,x.c1,y.c0,y.c1,z.c0,z.c1), Q1
+    Fp* h;           // [6][N]   H(m) projective
+    Fp* pkaff;       // [2][N]   prepare_g1(pk)
+    Fp* coeff_h;     // [272][N]      line coefficients of prepare_g2(H(m))
+    Fp* coeff_sig;   // [272][n_sig]  line coefficients of prepare_g2(sig)
+    uint64_t n_sig;  // = N for the single-key circuit; = instances (not pairs) for the N+1-pair product
+    Fp* keyproj;     // [3][N * n_keys] allocated keys of the aggregate_verify circuit (projective), else nullptr
+    Fp* staging;     // [N/64][split_row][64] field witnesses (engine mode), or nullptr (direct mode): each wave of 64
+                     // instances owns one contiguous tile and appends 3 KiB rows to it (sequential HBM writes per wave)
+    uint64_t staging_rows;
+    Fp* pair;            // [N][pair_rows]: rows >= split_row of the staging coordinates (Miller loop, final exponentiation,
+    uint32_t split_row;  // is_one), instance-major: the six-lane pairing kernel appends each instance's segment sequentially
+    uint32_t pair_rows;  // (split_row = staging_rows, pair_rows = 0 when the single-lane pairing kernel is in use)
+    uint64_t sha_words;
+    uint64_t total_bytes;
+};
+inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
+BLSW_HD inline uint64_t bits_tile_words(uint64_t sha_words) { return sha_words * 64; }  // u32 per 64-instance tile
+// kernel variants, fixed per engine at creation (blsw_engine_options_t)
+struct Modes {
+    bool pairing_team;  // pairing segment: six lanes per instance (default) or the single-lane chain (kept for A/B runs)
+    bool g2_team;       // G2 allocation on the six-lane machinery: its segment is staged instance-major like the pairing rows,
+                        // so it moves to the end of the staging coordinates
+};
+constexpr Modes DEFAULT_MODES = {true, false};
+inline blsw_layout_t staging_layout(const blsw_layout_t& L, const Modes& m) {
+    blsw_layout_t S = L;
+    uint32_t* f = &S.off_msg;
+    const uint32_t* g = &L.off_msg;
+    for (int k = 0; k < 15; k++) f[k] = g[k] > L.off_expand ? g[k] - L.sha_bits : g[k];
+    if (m.g2_team) {
+        const uint32_t lo = L.off_sig_alloc, len = L.off_pk_not_zero - L.off_sig_alloc;
+        for (int k = 0; k < 15; k++)
+            if (f[k] > lo) f[k] -= len;
+        S.off_sig_alloc = L.n_witness - L.sha_bits - len;  // last rows of the staging coordinates
+    }
+    return S;
+}
+// N lanes of per-(pk, msg) work, n_sig lanes of per-signature work (n_sig = N except for the N+1-pair product)
+inline Workspace carve(void* base, uint64_t N, const blsw_layout_t& L, bool with_staging, const Modes& m, uint64_t n_sig = 0) {
+    Workspace w;
+    if (n_sig == 0) n_sig = N;
+    w.sha_words = align_up((L.sha_bits + 31) / 32 + 1, BLSW_BITS_CHUNK_WORDS);
+    uint64_t off = 0;
+    auto take = [&](uint64_t bytes) {
+        uint64_t o = off;
+        off = align_up(off + bytes, 256);
+        return reinterpret_cast<char*>(base) + o;
+    };
+    w.bits = reinterpret_cast<uint32_t*>(take(bits_tile_words(w.sha_words) * (align_up(N, 64) / 64) * 4));
+    w.u = reinterpret_cast<Fp*>(take(4 * N * sizeof(Fp)));
+    w.q = reinterpret_cast<Fp*>(take(12 * N * sizeof(Fp)));
+    w.h = reinterpret_cast<Fp*>(take(6 * N * sizeof(Fp)));
+    w.pkaff = reinterpret_cast<Fp*>(take(2 * N * sizeof(Fp)));
+    w.coeff_h = reinterpret_cast<Fp*>(take(272ull * N * sizeof(Fp)));
+    w.coeff_sig = reinterpret_cast<Fp*>(take(272ull * n_sig * sizeof(Fp)));
+    w.n_sig = n_sig;
+    w.keyproj = L.n_keys ? reinterpret_cast<Fp*>(take(3ull * N * L.n_keys * sizeof(Fp))) : nullptr;
+    w.staging_rows = L.n_witness - L.sha_bits;
+    w.split_row = m.pairing_team ? staging_layout(L, m).off_miller : (uint32_t)w.staging_rows;
+    w.pair_rows = (uint32_t)w.staging_rows - w.split_row;
+    w.staging = with_staging ? reinterpret_cast<Fp*>(take((uint64_t)w.split_row * align_up(N, 64) * sizeof(Fp))) : nullptr;
+    w.pair = with_staging && w.pair_rows ? reinterpret_cast<Fp*>(take((uint64_t)w.pair_rows * N * sizeof(Fp))) : nullptr;
+    w.total_bytes = off;
+    return w;
+}
+
+// one submitted batch ("step"): where its inputs are and where its witness tensor / results go
+struct StepDesc {
+    const uint64_t* pk;
+    const uint64_t* sig;
+    const uint8_t* msg;
+    uint64_t* out;        // [n][out_stride] field elements, or nullptr (results only)
+    uint64_t out_stride;  // in field elements
+    int32_t* result;
+    // aggregate_verify only
+    const uint64_t* keys;   // [n][n_keys][12]
+    const uint8_t* bitmap;  // [n][n_keys]
+    uint32_t* count;        // [n]
+    // host side only: the step leaves the engine in its compact wire form (blsw_engine_submit_compact) instead of as witness vectors
+    void* compact;
+};
+// Compact wire form of a step of n instances (n a multiple of 64): the step's slices of the group workspace, back to back —
+// [n/64][sha_words/16][64][16] u32 bit words | [n/64][split_row][64] Fp tile-major rows | [n][pair_rows] Fp instance-major rows
+struct CompactForm {
+    uint64_t bits_bytes, staging_bytes, pair_bytes, off_staging, off_pair, total;
+};
+inline CompactForm compact_form(uint64_t n, const Workspace& w) {
+    CompactForm c;
+    c.bits_bytes = bits_tile_words(w.sha_words) * (n / 64) * 4;
+    c.staging_bytes = (uint64_t)w.split_row * n * sizeof(Fp);
+    c.pair_bytes = (uint64_t)w.pair_rows * n * sizeof(Fp);
+    c.off_staging = align_up(c.bits_bytes, 256);
+    c.off_pair = align_up(c.off_staging + c.staging_bytes, 256);
+    c.total = align_up(c.off_pair + c.pair_bytes, 256);
+    return c;
+}
+// a group of `steps` batches of n instances each, processed by one set of launches (N = steps * n * K lanes per chain;
+// K = (pk, msg) pairs per instance: 1 except for the N+1-pair product)
+struct Group {
+    uint64_t N;
+    uint32_t n;   // instances per step
+    uint32_t K;   // pairs per instance
+    uint32_t msg_len;
+    const StepDesc* desc;  // device array [steps]
+    blsw_layout_t L;       // offsets in the witness vector
+    blsw_layout_t LS;      // offsets in the staging rows (the vector with the SHA segment cut out)
+    Workspace ws;
+    int chain_prio;        // chain waves raise s_setprio
+};
+
+__device__ __forceinline__ Fp ld_fp(const Fp* p) {
+    const uint4* s = reinterpret_cast<const uint4*>(p);
+    uint4 a = s[0], b = s[1], c = s[2];
+    Fp r;
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    r.l[8] = c.x; r.l[9] = c.y; r.l[10] = c.z; r.l[11] = c.w;
+    return r;
+}
+__device__ __forceinline__ void st_fp(Fp* p, const Fp& v) {
+    uint4* d = reinterpret_cast<uint4*>(p);
+    d[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    d[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+    d[2] = make_uint4(v.l[8], v.l[9], v.l[10], v.l[11]);
+}
+__device__ __forceinline__ Fp2 ld_fp2(const Fp* p, uint64_t n) { return {ld_fp(p), ld_fp(p + n)}; }
+
+// lane -> (step, instance-in-step, pair). Inputs of per-pair work are indexed by f (flat [n][K]), outputs by (i, j).
+struct LaneId {
+    uint64_t I;
+    uint32_t s, i, j, f;
+};
+__device__ __forceinline__ LaneId lane_id(const Group& g, uint64_t I) {
+    LaneId r;
+    r.I = I;
+    const uint32_t nk = g.n * g.K;
+    r.s = (uint32_t)(I / nk);
+    r.f = (uint32_t)(I - (uint64_t)r.s * nk);
+    r.i = g.K == 1 ? r.f : r.f / g.K;
+    r.j = g.K == 1 ? 0u : r.f - r.i * g.K;
+    return r;
+}
+// witness cursor for a segment: staging row (engine mode), the instance's dense vector (direct mode), or value-only
+__device__ __forceinline__ Emitter emitter(const Group& g, const LaneId& id, uint32_t off_full, uint32_t off_staging) {
+    Emitter e;
+    if (g.ws.staging) {
+        if (off_staging >= g.ws.split_row) {  // instance-major rows of the pairing segments
+            e.base = reinterpret_cast<uint32_t*>(g.ws.pair + id.I * g.ws.pair_rows);
+            e.pos = off_staging - g.ws.split_row;
+            e.stride = 12;
+            return e;
+        }
+        e.base = reinterpret_cast<uint32_t*>(g.ws.staging + (id.I >> 6) * (uint64_t)g.ws.split_row * 64 + (id.I & 63));
+        e.pos = off_staging;
+        e.stride = 64 * 12;
+        return e;
+    }
+    const StepDesc& d = g.desc[id.s];
+    e.base = d.out ? reinterpret_cast<uint32_t*>(d.out + (uint64_t)id.i * d.out_stride * 6) : nullptr;
+    e.pos = off_full;
+    e.stride = 12;
+    return e;
+}
+#define EMIT(g, id, field) emitter(g, id, (g).L.field, (g).LS.field)
+// segment that exists once per pair: pair j's copy starts j * stride further (staged groups always have K = 1)
+#define EMITJ(g, id, field, stride) emitter(g, id, (g).L.field + (id).j * (g).L.stride, (g).LS.field + (id).j * (g).L.stride)
+
+__device__ __forceinline__ Proj<OpsFp2> ld_proj2(const Fp* p, uint64_t n) {
+    Proj<OpsFp2> r;
+    r.x = ld_fp2(p, n);
+    r.y = ld_fp2(p + 2 * n, n);
+    r.z = ld_fp2(p + 4 * n, n);
+    return r;
+}
+
+// line coefficients, element-major: coefficient idx of instance I at p[idx * N]
+struct CoeffStrided {
+    Fp* p;
+    uint64_t n;
+    __device__ __forceinline__ void st(uint32_t idx, const Fp& v) const { st_fp(p + (uint64_t)idx * n, v); }
+    __device__ __forceinline__ Fp ld(uint32_t idx) const { return ld_fp(p + (uint64_t)idx * n); }
+};
+
+// bitstream -> Fp elements: element e of the expand segment = bit ? R mod p : 0. The segment is a stream of 16-byte pieces
+// (piece p = element p / 3, column p % 3) that starts at an arbitrary multiple of 16 bytes (instance vectors are 33 956 496
+// bytes apart). blockIdx.y = flat (instance, pair) index of the step. Three store geometries (blsw_engine_options_t::
+// expand_variant; measured alone in tools/expand_lab.hip -> profiles/r02_expand_lab.txt, and in the pipeline by bench.py):
+//   0  384-thread workgroups, 8 pieces per thread 6 KiB apart, pieces counted from the first 256-byte boundary
+//   1  256-thread workgroups, ONE piece per thread, every workgroup writes one 4 KiB-aligned 4 KiB chunk of the address space
+//   2  768-thread workgroups, 8 pieces per thread 12 KiB apart: every iteration writes three 4 KiB-aligned chunks; column and
+//      bit position of a thread are loop invariants (768 = 3 * 256 pieces = 256 elements = 8 bit words per iteration)
+//   3  as 2 with 4 pieces per thread;  4  as 2 with 16;  5  384 threads x 16 pieces, 4 KiB-aligned start
+struct ExpandArgs {
+    const uint32_t* bits;
+    uint64_t sha_words, first;
+    uint32_t sha_bits, off_expand;
+    uint64_t* d_witness;
+    uint64_t stride;
+    uint32_t K, stride_hash;  // K = 1 for the single-key circuit
+    int prio;                 // raise the wave priority (s_setprio 3): wins VALU issue arbitration against the chain waves
+    int canonical;            // elements as canonical integers (true = 1) instead of Montgomery form (true = R mod p)
+};
+
+#define BLSW_TEAMS_PER_WAVE 10
+#ifndef BLSW_PLACE_ITERS
+#define BLSW_PLACE_ITERS 8
+#endif
+#define BLSW_DIGEST_ITERS 16
+
+// ---------------------------------------------------------------- kernels (defined in k_*.hip, launched by engine.hip)
+__global__ void k_sha(Group g, int want_bits, int write_u);
+__global__ void k_sha_values(Group g);
+__global__ void k_place_field(const Fp* __restrict__ staging, const Fp* __restrict__ pair, uint64_t first, uint32_t off_expand, uint32_t sha_bits,
+                              uint32_t staging_rows, uint32_t split_row, uint64_t* __restrict__ d_witness, uint64_t stride, uint32_t n_inst, uint32_t moved_lo,
+                              uint32_t moved_len, uint32_t moved_at);
+__global__ void k_canonical_rows(uint64_t* __restrict__ d_witness, uint64_t stride, uint32_t off_expand, uint32_t sha_bits, uint32_t rows);
+__global__ void k_digest(const uint64_t* __restrict__ w, uint64_t stride, uint64_t n_words, uint64_t* __restrict__ digest);
+__global__ void k_g1(Group g);
+__global__ void k_agg_keys(Group g, Fp* keyproj);
+__global__ void k_agg_sum(Group g, const Fp* keyproj);
+__global__ void k_g2_alloc(Group g);
+__global__ void k_map(Group g);
+__global__ void k_cofactor(Group g);
+__global__ void k_map_values(Group g);
+__global__ void k_cofactor_values(Group g);
+__global__ void k_prepare(Group g, int which);
+__global__ void k_pairing(Group g);
+__global__ void k_pairing_team(Group g);
+__global__ void k_g2_alloc_team(Group g);
+__global__ void k_pairing_team_multi(Group gs, uint32_t K, uint64_t n_h);
+__global__ void k_decode(const uint8_t* __restrict__ pk48, const uint8_t* __restrict__ sig96, uint64_t n, uint64_t* pk_xy, uint64_t* sig_xy, int32_t* status);
+__global__ void k_h_to_affine(uint64_t n, Workspace ws, uint64_t* d_out);
+__global__ void k_sign(uint64_t n, Workspace ws, const uint8_t* __restrict__ sk32, uint8_t* sig96, uint64_t* sig_xy, uint8_t* pk48, uint64_t* pk_xy, int32_t* status);
+__global__ void k_bench_mad(uint32_t iters, uint32_t* out);
+__global__ void k_bench_fpmul(uint32_t iters, uint32_t* out);
+__global__ void k_bench_fpmul32(uint32_t iters, uint32_t* out);
+__global__ void k_bench_fpinv(uint32_t iters, uint32_t* out);
+__global__ void k_bench_fp2mulw(uint32_t iters, uint32_t* out);
+// host-side launch helpers that live next to their (templated) kernels
+void launch_expand(uint32_t variant, uint32_t store, unsigned lds, hipStream_t st, ExpandArgs a, unsigned n_y);
+void launch_pairing(const Group& g, const Modes& m, hipStream_t st);
+
+}  // namespace blsw

@@ -390,7 +390,7 @@ BLSW_TEAM_DEV Fp2 team_exec_lane_inl(const TeamOp& T, Fp2* slots, uint32_t j, bo
     return out;
 }
 
-__device__ __noinline__ Fp2 team_exec_lane(const TeamOp& T, Fp2* slots, uint32_t j, bool active, const Fp2& in0, const Fp2& in1, Emitter& e) {
+inline __device__ __noinline__ Fp2 team_exec_lane(const TeamOp& T, Fp2* slots, uint32_t j, bool active, const Fp2& in0, const Fp2& in1, Emitter& e) {
     return team_exec_lane_inl(T, slots, j, active, in0, in1, e);
 }
 

@@ -1,7 +1,7 @@
-// LAB PROGRAM: the product's own expansion kernels (kernels.hip is included, launch_expand is called directly) timed in
+// LAB PROGRAM: the product's own expansion kernels (k_stream.hip is included, launch_expand is called directly) timed in
 // different launch contexts, to find what the pipeline does differently from tools/expand_lab.hip.
 //   hipcc -O3 --offload-arch=gfx950 -std=c++17 -o build/expand_ctx_lab tools/expand_ctx_lab.hip && build/expand_ctx_lab
-#include "../bls-verify-gadget_amd/csrc/kernels.hip"
+#include "../bls-verify-gadget_amd/csrc/k_stream.hip"
 #include <vector>
 #define CK(x)                                                                      \
     do {                                                                           \
