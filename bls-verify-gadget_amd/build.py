@@ -43,6 +43,7 @@ def build(force=False, verbose=False, out=None, defines=(), only=None):
     if out is None and not force and not needs_build():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    out = os.path.abspath(out) if out else None
     os.makedirs(OBJ, exist_ok=True)
     tag = hashlib.sha1(" ".join(defines).encode()).hexdigest()[:8] if defines else "std"
     hdr_time = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)

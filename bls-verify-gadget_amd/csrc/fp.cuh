@@ -10,7 +10,14 @@
 #include <hip/hip_runtime.h>
 #define BLSW_HD __host__ __device__ __forceinline__
 #define BLSW_HD_NOINLINE inline __host__ __device__ __noinline__  // `inline`: one definition per program across the translation units
+// BLSW_FN: the witness programs above the Fp product. Out of line by default (one body per code object); a translation unit that
+// defines BLSW_INLINE_CHAINS inlines them into its kernels, so that the kernel's register budget (amdgpu_waves_per_eu) governs
+// all of the chain's code — a separate function is compiled against the full 512-register file whatever its caller asks for.
+#if defined(BLSW_INLINE_CHAINS) && defined(__HIP_DEVICE_COMPILE__)
+#define BLSW_FN __host__ __device__ __forceinline__
+#else
 #define BLSW_FN inline __host__ __device__ __noinline__
+#endif
 #else
 #define BLSW_HD inline
 #define BLSW_HD_NOINLINE inline  // host-only translation units (test harness, csrc/r1cs.cpp): no second strong definition

@@ -1,9 +1,17 @@
 // libblsw.so, one translation unit per kernel family (see kcommon.cuh, build.py).
+#ifdef BLSW_CHAINS_INLINED  // build variant: the chain programs inlined into the kernel (fp.cuh: BLSW_FN)
+#define BLSW_INLINE_CHAINS 1
+#endif
 #include "kcommon.cuh"
+#if defined(BLSW_W2_ALL) || defined(BLSW_W2_COFACTOR)  // build variant: two waves per SIMD (256 registers)
+#define BLSW_CHAIN_ATTR BLSW_ATTR_W2
+#else
+#define BLSW_CHAIN_ATTR
+#endif
 
 namespace blsw {
 
-__global__ __launch_bounds__(64) void k_cofactor(Group g) {
+__global__ __launch_bounds__(64) BLSW_CHAIN_ATTR void k_cofactor(Group g) {
     if (g.chain_prio) __builtin_amdgcn_s_setprio(3);  // latency-critical chain: win VALU issue arbitration against the streaming placement waves
     uint64_t I = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (I >= g.N) return;

@@ -1,11 +1,19 @@
 // libblsw.so, one translation unit per kernel family (see kcommon.cuh, build.py).
+#ifdef BLSW_CHAINS_INLINED  // build variant: the chain programs inlined into the kernel (fp.cuh: BLSW_FN)
+#define BLSW_INLINE_CHAINS 1
+#endif
 #include "kcommon.cuh"
+#if defined(BLSW_W2_ALL) || defined(BLSW_W2_SHA)  // build variant: two waves per SIMD (256 registers)
+#define BLSW_CHAIN_ATTR BLSW_ATTR_W2
+#else
+#define BLSW_CHAIN_ATTR
+#endif
 
 namespace blsw {
 
 // ---------------------------------------------------------------- kernels (one instance per lane)
 // SHA-256 witness bits of expand_message (+ the message bits themselves)
-__global__ __launch_bounds__(64) void k_sha(Group g, int want_bits, int write_u) {
+__global__ __launch_bounds__(64) BLSW_CHAIN_ATTR void k_sha(Group g, int want_bits, int write_u) {
     __shared__ uint32_t sha_lds[BLSW_BITS_CHUNK_WORDS * 64];  // the wave's word buffer of the bit sink
     if (g.chain_prio) __builtin_amdgcn_s_setprio(3);  // latency-critical chain: win VALU issue arbitration against the streaming placement waves
     uint64_t I = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;

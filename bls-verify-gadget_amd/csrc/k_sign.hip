@@ -1,6 +1,7 @@
 // libblsw.so, one translation unit per kernel family (see kcommon.cuh, build.py).
 #include "kcommon.cuh"
 #include "values.cuh"
+#include "vsign.cuh"
 
 namespace blsw {
 
@@ -18,15 +19,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         bool inf = true;
         if (st == SIGN_OK) {
             Proj<OpsFp2> h = ld_proj2(ws.h + i, n);
-            if (!fp2_is_zero(h.z)) {  // sig = sk * H(m): inlined Jacobian ladder (two waves per SIMD, as k_cofactor_values)
-                const Fp2 zi = fp2_inv_inl(h.z);
-                const Fp2 hx = fp2_mul_inl(h.x, zi), hy = fp2_mul_inl(h.y, zi);
-                Jac2 acc = {fp2_one(), fp2_one(), fp2_zero()};
-#pragma unroll 1
-                for (int b = 254; b >= 0; b--) {
-                    acc = v_dbl(acc);
-                    if ((k[b >> 5] >> (b & 31)) & 1) acc = v_add_mixed(acc, hx, hy);
-                }
+            if (!fp2_is_zero(h.z)) {  // sig = sk * H(m): joint ladder over the four base-|x| digits of sk (vsign.cuh)
+                // homogeneous (x, y, z) = affine (x / z, y / z) = Jacobian (x z, y z^2, z)
+                const Jac2 q = {fp2_mul_inl(h.x, h.z), fp2_mul_inl(h.y, v_sqr(h.z)), h.z};
+                const Jac2 acc = v_g2_mul_gls(ParkRows{ws.coeff_h + i, n}, q, k);
                 if (!fp2_is_zero(acc.z)) {
                     const Fp2 ai = fp2_inv_inl(acc.z), ai2 = v_sqr(ai);
                     x = fp2_mul_inl(acc.x, ai2);
@@ -47,14 +43,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     } else {
         Fp x = fp_zero(), y = fp_zero();
         bool inf = true;
-        if (st == SIGN_OK) {  // pk = sk * g1, the same ladder over Fp
-            const Fp gx = K_G1_GEN_X(), gy = fp_neg(K_G1_GEN_NEG_Y());
-            Jac1v acc = {fp_one(), fp_one(), fp_zero()};
-#pragma unroll 1
-            for (int b = 254; b >= 0; b--) {
-                acc = v1_dbl(acc);
-                if ((k[b >> 5] >> (b & 31)) & 1) acc = v1_add_mixed(acc, gx, gy);
-            }
+        if (st == SIGN_OK) {  // pk = sk * g1: fixed-base windows (vsign.cuh)
+            const Jac1v acc = v1_mul_g1_fixed(k);
             if (!fp_is_zero(acc.z)) {
                 const Fp ai = fp_inv(acc.z), ai2 = fp_sqr(ai);
                 x = fp_mul(acc.x, ai2);

@@ -22,7 +22,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_cofactor_values(Group g) {
     uint64_t I = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (I >= g.N) return;
-    constexpr uint32_t HE[20] = BLSW_H_EFF_WORDS;
     const uint64_t N = g.N;
     // Q0, Q1 leave the isogeny as (x, y, 1) or (0, 0, 0) (hasher.rs:339-345): affine points or the identity
     Jac2 r;
@@ -37,14 +36,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
     Proj<OpsFp2> h = {fp2_zero(), fp2_one(), fp2_zero()};
     if (!fp2_is_zero(r.z)) {
-        const Fp2 zi = fp2_inv_inl(r.z), zi2 = v_sqr(zi);
-        const Fp2 ax = fp2_mul_inl(r.x, zi2), ay = fp2_mul_inl(r.y, fp2_mul_inl(zi2, zi));
-        Jac2 acc = {ax, ay, fp2_one()};
-#pragma unroll 1
-        for (int i = BLSW_H_EFF_NBITS - 2; i >= 0; i--) {
-            acc = v_dbl(acc);
-            if (bit_of(HE, i)) acc = v_add_mixed(acc, ax, ay);
-        }
+        const Jac2 acc = v_clear_cofactor(ParkRows{g.ws.coeff_h + I, N}, r);  // hasher.rs:664-673 (same point as h_eff * r)
         if (!fp2_is_zero(acc.z)) {  // (X / Z^2, Y / Z^3) as homogeneous (X Z, Y, Z^3)
             h.x = fp2_mul_inl(acc.x, acc.z);
             h.y = acc.y;

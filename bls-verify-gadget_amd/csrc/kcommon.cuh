@@ -222,6 +222,7 @@ struct ExpandArgs {
 };
 
 #define BLSW_TEAMS_PER_WAVE 10
+#define BLSW_ATTR_W2 __attribute__((amdgpu_waves_per_eu(2, 2)))  // register budget of a kernel: two waves per SIMD
 #ifndef BLSW_PLACE_ITERS
 #define BLSW_PLACE_ITERS 8
 #endif

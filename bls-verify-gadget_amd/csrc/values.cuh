@@ -1,168 +1,28 @@
-// Value-only curve arithmetic with inlined Fp2 operations (two waves per SIMD): shared by k_values.hip and k_sign.hip.
+// Device side of the value-only entries: vcurve.cuh plus the kernels' common definitions.
 #pragma once
 #include "kcommon.cuh"
-#include "decode.cuh"
+#include "vcurve.cuh"
 
 namespace blsw {
 
-// Value-only entry points (hash_to_g2 batch, signer): the same group element without the circuit's witness structure — the
-// in-circuit clear_cofactor2 is an AFFINE double-and-add with one slope inversion per step (939 Fp2 inversions, App. A.5);
-// here it is a Jacobian ladder over the 636 bits of h_eff with two inversions in all. Output as k_cofactor's: homogeneous (x, y, z).
-// The ladder is written out with inlined Fp2 operations (only the Fp product and the inversion are calls), so that the kernel
-// fits two waves per SIMD: the shared jac2_dbl / jac2_add_mixed are separate functions that take 248 VGPRs + 32 AGPRs each.
-namespace {
-__device__ __forceinline__ Fp2 v_sqr(const Fp2& a) {
-    Fp v = fp_mul(a.c0, a.c1);
-    Fp t = fp_mul(fp_sub(a.c0, a.c1), fp_add(a.c0, a.c1));
-    return {t, fp_dbl(v)};
-}
-__device__ __forceinline__ Jac2 v_dbl(const Jac2& p) {  // dbl-2009-l, a = 0
-    Fp2 A = v_sqr(p.x), B = v_sqr(p.y), C = v_sqr(B);
-    Fp2 D = fp2_dbl(fp2_sub(fp2_sub(v_sqr(fp2_add(p.x, B)), A), C));
-    Fp2 E = fp2_add(fp2_dbl(A), A);
-    Fp2 x3 = fp2_sub(v_sqr(E), fp2_dbl(D));
-    Fp2 y3 = fp2_sub(fp2_mul_inl(E, fp2_sub(D, x3)), fp2_dbl(fp2_dbl(fp2_dbl(C))));
-    Fp2 z3 = fp2_dbl(fp2_mul_inl(p.y, p.z));
-    return {x3, y3, z3};
-}
-__device__ __forceinline__ Jac1v v1_dbl(const Jac1v& p) {
-    Fp A = fp_sqr(p.x), B = fp_sqr(p.y), C = fp_sqr(B);
-    Fp D = fp_dbl(fp_sub(fp_sub(fp_sqr(fp_add(p.x, B)), A), C));
-    Fp E = fp_add(fp_dbl(A), A);
-    Fp x3 = fp_sub(fp_sqr(E), fp_dbl(D));
-    Fp y3 = fp_sub(fp_mul(E, fp_sub(D, x3)), fp_dbl(fp_dbl(fp_dbl(C))));
-    Fp z3 = fp_dbl(fp_mul(p.y, p.z));
-    return {x3, y3, z3};
-}
-__device__ __forceinline__ Jac1v v1_add_mixed(const Jac1v& p, const Fp& qx, const Fp& qy) {
-    if (fp_is_zero(p.z)) return {qx, qy, fp_one()};
-    Fp z1z1 = fp_sqr(p.z);
-    Fp u2 = fp_mul(qx, z1z1);
-    Fp s2 = fp_mul(fp_mul(qy, p.z), z1z1);
-    Fp h = fp_sub(u2, p.x);
-    Fp rr = fp_dbl(fp_sub(s2, p.y));
-    if (fp_is_zero(h)) {
-        if (fp_is_zero(rr)) return v1_dbl(p);
-        return {fp_one(), fp_one(), fp_zero()};
+// Jacobian points of a lane parked in workspace rows (element-major: row * N + lane, coalesced): the line-coefficient area of
+// prepare_g2(H(m)), which the value-only entries do not use
+struct ParkRows {
+    Fp* p;  // first row, this lane
+    uint64_t n;
+    __device__ __forceinline__ void st(int slot, const Jac2& v) const {
+        Fp* o = p + (uint64_t)(6 * slot) * n;
+        st_fp(o, v.x.c0);
+        st_fp(o + n, v.x.c1);
+        st_fp(o + 2 * n, v.y.c0);
+        st_fp(o + 3 * n, v.y.c1);
+        st_fp(o + 4 * n, v.z.c0);
+        st_fp(o + 5 * n, v.z.c1);
     }
-    Fp hh = fp_sqr(h);
-    Fp i = fp_dbl(fp_dbl(hh));
-    Fp j = fp_mul(h, i);
-    Fp v = fp_mul(p.x, i);
-    Fp x3 = fp_sub(fp_sub(fp_sqr(rr), j), fp_dbl(v));
-    Fp y3 = fp_sub(fp_mul(rr, fp_sub(v, x3)), fp_dbl(fp_mul(p.y, j)));
-    Fp z3 = fp_sub(fp_sub(fp_sqr(fp_add(p.z, h)), z1z1), hh);
-    return {x3, y3, z3};
-}
-__device__ __forceinline__ Jac2 v_add_mixed(const Jac2& p, const Fp2& qx, const Fp2& qy) {  // madd-2007-bl; p = 0, p = +-q handled
-    if (fp2_is_zero(p.z)) return {qx, qy, fp2_one()};
-    Fp2 z1z1 = v_sqr(p.z);
-    Fp2 u2 = fp2_mul_inl(qx, z1z1);
-    Fp2 s2 = fp2_mul_inl(fp2_mul_inl(qy, p.z), z1z1);
-    Fp2 h = fp2_sub(u2, p.x);
-    Fp2 rr = fp2_dbl(fp2_sub(s2, p.y));
-    if (fp2_is_zero(h)) {
-        if (fp2_is_zero(rr)) return v_dbl(p);
-        return {fp2_one(), fp2_one(), fp2_zero()};
+    __device__ __forceinline__ Jac2 ld(int slot) const {
+        const Fp* o = p + (uint64_t)(6 * slot) * n;
+        return {ld_fp2(o, n), ld_fp2(o + 2 * n, n), ld_fp2(o + 4 * n, n)};
     }
-    Fp2 hh = v_sqr(h);
-    Fp2 i = fp2_dbl(fp2_dbl(hh));
-    Fp2 j = fp2_mul_inl(h, i);
-    Fp2 v = fp2_mul_inl(p.x, i);
-    Fp2 x3 = fp2_sub(fp2_sub(v_sqr(rr), j), fp2_dbl(v));
-    Fp2 y3 = fp2_sub(fp2_mul_inl(rr, fp2_sub(v, x3)), fp2_dbl(fp2_mul_inl(p.y, j)));
-    Fp2 z3 = fp2_sub(fp2_sub(v_sqr(fp2_add(p.z, h)), z1z1), hh);
-    return {x3, y3, z3};
-}
-}  // namespace
-// map_to_curve_9mod16 + isogeny_map (hasher.rs:352-502, 294-348) for the value-only entries: the statements of
-// chain_map_to_curve without the witness cursor, on the inlined Fp2 operations above (two waves per SIMD). Same field
-// operations in the same order, so the result is the same element bit for bit.
-namespace {
-__device__ __forceinline__ bool v_eq(const Fp2& a, const Fp2& b) { return fp_eq(a.c0, b.c0) && fp_eq(a.c1, b.c1); }
-__device__ __forceinline__ Fp2 v_sel(bool c, const Fp2& a, const Fp2& b) { return c ? a : b; }
-__device__ __forceinline__ bool v_sgn0(const Fp2& v) {  // hasher.rs:520-530
-    const Fp c0 = fp_to_canonical(v.c0), c1 = fp_to_canonical(v.c1);
-    return (c0.l[0] & 1) || (fp_is_zero(v.c0) && (c1.l[0] & 1));
-}
-__device__ __forceinline__ Fp2 v_poly(const Fp2* k, int n, const Fp2& x) {  // sum k[i] x^i, powers as DensePolynomialVar::evaluate builds them
-    Fp2 result = k[0], cp = x;
-    for (int i = 1; i < n; i++) {
-        result = fp2_add(result, fp2_mul_inl(cp, k[i]));
-        if (i + 1 < n) cp = fp2_mul_inl(cp, x);
-    }
-    return result;
-}
-__device__ __forceinline__ Proj<OpsFp2> v_map_to_curve(const Fp2& u) {
-    constexpr uint32_t C1[24] = BLSW_SSWU_C1_WORDS;
-    const Fp2 Z = K_SSWU_Z(), A = K_SSWU_A(), B = K_SSWU_B(), C2 = K_SSWU_C2(), C3 = K_SSWU_C3(), C4 = K_SSWU_C4(), C5 = K_SSWU_C5();
-    Fp2 tv1 = v_sqr(u);
-    Fp2 tv3 = fp2_mul_inl(Z, tv1);
-    Fp2 tv5 = v_sqr(tv3);
-    Fp2 xd = fp2_add(tv5, tv3);
-    Fp2 x1n = fp2_mul_inl(fp2_add(xd, fp2_one()), B);
-    xd = fp2_mul_inl(K_SSWU_NEG_A(), xd);
-    xd = v_sel(fp2_is_zero(xd), K_SSWU_ZA(), xd);
-    Fp2 tv2 = v_sqr(xd);
-    Fp2 gxd = fp2_mul_inl(tv2, xd);
-    tv2 = fp2_mul_inl(A, tv2);
-    Fp2 gx1 = fp2_add(v_sqr(x1n), tv2);
-    gx1 = fp2_mul_inl(gx1, x1n);
-    gx1 = fp2_add(gx1, fp2_mul_inl(B, gxd));
-    Fp2 tv4 = v_sqr(gxd);
-    tv2 = fp2_mul_inl(tv4, gxd);
-    tv4 = v_sqr(tv4);
-    tv2 = fp2_mul_inl(tv2, tv4);
-    tv2 = fp2_mul_inl(tv2, gx1);
-    tv4 = v_sqr(tv4);
-    tv4 = fp2_mul_inl(tv2, tv4);
-    Fp2 y = tv4;  // y = tv4 ^ c1 (bits 759, 758 are zero, bit 757 is the leading one)
-#pragma unroll 1
-    for (int i = BLSW_SSWU_C1_NBITS - 4; i >= 0; i--) {
-        y = v_sqr(y);
-        if (bit_of(C1, i)) y = fp2_mul_inl(y, tv4);
-    }
-    y = fp2_mul_inl(y, tv2);
-    tv4 = fp2_mul_inl(y, C2);
-    y = v_sel(v_eq(fp2_mul_inl(v_sqr(tv4), gxd), gx1), tv4, y);
-    tv4 = fp2_mul_inl(y, C3);
-    y = v_sel(v_eq(fp2_mul_inl(v_sqr(tv4), gxd), gx1), tv4, y);
-    tv4 = fp2_mul_inl(tv4, C2);
-    y = v_sel(v_eq(fp2_mul_inl(v_sqr(tv4), gxd), gx1), tv4, y);
-    Fp2 gx2 = fp2_mul_inl(fp2_mul_inl(gx1, tv5), tv3);
-    tv5 = fp2_mul_inl(fp2_mul_inl(y, tv1), u);
-    tv1 = fp2_mul_inl(tv5, C4);
-    tv4 = fp2_mul_inl(tv1, C2);
-    tv1 = v_sel(v_eq(fp2_mul_inl(v_sqr(tv4), gxd), gx2), tv4, tv1);
-    tv4 = fp2_mul_inl(tv5, C5);
-    tv1 = v_sel(v_eq(fp2_mul_inl(v_sqr(tv4), gxd), gx2), tv4, tv1);
-    tv4 = fp2_mul_inl(tv4, C2);
-    tv1 = v_sel(v_eq(fp2_mul_inl(v_sqr(tv4), gxd), gx2), tv4, tv1);
-    const bool e8 = v_eq(fp2_mul_inl(v_sqr(y), gxd), gx1);
-    y = v_sel(e8, y, tv1);
-    const Fp2 xn = v_sel(e8, x1n, fp2_mul_inl(tv3, x1n));
-    const bool e9 = !(v_sgn0(u) ^ v_sgn0(y));
-    y = v_sel(e9, y, fp2_neg(y));
-    // to_projective_short (hasher.rs:551-559), to_affine_unchecked (:569-583), isogeny_map (:294-348)
-    const Fp2 xd3 = fp2_mul_inl(v_sqr(xd), xd);
-    const Fp2 jx = fp2_mul_inl(xn, xd), jy = fp2_mul_inl(y, xd3);
-    const bool is_infinity = fp2_is_zero(xd);
-    const Fp2 zi = fp2_inv_inl(xd), zi2 = v_sqr(zi);
-    const Fp2 ax = fp2_mul_inl(jx, zi2), ay = fp2_mul_inl(jy, fp2_mul_inl(zi2, zi));
-    const Fp2 kxd[3] = {K_ISO_XDEN0(), K_ISO_XDEN1(), K_ISO_XDEN2()};
-    const Fp2 kyd[4] = {K_ISO_YDEN0(), K_ISO_YDEN1(), K_ISO_YDEN2(), K_ISO_YDEN3()};
-    const Fp2 kxn[4] = {K_ISO_XNUM0(), K_ISO_XNUM1(), K_ISO_XNUM2(), K_ISO_XNUM3()};
-    const Fp2 kyn[4] = {K_ISO_YNUM0(), K_ISO_YNUM1(), K_ISO_YNUM2(), K_ISO_YNUM3()};
-    const Fp2 x_den_inv = fp2_inv_inl(v_poly(kxd, 3, ax));
-    const Fp2 y_den_inv = fp2_inv_inl(v_poly(kyd, 4, ax));
-    const Fp2 img_x = fp2_mul_inl(v_poly(kxn, 4, ax), x_den_inv);
-    const Fp2 img_y = fp2_mul_inl(fp2_mul_inl(v_poly(kyn, 4, ax), ay), y_den_inv);
-    Proj<OpsFp2> q;
-    q.x = v_sel(is_infinity, fp2_zero(), img_x);
-    q.y = v_sel(is_infinity, fp2_zero(), img_y);
-    q.z = is_infinity ? fp2_zero() : fp2_one();
-    return q;
-}
-}  // namespace
+};
 
 }  // namespace blsw

@@ -8,6 +8,7 @@
 #include "../../bls-verify-gadget_amd/csrc/decode.cuh"
 #include "../../bls-verify-gadget_amd/csrc/layout.h"
 #include "../../bls-verify-gadget_amd/csrc/team.cuh"
+#include "../../bls-verify-gadget_amd/csrc/vsign.cuh"
 #include <array>
 
 using namespace blsw;
@@ -138,6 +139,11 @@ static bool pairing_segment(uint32_t* base, const blsw_layout_t& L, const Fp& ax
     return r;
 }
 
+struct ParkHost {
+    Jac2* p;
+    void st(int slot, const Jac2& v) const { p[slot] = v; }
+    Jac2 ld(int slot) const { return p[slot]; }
+};
 extern "C" {
 void hostsim_use_team(int on) { g_use_team = on; }
 int hostsim_layout(uint32_t msg_len, blsw_layout_t* L) {
@@ -308,7 +314,7 @@ int hostsim_g2_decode(const uint8_t* in, uint64_t* out_xy) {
     memcpy(out_xy + 18, y.c1.l, 48);
     return st;
 }
-// signer logic (decode.cuh): sk (32 LE bytes), H(msg) affine -> sig96, pk48; returns the SIGN_* status
+// signer logic (vsign.cuh, what k_sign runs per lane): sk (32 LE bytes), H(msg) affine -> sig96, pk48; returns the SIGN_* status
 int hostsim_sign(const uint8_t* sk32, const uint64_t* h_xy, uint8_t* sig96, uint8_t* pk48) {
     uint32_t k[8];
     int st = sk_from_le32(sk32, k);
@@ -317,8 +323,21 @@ int hostsim_sign(const uint8_t* sk32, const uint64_t* h_xy, uint8_t* sig96, uint
     bool sinf = true, pinf = true;
     if (st == SIGN_OK) {
         Fp2 hx = {load_fp(h_xy), load_fp(h_xy + 6)}, hy = {load_fp(h_xy + 12), load_fp(h_xy + 18)};
-        sinf = !g2_mul_affine(hx, hy, k, x, y);
-        pinf = !g1_mul_affine(K_G1_GEN_X(), fp_neg(K_G1_GEN_NEG_Y()), k, px, py);
+        Jac2 park[16];
+        Jac2 acc = v_g2_mul_gls(ParkHost{park}, Jac2{hx, hy, fp2_one()}, k);
+        if (!fp2_is_zero(acc.z)) {
+            Fp2 zi = fp2_inv(acc.z), zi2 = fp2_sqr(zi);
+            x = fp2_mul(acc.x, zi2);
+            y = fp2_mul(acc.y, fp2_mul(zi2, zi));
+            sinf = false;
+        }
+        Jac1v a1 = v1_mul_g1_fixed(k);
+        if (!fp_is_zero(a1.z)) {
+            Fp zi = fp_inv(a1.z), zi2 = fp_sqr(zi);
+            px = fp_mul(a1.x, zi2);
+            py = fp_mul(a1.y, fp_mul(zi2, zi));
+            pinf = false;
+        }
     }
     g2_encode(x, y, sinf, sig96);
     g1_encode(px, py, pinf, pk48);
@@ -341,6 +360,27 @@ int64_t hostsim_r1cs_check(uint64_t n_cons, const uint64_t* const* row_ptr, cons
     for (uint64_t i = 0; i < n_cons; i++)
         if (!fp_eq(fp_mul(dot(0, i), dot(1, i)), dot(2, i))) return (int64_t)i;
     return -1;
+}
+// value-only hash_to_g2 (vcurve.cuh: what blsw_hash_to_g2_batch / blsw_sign_batch run per lane): expand_message values,
+// hash_to_field, SSWU + isogeny x 2, Q0 + Q1, psi-based cofactor clearing; affine result (all zero = identity)
+void hostsim_hash_to_g2_values(const uint8_t* msg, uint32_t msg_len, uint64_t* out_xy) {
+    uint32_t uw[64];
+    expand_message_values(msg, msg_len, uw);
+    Fp2 u0 = {hash_to_field_elem(uw), hash_to_field_elem(uw + 16)}, u1 = {hash_to_field_elem(uw + 32), hash_to_field_elem(uw + 48)};
+    Proj<OpsFp2> q0 = v_map_to_curve(u0), q1 = v_map_to_curve(u1);
+    Jac2 r = {q0.x, q0.y, q0.z};
+    if (fp2_is_zero(q0.z)) r = {fp2_one(), fp2_one(), fp2_zero()};
+    if (!fp2_is_zero(q1.z)) r = v_add_mixed(r, q1.x, q1.y);
+    Jac2 park[3];
+    Jac2 acc = v_clear_cofactor(ParkHost{park}, r);
+    memset(out_xy, 0, 24 * 8);
+    if (fp2_is_zero(acc.z)) return;
+    Fp2 zi = fp2_inv(acc.z), zi2 = fp2_sqr(zi);
+    Fp2 x = fp2_mul(acc.x, zi2), y = fp2_mul(acc.y, fp2_mul(zi2, zi));
+    memcpy(out_xy, x.c0.l, 48);
+    memcpy(out_xy + 6, x.c1.l, 48);
+    memcpy(out_xy + 12, y.c0.l, 48);
+    memcpy(out_xy + 18, y.c1.l, 48);
 }
 // field micro-checks
 void hostsim_fp_mul(const uint64_t* a, const uint64_t* b, uint64_t* r) {

@@ -244,3 +244,33 @@ def test_team_table_invariants():
         for o in op.out:
             o.lists()
             assert all(slot in written or slot < gen.P0 or slot >= gen.X0 for slot in o.d), op.name
+
+
+def test_value_only_hash_to_g2_device_logic(oracle):
+    """vcurve.cuh (SSWU + isogeny without witnesses, psi-based cofactor clearing: two 64-bit ladders instead of the 636-bit
+    h_eff ladder of the circuit) gives the point of hash_to_g2_with_cons (hasher.rs:727-740) — the reference's own equality,
+    hasher.rs:1004-1026 — for the bls.rs:645 input, the reference's test strings and ragged lengths."""
+    msgs = [b"", b"abc", b"abcdef0123456789", b"\x00" * 32, bytes(range(55)), bytes(range(56)), bytes(range(119)), bytes(range(120)), b"q" * 300]
+    for m in msgs:
+        _, want = oracle.hash_to_g2(m)
+        got = hostsim_lib.hash_to_g2_values(m)
+        assert np.array_equal(got, want), len(m)
+
+
+def test_sign_random_scalars_device_logic(oracle):
+    """vsign.cuh against the oracle's signer on scalars that exercise every digit pattern of the base-|x| decomposition
+    (small, one-digit, digit borders, near r) and random ones: sig = sk * H(m) through the psi ladder, pk = sk * g1 through the
+    fixed-base windows."""
+    import random
+
+    r = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+    z = 0xD201000000010000
+    rng = random.Random(7)
+    sks = [1, 2, 15, 16, z - 1, z, z + 1, z * z, z * z - 1, z ** 3, z ** 3 + z * z + z + 1, r - 1, r - 2, (1 << 254) + 1] + [rng.randrange(1, r) for _ in range(10)]
+    msg = b"vsign"
+    _, h_xy = oracle.hash_to_g2(msg)
+    for sk in sks:
+        st, sig, pk = hostsim_lib.sign(sk.to_bytes(32, "little"), h_xy)
+        assert st == 0
+        assert sig == oracle.sign(sk, msg), hex(sk)
+        assert pk == oracle.sk_to_pk(sk), hex(sk)
