@@ -57,6 +57,8 @@ def parse_args():
     ap.add_argument("--mem-frac", type=float, default=0.68, help="share of the free HBM the engine workspace and the output ring may take")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=256, help="instances of the batch timed on the host (all cores, and one thread)")
+    ap.add_argument("--consumer-shard", type=int, default=8192,
+                    help="instances of the consumer-mode leg at N = 1 (configs[2]'s per-GPU shard streamed through a ring of two tensors with the digest kernel reading every one; 0 = skip)")
     ap.add_argument("--allgather-steps", type=int, default=32, help="steps of the generation + all-gather leg (0 = skip; runs when a process group exists)")
     ap.add_argument("--allgather-chunk", type=int, default=64, help="instances per rank in one all-gathered micro-batch (form full)")
     ap.add_argument("--allgather-group", type=int, default=16, help="steps per launch group in the all-gather leg (consumer-mode engine)")
@@ -364,6 +366,9 @@ def main():
     exp_count, exp_avg_ms = eng.expand_stats()
     res = torch.stack(results)
     ok = bool((res.cpu().numpy().astype(bool) == expect[None, :]).all())
+    # what the timed region left in the ring: every step submitted the same batch, so each ring tensor must hold exactly the
+    # witness vectors a direct-mode engine (chains write in place, no staging, no expansion ordering) produces for that batch
+    ring_digests = [pkg.witness_digest(o).cpu() for o in outs]
     gathered_ok = None
     if dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -372,8 +377,33 @@ def main():
         allres = sharding.all_gather_results(results[0], n * world)  # result shards only (multi-GPU)
         gathered_ok = bool(allres.numel() == n * world)
     eng.close()
-    del eng, outs
+    del eng
+    direct = pkg.WitnessEngine(n, 32, max_steps=1, device=dev, n_buffers=1)
+    direct.submit(d_pk, d_sig, d_msg, witness=outs[0], result=results[0])
+    direct.flush()
+    torch.cuda.synchronize()
+    ref_digest = pkg.witness_digest(outs[0]).cpu()
+    direct.close()
+    witness_ok = bool(all(torch.equal(d, ref_digest) for d in ring_digests)) and bool(ref_digest.abs().sum().item() != 0)
+    del direct, outs
     torch.cuda.empty_cache()
+
+    consumer = None
+    if world == 1 and args.consumer_shard >= 2 * n:  # the real-use rate: a consumer reads every tensor before it is overwritten
+        try:
+            shard = args.consumer_shard // n * n
+            sharding.stream_shard(pkg, 2 * n, n, 2, 0, 1, device=dev)  # warm-up: code objects, scratch, allocator
+            torch.cuda.empty_cache()
+            cs = sharding.stream_shard(pkg, shard, n, 2, 0, 1, device=dev)
+            consumer = {"value": cs["instances_per_s"], "unit": "instances/s", "shard_instances": shard, "steps": cs["steps"], "ring": 2, "group_steps": cs["group_steps"],
+                        "seconds": cs["seconds"], "results_ok": cs["results_ok"],
+                        "digests_equal_free_running": bool((cs["digests"][:n].view("int64") == ref_digest.numpy()).all()) if cs["first_instance"] == 0 else None,
+                        "consumer": "blsw_witness_digest reads every witness tensor before the engine may overwrite it (consumer-mode engine: late materialisation)",
+                        "hbm_bytes_per_instance": 2 * lay["n_witness"] * 48}
+            del cs
+        except Exception as exc:  # noqa: BLE001 (reported in the JSON line)
+            consumer = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        torch.cuda.empty_cache()
 
     ag = None
     if dist and args.allgather_steps > 0:
@@ -423,7 +453,7 @@ def main():
         "dtype": "u32 (381-bit Montgomery integers mod the BLS12-381 prime as 12 x 32-bit limbs in memory, products on 14 x 28-bit limbs with 64-bit columns; SHA-256 words)",
         "data": "synthetic",
         "config": {"workload": "configs[1]: batch of 1024 independent BLS-verify instances per GPU per step (1024 distinct messages, 16 keys, every 16th tampered), 32-byte messages, full witness vectors written",
-                   "instances_per_gpu_per_step": n, "batches_fused_per_launch_group": coalesce, "groups_in_flight": buffers, "output_ring": n_out, "n_witness": lay["n_witness"], "results_ok": ok,
+                   "instances_per_gpu_per_step": n, "batches_fused_per_launch_group": coalesce, "groups_in_flight": buffers, "output_ring": n_out, "n_witness": lay["n_witness"], "results_ok": ok, "witness_ok": witness_ok,
                    "result_shards_gathered": gathered_ok},
         "roofline": {"bound": "hbm", "kernel": "k_sha_expand", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                      "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": expand_bytes, "avg_launch_ms": exp_avg_ms, "launches_timed": exp_count},
@@ -444,6 +474,10 @@ def main():
         tot = whole_step["write_bytes"] + whole_step["fetch_bytes"]
         out["roofline_hbm_total"] = {"bound": "hbm", "traffic_per_step": tot, "achieved": tot / (dt / args.steps) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                      "frac": tot / (dt / args.steps) / 1e9 / HBM_PEAK_GBPS, "source": "profiles/r02_traffic.json whole_step (rocprofv3 --pmc passes)"}
+    out["witness_ok"] = witness_ok  # digests of the ring tensors after the timed region == a direct-mode engine's on the same batch
+    if consumer:
+        out["value_consumer_mode"] = consumer.get("value")
+        out["consumer_mode"] = consumer
     if ag:
         ag_dt, ag_steps, ag_info = ag
         if ag_dt:

@@ -97,6 +97,7 @@ def lib():
         L.blsw_verify_multi_batch.argtypes = [vp, vp, u32, u32, vp, u64, vp, u64, vp, vp, u64, vp]
         L.blsw_engine_destroy.argtypes = [vp]
         L.blsw_engine_submit.argtypes = [vp, vp, vp, vp, vp, u64, vp, vp]
+        L.blsw_engine_submit_bytes.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, u64, vp, vp]
         L.blsw_engine_flush.argtypes = [vp, vp]
         L.blsw_engine_expand_stats.argtypes = [vp, ctypes.POINTER(u32), ctypes.POINTER(ctypes.c_float)]
         L.blsw_hash_to_g2_workspace_bytes.argtypes = [u64, u32, ctypes.POINTER(u64)]
@@ -112,7 +113,7 @@ def lib():
 
 
 EXPORTED_SYMBOLS = ["blsw_version", "blsw_layout", "blsw_engine_options_default", "blsw_engine_workspace_bytes", "blsw_engine_workspace_bytes_ex", "blsw_engine_create",
-                    "blsw_engine_create_ex", "blsw_engine_destroy", "blsw_engine_submit", "blsw_engine_submit_aggregate", "blsw_engine_flush", "blsw_engine_submitted", "blsw_engine_launched", "blsw_engine_materialised", "blsw_engine_wait_step",
+                    "blsw_engine_create_ex", "blsw_engine_destroy", "blsw_engine_submit", "blsw_engine_submit_bytes", "blsw_engine_submit_aggregate", "blsw_engine_flush", "blsw_engine_submitted", "blsw_engine_launched", "blsw_engine_materialised", "blsw_engine_wait_step",
                     "blsw_engine_output_consumed", "blsw_engine_compact_bytes", "blsw_engine_submit_compact", "blsw_engine_submit_aggregate_compact", "blsw_engine_expand_compact", "blsw_engine_expand_stats", "blsw_witness_digest", "blsw_hash_to_g2_workspace_bytes", "blsw_hash_to_g2_batch",
                     "blsw_decode_batch", "blsw_layout_aggregate", "blsw_aggregate_workspace_bytes", "blsw_aggregate_verify_batch", "blsw_layout_multi",
                     "blsw_verify_multi_workspace_bytes", "blsw_verify_multi_batch", "blsw_matrices_info", "blsw_matrices_fill", "blsw_sign_batch", "blsw_microbench"]
@@ -144,12 +145,22 @@ def _require_cuda():
 
 
 def engine_options(**overrides):
-    """blsw_engine_options_default (BLSW_* environment overrides applied there) with keyword overrides:
-    device, pairing_mode ("team"/"lane" or 0/1), g2_mode ("lane"/"team" or 0/1), expand_store, prio_mode, place_lds."""
+    """blsw_engine_options_default with keyword overrides: device, pairing_mode ("team"/"lane" or 0/1), g2_mode ("lane"/"team"
+    or 0/1), expand_variant, expand_store, prio_mode, place_lds, consumer_mode, output_form, n_keys. The library itself reads no
+    environment; for A/B runs of measurement scripts THIS function applies BLSW_PAIRING=lane, BLSW_G2=team, BLSW_EXPAND_VARIANT,
+    BLSW_EXPAND_NT, BLSW_PRIO_MODE, BLSW_PLACE_LDS (explicit keyword arguments win)."""
     o = blsw_engine_options_t()
     rc = lib().blsw_engine_options_default(ctypes.byref(o))
     if rc:
         raise BlswError("blsw_engine_options_default failed: %d" % rc)
+    env = os.environ
+    if env.get("BLSW_PAIRING", "")[:1] == "l":
+        o.pairing_mode = 1
+    if env.get("BLSW_G2", "")[:1] == "t" and o.pairing_mode == 0:
+        o.g2_mode = 1
+    for var, field in (("BLSW_EXPAND_VARIANT", "expand_variant"), ("BLSW_EXPAND_NT", "expand_store"), ("BLSW_PRIO_MODE", "prio_mode"), ("BLSW_PLACE_LDS", "place_lds")):
+        if env.get(var):
+            setattr(o, field, int(env[var]))
     names = {"pairing_mode": {"team": 0, "lane": 1}, "g2_mode": {"lane": 0, "team": 1}}
     for k, v in overrides.items():
         if v is None:
@@ -225,6 +236,27 @@ class WitnessEngine:
         self._keep = self._keep[-(self.n_buffers + 1) * self.max_steps:]
         return seq
 
+    def submit_bytes(self, pk48, sig96, msg, witness=None, result=None, stream=None):
+        """blsw_engine_submit_bytes: compressed points [n, 48] / [n, 96] uint8 -> (step number, pk_xy, sig_xy, status [n, 2]);
+        result[i] = 1 iff both points decode to non-identity subgroup points and the gadget's Boolean is true (tests.rs:244-263)."""
+        torch = self.torch
+        assert pk48.shape == (self.n, 48) and sig96.shape == (self.n, 96) and msg.shape == (self.n, self.msg_len)
+        assert pk48.is_contiguous() and sig96.is_contiguous() and msg.is_contiguous() and pk48.dtype == torch.uint8 and sig96.dtype == torch.uint8
+        if witness is not None:
+            assert witness.is_contiguous() and witness.shape[0] == self.n and witness.shape[1] >= self.n_witness
+        pk_xy = torch.empty((self.n, 12), dtype=torch.int64, device=self.device)
+        sig_xy = torch.empty((self.n, 24), dtype=torch.int64, device=self.device)
+        status = torch.empty((self.n, 2), dtype=torch.int32, device=self.device)
+        seq = self.submitted()
+        rc = lib().blsw_engine_submit_bytes(self._e, pk48.data_ptr(), sig96.data_ptr(), msg.data_ptr() if self.msg_len else None, pk_xy.data_ptr(), sig_xy.data_ptr(),
+                                            status.data_ptr(), witness.data_ptr() if witness is not None else None, witness.shape[1] if witness is not None else 0,
+                                            result.data_ptr() if result is not None else None, self._stream(stream))
+        if rc:
+            raise (BlswBusy if rc == ERR_BUSY else BlswError)("blsw_engine_submit_bytes failed: %d" % rc)
+        self._keep.append((pk48, sig96, msg, pk_xy, sig_xy, status, witness, result))
+        self._keep = self._keep[-(self.n_buffers + 1) * self.max_steps:]
+        return seq, pk_xy, sig_xy, status
+
     def submit_aggregate(self, pks_xy, bitmap, sig_xy, msg, witness=None, result=None, count=None, stream=None):
         """aggregate_verify batch (engine created with n_keys=K): pks_xy [n, K, 12] int64, bitmap [n, K] uint8 -> step number"""
         K = self.n_keys
@@ -237,7 +269,7 @@ class WitnessEngine:
                                                 witness.data_ptr() if witness is not None else None, witness.shape[1] if witness is not None else 0,
                                                 result.data_ptr() if result is not None else None, count.data_ptr() if count is not None else None, self._stream(stream))
         if rc:
-            raise BlswError("blsw_engine_submit_aggregate failed: %d" % rc)
+            raise (BlswBusy if rc == ERR_BUSY else BlswError)("blsw_engine_submit_aggregate failed: %d" % rc)
         self._keep.append((pks_xy, bitmap, sig_xy, msg, witness, result, count))
         self._keep = self._keep[-(self.n_buffers + 1) * self.max_steps:]
         return seq
@@ -405,14 +437,16 @@ def decode_batch(pk48, sig96):
 
 
 def verify_bytes_batch(pk48, msg, sig96):
-    """tests/tests.rs:239-268 semantics on the GPU: decode, run the gadget, accept iff both points decode to non-identity
-    subgroup points and the in-circuit result is true. Returns a bool tensor [n]."""
+    """tests/tests.rs:239-268 semantics on the GPU in one ABI call (blsw_engine_submit_bytes): decode, run the gadget, accept iff
+    both points decode to non-identity subgroup points and the in-circuit result is true. Returns a bool tensor [n]."""
     torch = _require_cuda()
-    pk_xy, sig_xy, status = decode_batch(pk48, sig96)
-    g = BlsSignatureVerifyGadget(pk48.shape[0], msg.shape[1], device=pk48.device, want_witness=False)
-    res = g.verify(ParametersVar(), PublicKeyVar.new_witness(pk_xy), msg, SignatureVar.new_witness(sig_xy))
+    eng = WitnessEngine(pk48.shape[0], msg.shape[1], device=pk48.device)
+    res = torch.empty(pk48.shape[0], dtype=torch.int32, device=pk48.device)
+    eng.submit_bytes(pk48.contiguous(), sig96.contiguous(), msg.contiguous(), witness=None, result=res)
+    eng.flush()
     torch.cuda.synchronize(pk48.device)
-    return (status[:, 0] == ST_OK) & (status[:, 1] == ST_OK) & (res == 1)
+    eng.close()
+    return res == 1
 
 
 def layout_aggregate(msg_len, n_keys):

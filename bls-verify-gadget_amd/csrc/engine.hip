@@ -1,5 +1,6 @@
 // libblsw.so — the execution engine and the C ABI of include/blsw.h (host code; the kernels are in k_*.hip).
 #include <deque>
+#include <map>
 #include "kcommon.cuh"
 
 using namespace blsw;
@@ -26,6 +27,17 @@ struct DeviceGuard {
         if (switched) hipSetDevice(prev);
     }
 };
+
+// device that owns `st` (the current device for the NULL stream): the stateless entry points run there
+inline int stream_device(hipStream_t st) {
+    int dev = -1;
+    if (st) {
+        hipDevice_t d;
+        if (hipStreamGetDevice(st, &d) == hipSuccess) return (int)d;
+    }
+    hipGetDevice(&dev);
+    return dev;
+}
 
 }  // namespace
 
@@ -152,6 +164,17 @@ static int consumed_slot(blsw_engine* e, const void* ptr) {
         if (e->consumed_ptr[c] == ptr && (e->consumed_live[c] || e->held[c])) return c;
     return -1;
 }
+// a free slot of the release table; a recorded release whose event has completed needs no wait any more and is recycled
+static int free_consumed_slot(blsw_engine* e) {
+    for (int c = 0; c < BLSW_MAX_CONSUMED; c++)
+        if (!e->consumed_live[c] && !e->held[c]) return c;
+    for (int c = 0; c < BLSW_MAX_CONSUMED; c++)
+        if (e->consumed_live[c] && !e->held[c] && hipEventQuery(e->consumed_ev[c]) == hipSuccess) {
+            e->consumed_live[c] = false;
+            return c;
+        }
+    return -1;
+}
 // a consumer's release of an output (blsw_engine_output_consumed): the stream that is about to overwrite it waits for it
 static void wait_released(blsw_engine* e, hipStream_t stream, const void* ptr) {
     const int c = consumed_slot(e, ptr);
@@ -205,19 +228,19 @@ static int pump(blsw_engine* e) {
         const StepDesc& d = b.h_desc[j.s];
         const void* ptr = d.out ? static_cast<const void*>(d.out) : d.compact;
         const bool track = e->opt.consumer_mode && e->staged && ptr;
+        int slot = -1;
         if (track) {
-            const int c = consumed_slot(e, ptr);
-            if (c >= 0 && e->held[c]) break;
+            slot = consumed_slot(e, ptr);
+            if (slot >= 0 && e->held[slot]) break;
+            if (slot < 0) slot = free_consumed_slot(e);
+            if (slot < 0) return BLSW_ERR_ARG;  // more than BLSW_MAX_CONSUMED outputs in use: nothing issued, the step stays queued
+        }
+        if (slot >= 0 && e->consumed_ptr[slot] != ptr) {  // a fresh slot for this output (an existing one keeps its recorded release)
+            e->consumed_ptr[slot] = ptr;
+            e->consumed_live[slot] = false;
         }
         materialise(e, j.buf, j.s);
-        if (track) {
-            int c = consumed_slot(e, ptr);
-            for (int i = 0; i < BLSW_MAX_CONSUMED && c < 0; i++)
-                if (!e->consumed_live[i] && !e->held[i]) c = i;
-            if (c < 0) return BLSW_ERR_ARG;  // more than BLSW_MAX_CONSUMED outputs in use
-            e->consumed_ptr[c] = ptr;
-            e->held[c] = true;
-        }
+        if (slot >= 0) e->held[slot] = true;
         e->jobs.pop_front();
         e->materialised++;
         if (--b.jobs_left == 0) hipEventRecord(b.ev_done, e->place);
@@ -295,11 +318,6 @@ static int launch_group(blsw_engine* e) {
     return pump(e);
 }
 
-static uint32_t env_u32(const char* name, uint32_t dflt) {
-    const char* s = getenv(name);
-    return s && *s ? (uint32_t)strtoul(s, nullptr, 10) : dflt;
-}
-
 extern "C" {
 
 int blsw_version(void) { return BLSW_ABI_VERSION; }
@@ -312,16 +330,14 @@ int blsw_layout(uint32_t msg_len, blsw_layout_t* out) {
 
 int blsw_engine_options_default(blsw_engine_options_t* o) {
     if (!o) return BLSW_ERR_ARG;
-    const char* p = getenv("BLSW_PAIRING");
-    const char* g2 = getenv("BLSW_G2");
     o->device = -1;
     o->n_keys = 0;
-    o->pairing_mode = (p && p[0] == 'l') ? 1u : 0u;
-    o->g2_mode = (g2 && g2[0] == 't' && o->pairing_mode == 0) ? 1u : 0u;
-    o->expand_variant = env_u32("BLSW_EXPAND_VARIANT", BLSW_DEFAULT_EXPAND_VARIANT);
-    o->expand_store = env_u32("BLSW_EXPAND_NT", 0);  // plain stores: nontemporal ones cost 8-10 % since the chains' stack traffic was cut
-    o->prio_mode = env_u32("BLSW_PRIO_MODE", 1);
-    o->place_lds = env_u32("BLSW_PLACE_LDS", 0);
+    o->pairing_mode = 0;
+    o->g2_mode = 0;
+    o->expand_variant = BLSW_DEFAULT_EXPAND_VARIANT;
+    o->expand_store = 0;  // plain stores: nontemporal ones cost 8-10 % since the chains' stack traffic was cut
+    o->prio_mode = 1;
+    o->place_lds = 0;
     o->consumer_mode = 0;
     o->output_form = 0;
     return BLSW_OK;
@@ -351,8 +367,12 @@ int blsw_engine_workspace_bytes(uint64_t n, uint32_t msg_len, uint32_t max_steps
 
 int blsw_engine_create_ex(blsw_engine_t** out, uint64_t n, uint32_t msg_len, uint32_t max_steps, uint32_t n_buffers, const blsw_engine_options_t* options,
                           void* d_workspace, uint64_t workspace_bytes) {
-    if (!out || n == 0 || n > 0x7fffffffu || max_steps == 0 || !d_workspace || n_buffers == 0 || n_buffers > BLSW_MAX_BUFFERS || !options || msg_len > 65535)
+    // n is the y extent of the expansion / canonical-form launches (one row of workgroups per instance): at most 65535
+    if (!out || n == 0 || n > 65535 || max_steps == 0 || !d_workspace || n_buffers == 0 || n_buffers > BLSW_MAX_BUFFERS || !options || msg_len > 65535)
         return BLSW_ERR_ARG;
+    // consumer mode is late materialisation out of the staging: a direct-mode engine (one step, one buffer) writes its witnesses in
+    // place while the chains run and could not honour a held output
+    if (options->consumer_mode > 1 || (options->consumer_mode == 1 && max_steps == 1 && n_buffers == 1)) return BLSW_ERR_ARG;
     if (options->pairing_mode > 1 || options->g2_mode > 1 || (options->g2_mode == 1 && options->pairing_mode != 0) || options->expand_store > 3 ||
         options->prio_mode > 2 || options->output_form > 1 || (options->expand_variant & 0xff) > 5 || (options->expand_variant >> 9) || options->n_keys > 65535 ||
         (options->n_keys && options->g2_mode))
@@ -499,7 +519,24 @@ static int engine_submit(blsw_engine_t* e, const StepDesc& step, void* stream_) 
 int blsw_engine_submit(blsw_engine_t* e, const uint64_t* d_pk_xy, const uint64_t* d_sig_xy, const uint8_t* d_msg, uint64_t* d_witness,
                        uint64_t witness_stride, int32_t* d_result, void* stream_) {
     if (!e || e->L.n_keys || !d_pk_xy || !d_sig_xy || (!d_msg && e->msg_len)) return BLSW_ERR_ARG;
-    StepDesc d = {d_pk_xy, d_sig_xy, d_msg, d_witness, witness_stride, d_result, nullptr, nullptr, nullptr, nullptr};
+    StepDesc d = {d_pk_xy, d_sig_xy, d_msg, d_witness, witness_stride, d_result, nullptr, nullptr, nullptr, nullptr, nullptr};
+    return engine_submit(e, d, stream_);
+}
+// One call from compressed bytes: decode on `stream`, then the step; result[i] = gadget Boolean AND both points decoded
+// to non-identity subgroup points (tests/tests.rs:244-263: a point that fails to decode is replaced by the default — the identity —
+// and the case must come out false). The decoded coordinates live in caller buffers (they are the step's inputs).
+int blsw_engine_submit_bytes(blsw_engine_t* e, const uint8_t* d_pk48, const uint8_t* d_sig96, const uint8_t* d_msg, uint64_t* d_pk_xy, uint64_t* d_sig_xy,
+                             int32_t* d_status, uint64_t* d_witness, uint64_t witness_stride, int32_t* d_result, void* stream_) {
+    if (!e || e->L.n_keys || !d_pk48 || !d_sig96 || !d_pk_xy || !d_sig_xy || !d_status || (!d_msg && e->msg_len)) return BLSW_ERR_ARG;
+    if (d_witness && witness_stride < e->L.n_witness) return BLSW_ERR_ARG;
+    DeviceGuard guard(e->device);
+    // the decode is issued only if the step can be taken (same conditions as engine_submit: nothing may be half done on BUSY)
+    GroupBuf& b = e->buf[e->cur];
+    if (e->pending == 0 && b.used && b.jobs_left) return BLSW_ERR_BUSY;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream_);
+    hipLaunchKernelGGL(k_decode, dim3((unsigned)((2 * e->n + 63) / 64)), dim3(64), 0, st, d_pk48, d_sig96, e->n, d_pk_xy, d_sig_xy, d_status);
+    if (hip_ok(hipGetLastError(), "launch")) return BLSW_ERR_HIP;
+    StepDesc d = {d_pk_xy, d_sig_xy, d_msg, d_witness, witness_stride, d_result, nullptr, nullptr, nullptr, nullptr, d_status};
     return engine_submit(e, d, stream_);
 }
 // aggregate_verify through the engine (an engine created with options.n_keys = K): one batch of n instances of K keys each
@@ -590,9 +627,8 @@ int blsw_engine_output_consumed(blsw_engine_t* e, const void* d_output, void* st
     if (!e || !d_output) return BLSW_ERR_ARG;
     DeviceGuard guard(e->device);
     int slot = consumed_slot(e, d_output);
-    for (int c = 0; c < BLSW_MAX_CONSUMED && slot < 0; c++)
-        if (!e->consumed_live[c] && !e->held[c]) slot = c;
-    if (slot < 0) return BLSW_ERR_ARG;  // more than BLSW_MAX_CONSUMED distinct outputs in use
+    if (slot < 0) slot = free_consumed_slot(e);
+    if (slot < 0) return BLSW_ERR_ARG;  // more than BLSW_MAX_CONSUMED distinct outputs with a pending release or a held step
     if (!e->consumed_ev[slot] && hip_ok(hipEventCreateWithFlags(&e->consumed_ev[slot], hipEventDisableTiming), "event create")) return BLSW_ERR_HIP;
     if (hip_ok(hipEventRecord(e->consumed_ev[slot], reinterpret_cast<hipStream_t>(stream_)), "event record")) return BLSW_ERR_HIP;
     e->consumed_ptr[slot] = d_output;
@@ -622,6 +658,7 @@ int blsw_engine_expand_stats(blsw_engine_t* e, uint32_t* count, float* avg_ms) {
 int blsw_witness_digest(const uint64_t* d_witness, uint64_t witness_stride, uint64_t n, uint32_t n_witness, uint64_t* d_digest, void* stream_) {
     if (!d_witness || !d_digest || n == 0 || n > 65535 || n_witness == 0 || witness_stride < n_witness) return BLSW_ERR_ARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream_);
+    DeviceGuard guard(stream_device(st));
     if (hip_ok(hipMemsetAsync(d_digest, 0, n * 2 * sizeof(uint64_t), st), "memset")) return BLSW_ERR_HIP;
     const uint64_t n_words = (uint64_t)n_witness * 6, per_block = 2ull * 256 * BLSW_DIGEST_ITERS;
     dim3 grid((unsigned)((n_words + per_block - 1) / per_block), (unsigned)n);
@@ -659,6 +696,7 @@ int blsw_hash_to_g2_batch(const uint8_t* d_msg, uint32_t msg_len, uint64_t n, ui
     if (ws.total_bytes + 256 > workspace_bytes) return BLSW_ERR_WORKSPACE;
     Group g = direct_group(n, 1, msg_len, L, d_desc, ws);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream_);
+    DeviceGuard guard(stream_device(st));  // the device that owns `stream`
     StepDesc h = {nullptr, nullptr, d_msg, nullptr, 0, nullptr, nullptr, nullptr, nullptr};
     if (int rc = put_desc(d_desc, h, st)) return rc;
     const unsigned g1 = (unsigned)((n + 63) / 64), g2 = (unsigned)((2 * n + 63) / 64);
@@ -679,6 +717,7 @@ int blsw_sign_batch(const uint8_t* d_sk32_le, const uint8_t* d_msg, uint32_t msg
     if (ws.total_bytes + 256 > workspace_bytes) return BLSW_ERR_WORKSPACE;
     Group g = direct_group(n, 1, msg_len, L, d_desc, ws);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream_);
+    DeviceGuard guard(stream_device(st));  // the device that owns `stream`
     StepDesc h = {nullptr, nullptr, d_msg, nullptr, 0, nullptr, nullptr, nullptr, nullptr};
     if (int rc = put_desc(d_desc, h, st)) return rc;
     const unsigned g1 = (unsigned)((n + 63) / 64), g2 = (unsigned)((2 * n + 63) / 64);
@@ -724,6 +763,7 @@ int blsw_aggregate_verify_batch(const uint64_t* d_pks_xy, const uint8_t* d_bitma
     Fp* keyproj = reinterpret_cast<Fp*>(base + off_keyproj);
     Group g = direct_group(n, 1, msg_len, L, d_desc, carve(base + off_ws, n, L, false, DEFAULT_MODES));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream_);
+    DeviceGuard guard(stream_device(st));  // the device that owns `stream`
     StepDesc h = {nullptr, d_sig_xy, d_msg, d_witness, witness_stride, d_result, d_pks_xy, d_bitmap, d_count};
     if (int rc = put_desc(d_desc, h, st)) return rc;
     const unsigned g1 = (unsigned)((n + 63) / 64), g2 = (unsigned)((2 * n + 63) / 64), gk = (unsigned)((n * n_keys + 63) / 64);
@@ -771,6 +811,8 @@ int blsw_verify_multi_batch(const uint64_t* d_pks_xy, const uint8_t* d_msgs, uin
     Group gp = direct_group(n, n_pairs, msg_len, L, d_desc, ws);  // per-pair work: N = n * n_pairs lanes
     Group gs = direct_group(n, 1, msg_len, L, d_desc, ws);        // per-signature work: N = n lanes
     hipStream_t st = reinterpret_cast<hipStream_t>(stream_);
+    const int dev = stream_device(st);  // the device that owns `stream`
+    DeviceGuard guard(dev);
     StepDesc h = {d_pks_xy, d_sig_xy, d_msgs, d_witness, witness_stride, d_result, nullptr, nullptr, nullptr};
     if (int rc = put_desc(d_desc, h, st)) return rc;
     const unsigned p1 = (unsigned)((NP + 63) / 64), p2 = (unsigned)((2 * NP + 63) / 64), s1 = (unsigned)((n + 63) / 64);
@@ -783,10 +825,8 @@ int blsw_verify_multi_batch(const uint64_t* d_pks_xy, const uint8_t* d_msgs, uin
         hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
         bool ok = false;
     };
-    static thread_local Side sides[16];
-    int dev = 0;
-    hipGetDevice(&dev);
-    Side& sd = sides[dev & 15];
+    static thread_local std::map<int, Side> sides;  // per host thread and device ordinal (the device that owns `stream`)
+    Side& sd = sides[dev];
     if (sd.device != dev) {
         sd.device = dev;
         sd.ok = hipStreamCreateWithFlags(&sd.aux[0], hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&sd.aux[1], hipStreamNonBlocking) == hipSuccess &&
@@ -831,6 +871,7 @@ int blsw_verify_multi_batch(const uint64_t* d_pks_xy, const uint8_t* d_msgs, uin
 int blsw_decode_batch(const uint8_t* d_pk48, const uint8_t* d_sig96, uint64_t n, uint64_t* d_pk_xy, uint64_t* d_sig_xy, int32_t* d_status, void* stream_) {
     if (!d_pk48 || !d_sig96 || !d_pk_xy || !d_sig_xy || !d_status || n == 0 || n > 0x3fffffffu) return BLSW_ERR_ARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream_);
+    DeviceGuard guard(stream_device(st));  // the device that owns `stream`
     hipLaunchKernelGGL(k_decode, dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, st, d_pk48, d_sig96, n, d_pk_xy, d_sig_xy, d_status);
     return hip_ok(hipGetLastError(), "launch");
 }

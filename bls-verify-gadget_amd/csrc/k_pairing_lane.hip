@@ -16,7 +16,7 @@ __global__ __launch_bounds__(64) void k_pairing(Group g) {
     Fp12 f = chain_miller(EMIT(g, id, off_miller), pkx, pky, cs, ch);
     bool res = chain_final_exp_is_one(EMIT(g, id, off_final_exp), EMIT(g, id, off_is_one), f);
     int32_t* r = g.desc[id.s].result;
-    if (r) r[id.i] = res ? 1 : 0;
+    if (r) r[id.i] = step_result(g.desc[id.s], id.i, res);
 }
 
 }  // namespace blsw

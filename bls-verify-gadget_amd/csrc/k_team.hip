@@ -29,7 +29,7 @@ __global__ __launch_bounds__(64) void k_pairing_team(Group g) {
     if (!active) e_one.base = nullptr;
     bool res = team_final_exp_is_one(t, f, e_one);
     int32_t* r = g.desc[id.s].result;
-    if (active && j == 0 && r) r[id.i] = res ? 1 : 0;
+    if (active && j == 0 && r) r[id.i] = step_result(g.desc[id.s], id.i, res);
 }
 // G2 allocation, six lanes per instance: the (r - 1) * sig chain of the subgroup check runs on the team machinery (points on
 // lanes 0..2), the allocation witnesses and the enforce_equal tail are single-lane work of lane 0
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(64) void k_pairing_team_multi(Group gs, uint32_t K,
     if (!active) e_one.base = nullptr;
     bool res = team_final_exp_is_one(t, f, e_one);
     int32_t* r = gs.desc[id.s].result;
-    if (active && j == 0 && r) r[id.i] = res ? 1 : 0;
+    if (active && j == 0 && r) r[id.i] = step_result(gs.desc[id.s], id.i, res);
 }
 void launch_pairing(const Group& g, const Modes& m, hipStream_t st) {
     if (!m.pairing_team)

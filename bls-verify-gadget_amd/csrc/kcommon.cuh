@@ -98,7 +98,14 @@ struct StepDesc {
     uint32_t* count;        // [n]
     // host side only: the step leaves the engine in its compact wire form (blsw_engine_submit_compact) instead of as witness vectors
     void* compact;
+    // blsw_engine_submit_bytes: [n][2] decode statuses of (pk, sig); result[i] = gadget Boolean AND both statuses BLSW_ST_OK
+    // (tests/tests.rs:244-263: a point that does not decode is replaced by the default and the case must verify false)
+    const int32_t* status;
 };
+__device__ __forceinline__ int32_t step_result(const StepDesc& d, uint32_t i, bool res) {
+    if (d.status && (d.status[2 * i] | d.status[2 * i + 1])) return 0;
+    return res ? 1 : 0;
+}
 // Compact wire form of a step of n instances (n a multiple of 64): the step's slices of the group workspace, back to back —
 // [n/64][sha_words/16][64][16] u32 bit words | [n/64][split_row][64] Fp tile-major rows | [n][pair_rows] Fp instance-major rows
 struct CompactForm {

@@ -1244,7 +1244,7 @@ static void circuit(uint32_t msg_len, uint32_t n_keys, uint32_t n_pairs) {
 }
 
 static int run(uint32_t msg_len, uint32_t n_keys, uint32_t n_pairs, Sys& sys) {
-    if (msg_len > 65535 || (n_keys && n_pairs > 1) || n_pairs == 0 || n_pairs > 4096) return BLSW_ERR_ARG;
+    if (msg_len > 65535 || n_keys > 65535 || (n_keys && n_pairs > 1) || n_pairs == 0 || n_pairs > 4096) return BLSW_ERR_ARG;
     S = &sys;
     circuit(msg_len, n_keys, n_pairs);
     sys.finish();
@@ -1274,8 +1274,14 @@ int blsw_matrices_info(uint32_t msg_len, uint32_t n_keys, uint32_t n_pairs, blsw
     blsw::r1cs::Cache& c = blsw::r1cs::cache();
     std::lock_guard<std::mutex> lock(c.mu);
     c.valid = false;
-    c.sys = blsw::r1cs::Sys();
-    int rc = blsw::r1cs::run(msg_len, n_keys, n_pairs, c.sys);
+    int rc;
+    try {  // no exception crosses the ABI: a system that does not fit in memory is BLSW_ERR_WORKSPACE
+        c.sys = blsw::r1cs::Sys();
+        rc = blsw::r1cs::run(msg_len, n_keys, n_pairs, c.sys);
+    } catch (...) {
+        c.sys = blsw::r1cs::Sys();
+        return BLSW_ERR_WORKSPACE;
+    }
     if (rc) return rc;
     c.valid = true;
     c.msg_len = msg_len;
@@ -1296,8 +1302,14 @@ int blsw_matrices_fill(uint32_t msg_len, uint32_t n_keys, uint32_t n_pairs, cons
     std::lock_guard<std::mutex> lock(c.mu);
     if (!(c.valid && c.msg_len == msg_len && c.n_keys == n_keys && c.n_pairs == n_pairs)) {
         c.valid = false;
-        c.sys = blsw::r1cs::Sys();
-        int rc = blsw::r1cs::run(msg_len, n_keys, n_pairs, c.sys);
+        int rc;
+        try {
+            c.sys = blsw::r1cs::Sys();
+            rc = blsw::r1cs::run(msg_len, n_keys, n_pairs, c.sys);
+        } catch (...) {
+            c.sys = blsw::r1cs::Sys();
+            return BLSW_ERR_WORKSPACE;
+        }
         if (rc) return rc;
     }
     const blsw::r1cs::Sys& s = c.sys;

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define BLSW_ABI_VERSION 6
+#define BLSW_ABI_VERSION 7
 
 #define BLSW_OK 0
 #define BLSW_ERR_ARG 1
@@ -81,7 +81,8 @@ int blsw_aggregate_verify_batch(const uint64_t* d_pks_xy, const uint8_t* d_bitma
  * bit for bit. Circuit allocation order: msg_0..msg_{K-1} witness bytes, params Constant, pk_0..pk_{K-1} Witness, sig Witness.
  *   d_pks_xy [n][n_pairs][12], d_msgs [n][n_pairs][msg_len], d_sig_xy [n][24]
  *   d_witness [n][witness_stride] (may be NULL), d_result [n] int32
- * Direct mode, asynchronous on `stream`. */
+ * Direct mode on the device that owns `stream`. The call copies its descriptor to the device and SYNCHRONISES `stream` once
+ * before issuing the kernels (asynchronous from there on); side streams are kept per host thread and device. */
 int blsw_layout_multi(uint32_t msg_len, uint32_t n_pairs, blsw_layout_t* out);
 int blsw_verify_multi_workspace_bytes(uint64_t n, uint32_t msg_len, uint32_t n_pairs, uint64_t* bytes);
 int blsw_verify_multi_batch(const uint64_t* d_pks_xy, const uint8_t* d_msgs, uint32_t msg_len, uint32_t n_pairs, const uint64_t* d_sig_xy, uint64_t n,
@@ -122,8 +123,7 @@ typedef struct {
                               The compact wire form is the same for both; blsw_engine_expand_compact follows the expanding
                               engine's option */
 } blsw_engine_options_t;
-/* defaults; the environment variables BLSW_PAIRING=lane, BLSW_G2=team, BLSW_EXPAND_VARIANT, BLSW_EXPAND_NT, BLSW_PRIO_MODE, BLSW_PLACE_LDS override
- * them HERE (read at every call, nothing is cached per process), so A/B runs need no recompilation */
+/* the defaults (pure: the library reads no environment variable; measurement scripts set the fields they want to vary) */
 int blsw_engine_options_default(blsw_engine_options_t* out);
 int blsw_engine_workspace_bytes(uint64_t n, uint32_t msg_len, uint32_t max_steps, uint32_t n_buffers, uint64_t* bytes);
 int blsw_engine_workspace_bytes_ex(uint64_t n, uint32_t msg_len, uint32_t max_steps, uint32_t n_buffers, const blsw_engine_options_t* options, uint64_t* bytes);
@@ -131,6 +131,9 @@ int blsw_engine_workspace_bytes_ex(uint64_t n, uint32_t msg_len, uint32_t max_st
  * allocated) when pairing_mode 1 is combined with so many group buffers that the runtime's per-queue scratch
  * (stack bytes x 64 lanes x wave slots of the device, per queue) would exceed what ROCr can back: that combination
  * used to abort the process with HSA_STATUS_ERROR_OUT_OF_RESOURCES. */
+/* BLSW_ERR_ARG also for: n > 65535 (one row of workgroups per instance in the expansion launches); options->consumer_mode > 1;
+ * options->consumer_mode == 1 on a direct-mode engine (max_steps == 1 and n_buffers == 1: it writes witnesses in place while
+ * the chains run and cannot hold a step back). */
 int blsw_engine_create(blsw_engine_t** out, uint64_t n, uint32_t msg_len, uint32_t max_steps, uint32_t n_buffers, void* d_workspace,
                        uint64_t workspace_bytes);
 int blsw_engine_create_ex(blsw_engine_t** out, uint64_t n, uint32_t msg_len, uint32_t max_steps, uint32_t n_buffers, const blsw_engine_options_t* options,
@@ -146,9 +149,22 @@ int blsw_engine_destroy(blsw_engine_t* e);
  *   d_result  [n] int32, may be NULL
  * Device work is issued when max_steps batches are pending or at blsw_engine_flush; `stream` (hipStream_t, may be NULL)
  * is the stream on which THIS batch's inputs become valid (recorded per submit). Buffers must stay alive until the
- * step has completed. Steps are numbered 0, 1, 2, ... in submission order (blsw_engine_submitted). */
+ * step has completed. Steps are numbered 0, 1, 2, ... in submission order (blsw_engine_submitted).
+ * Host blocking: the device work is asynchronous, but a submit that starts a new group in a group buffer whose previous group
+ * (n_buffers groups back) has not finished writing its outputs WAITS on the host for that group (its staging is about to be
+ * overwritten) — with n_buffers groups in flight this is the engine's back-pressure. In consumer mode it returns BLSW_ERR_BUSY
+ * instead when that group still has steps held back by unreleased outputs. */
 int blsw_engine_submit(blsw_engine_t* e, const uint64_t* d_pk_xy, const uint64_t* d_sig_xy, const uint8_t* d_msg, uint64_t* d_witness,
                        uint64_t witness_stride, int32_t* d_result, void* stream);
+/* The same step from COMPRESSED bytes in one call (PublicKey::try_from / Signature::try_from + verify, src/bls.rs:219-242, 316-339 and
+ * tests/tests.rs:239-268): d_pk48 [n][48] and d_sig96 [n][96] are decoded on `stream` into d_pk_xy [n][12] / d_sig_xy [n][24]
+ * (caller buffers: they are the step's inputs and must stay alive like them; a point that fails to decode, or the identity,
+ * becomes all zeros = the default point, as the reference's test substitutes it) with d_status [n][2] as blsw_decode_batch writes
+ * it, and the step is submitted. d_result[i] = 1 iff both statuses are BLSW_ST_OK and the gadget's Boolean is true — the
+ * verdict of tests/tests.rs:244-263. Witness vectors are written for every instance (for rejected inputs: the defined but
+ * unsatisfiable assignment of the default points). BLSW_ERR_BUSY as blsw_engine_submit (nothing is issued then). */
+int blsw_engine_submit_bytes(blsw_engine_t* e, const uint8_t* d_pk48, const uint8_t* d_sig96, const uint8_t* d_msg, uint64_t* d_pk_xy, uint64_t* d_sig_xy,
+                             int32_t* d_status, uint64_t* d_witness, uint64_t witness_stride, int32_t* d_result, void* stream);
 /* aggregate_verify (src/constraints.rs:153-191) through the engine, for an engine created with options.n_keys = K: one batch of n
  * instances of K keys each, same grouping / staging / streaming placement as blsw_engine_submit.
  *   d_pks_xy [n][K][12] u64, d_bitmap [n][K] bytes (0/1), d_sig_xy [n][24], d_msg [n][msg_len]
@@ -168,7 +184,9 @@ int blsw_engine_flush(blsw_engine_t* e, void* stream);
  * consumer_mode 0: that release must have been recorded before the group containing the next user of the output is launched
  * (max_steps <= ring). consumer_mode 1: no such rule — steps are written into their outputs in submission order, each as soon
  * as its output has been released; blsw_engine_submit returns BLSW_ERR_BUSY instead of blocking when the group buffer it needs
- * still has unwritten steps (drain: wait_step + output_consumed of the materialised steps, then submit again). */
+ * still has unwritten steps (drain: wait_step + output_consumed of the materialised steps, then submit again).
+ * At most 64 distinct output pointers may have a pending release or a held step at one time (BLSW_ERR_ARG beyond; releases
+ * whose event has completed are recycled). */
 int blsw_engine_submitted(blsw_engine_t* e, uint64_t* seq);
 int blsw_engine_launched(blsw_engine_t* e, uint64_t* seq);
 int blsw_engine_materialised(blsw_engine_t* e, uint64_t* seq);

@@ -6,6 +6,8 @@
  *   caller stream <pk48 hex> <msg hex> <sig96 hex>   64 copies of the instance, 5 steps through a consumer-mode engine (groups of 2)
  *       with ONE witness tensor and ONE compact buffer as the whole output ring: steps alternate plain / compact submits, the
  *       consumer (digest kernel; expand_compact first for compact steps) releases each output before the next step may use it
+ *   caller bytes <file>    every line "<pk48 hex> <msg32 hex> <sig96 hex>" is one instance of ONE batch through
+ *       blsw_engine_submit_bytes (decode + status rule + gadget in one call): prints results=<0/1 per instance> statuses=<pk,sig;...>
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -150,6 +152,45 @@ int main(int argc, char** argv) {
                (unsigned long long)cb, same, ok, res[0], busy, (unsigned long long)dig[0], (unsigned long long)dig[1]);
         return 0;
     }
-    fprintf(stderr, "usage: caller layout | caller verify <pk48> <msg32> <sig96> | caller stream <pk48> <msg32> <sig96> (hex)\n");
+    if (argc == 3 && !strcmp(argv[1], "bytes")) {
+        FILE* f = fopen(argv[2], "r");
+        if (!f) return 15;
+        enum { MAXN = 256 };
+        static uint8_t h_pk[MAXN * 48], h_msg[MAXN * 32], h_sig[MAXN * 96];
+        static char a[128], b[128], c[256];
+        int n = 0;
+        while (n < MAXN && fscanf(f, "%127s %127s %255s", a, b, c) == 3) {
+            if (unhex(a, h_pk + 48 * n, 48) || unhex(b, h_msg + 32 * n, 32) || unhex(c, h_sig + 96 * n, 96)) return 12;
+            n++;
+        }
+        fclose(f);
+        if (n == 0) return 16;
+        blsw_layout_t L;
+        CHECK(blsw_layout(32, &L));
+        uint8_t *d_pk, *d_sig, *d_msg;
+        uint64_t *d_pk_xy, *d_sig_xy;
+        int32_t *d_st, *d_res;
+        void* d_ws;
+        uint64_t ws = 0;
+        CHECK(blsw_engine_workspace_bytes((uint64_t)n, 32, 1, 1, &ws));
+        CHECK(hipMalloc((void**)&d_pk, n * 48) || hipMalloc((void**)&d_sig, n * 96) || hipMalloc((void**)&d_msg, n * 32) || hipMalloc((void**)&d_pk_xy, n * 96) ||
+              hipMalloc((void**)&d_sig_xy, n * 192) || hipMalloc((void**)&d_st, n * 8) || hipMalloc((void**)&d_res, n * 4) || hipMalloc(&d_ws, ws));
+        CHECK(hipMemcpy(d_pk, h_pk, n * 48, hipMemcpyHostToDevice) || hipMemcpy(d_sig, h_sig, n * 96, hipMemcpyHostToDevice) || hipMemcpy(d_msg, h_msg, n * 32, hipMemcpyHostToDevice));
+        blsw_engine_t* e = NULL;
+        CHECK(blsw_engine_create(&e, (uint64_t)n, 32, 1, 1, d_ws, ws));
+        CHECK(blsw_engine_submit_bytes(e, d_pk, d_sig, d_msg, d_pk_xy, d_sig_xy, d_st, NULL, 0, d_res, NULL));
+        CHECK(blsw_engine_flush(e, NULL));
+        CHECK(hipDeviceSynchronize());
+        static int32_t st[2 * MAXN], res[MAXN];
+        CHECK(hipMemcpy(st, d_st, n * 8, hipMemcpyDeviceToHost) || hipMemcpy(res, d_res, n * 4, hipMemcpyDeviceToHost));
+        CHECK(blsw_engine_destroy(e));
+        printf("n=%d results=", n);
+        for (int i = 0; i < n; i++) printf("%d", res[i]);
+        printf(" statuses=");
+        for (int i = 0; i < n; i++) printf("%d,%d;", st[2 * i], st[2 * i + 1]);
+        printf("\n");
+        return 0;
+    }
+    fprintf(stderr, "usage: caller layout | caller verify <pk48> <msg32> <sig96> | caller stream <pk48> <msg32> <sig96> (hex) | caller bytes <file>\n");
     return 2;
 }

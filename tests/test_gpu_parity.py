@@ -748,6 +748,25 @@ def test_c_caller_on_the_gpu(pkg, oracle):
     assert [int(kv["digest0"]), int(kv["digest1"])] == pkg.witness_digest_reference(w)
 
 
+def test_c_caller_submit_bytes_fixtures(pkg, tmp_path):
+    """blsw_engine_submit_bytes from plain C: all 29 verify/*.json cases of the reference (tests/tests.rs:239-268) as ONE batch of
+    compressed bytes — decode, status rule (an undecodable / identity point is replaced by the default and the case is false) and
+    gadget in one ABI call; the results must equal the fixtures' outputs."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "tests", "c_caller")])
+    cases = [c for _, c in eth_cases("verify")]
+    f = tmp_path / "cases.txt"
+    f.write_text("".join("%s %s %s\n" % (c["input"]["pubkey"][2:], c["input"]["message"][2:], c["input"]["signature"][2:]) for c in cases))
+    out = subprocess.check_output([os.path.join(root, "tests", "c_caller", "caller"), "bytes", str(f)], text=True, timeout=300)
+    kv = dict(p.split("=") for p in out.split())
+    assert int(kv["n"]) == len(cases)
+    assert [ch == "1" for ch in kv["results"]] == [bool(c["output"]) for c in cases]
+    st = [tuple(int(v) for v in pair.split(",")) for pair in kv["statuses"].strip(";").split(";")]
+    assert all((a == 0 and b == 0) or not c["output"] for (a, b), c in zip(st, cases))
+
+
 def test_gpu_witness_satisfies_product_matrices(pkg, oracle):
     """f1: witness vectors produced by the HIP kernels satisfy the constraint matrices emitted by the product
     (blsw_matrices_*: A z o B z = C z on every one of the 713 891 constraints; evaluator in the test harness) — single-key

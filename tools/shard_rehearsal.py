@@ -29,64 +29,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-def run_shard(pkg, n_shard=8192, batch=1024, ring=2, rank=0, world=8, buffers=6, seed=0x5EED, device=None, group=None):
-    import torch
-
-    workload = importlib.import_module("bls-verify-gadget_amd.workload")
-    sharding = importlib.import_module("bls-verify-gadget_amd.sharding")
-    dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
-    lo, hi = sharding.shard_range(n_shard * world, rank, world)  # this rank's contiguous block of the global batch
-    assert hi - lo == n_shard and n_shard % batch == 0
-    steps = n_shard // batch
-    if group is None:
-        group = max(1, min(16, steps // 2))
-    if group:
-        eng = pkg.WitnessEngine(batch, 32, max_steps=group, device=dev, n_buffers=max(2, min(3, (steps + group - 1) // group)), consumer_mode=1)
-    else:
-        eng = pkg.WitnessEngine(batch, 32, max_steps=ring, device=dev, n_buffers=min(buffers, max(1, steps // ring)))
-    outs = [eng.new_witness_tensor() for _ in range(ring)]
-    digests = torch.zeros((steps, batch, 2), dtype=torch.int64, device=dev)
-    results = torch.zeros((steps, batch), dtype=torch.int32, device=dev)
-    consumer = torch.cuda.Stream(device=dev)
-    inputs, expects = [], []
-    for k in range(steps):  # inputs are resident before the timed region (minted by the product's signer)
-        pk, msg, sig, expect = workload.make_batch(pkg, batch, seed=seed, device=dev, start=lo + k * batch)
-        inputs.append((pk, msg, sig))
-        expects.append(expect)
-    torch.cuda.synchronize(dev)
-    state = {"next": 0}
-
-    def drain():
-        while state["next"] < eng.materialised():
-            s = state["next"]
-            eng.wait_step(s, consumer)
-            pkg.witness_digest(outs[s % ring], out=digests[s], stream=consumer)
-            eng.output_consumed(outs[s % ring], consumer)
-            state["next"] += 1
-
-    t0 = time.perf_counter()
-    for k in range(steps):
-        pk, msg, sig = inputs[k]
-        while True:
-            try:
-                eng.submit(pk, sig, msg, witness=outs[k % ring], result=results[k])
-                break
-            except pkg.BlswBusy:  # the group buffer still has unwritten steps: their outputs are ours to release
-                drain()
-        drain()
-    eng.flush()
-    while state["next"] < steps:
-        drain()
-    consumer.synchronize()
-    torch.cuda.synchronize(dev)
-    dt = time.perf_counter() - t0
-    res = results.cpu().numpy().astype(bool)
-    expect = np.stack(expects)
-    eng.close()
-    return {"rank": rank, "world": world, "first_instance": lo, "n_shard": n_shard, "batch": batch, "ring": ring, "group_steps": group or ring,
-            "consumer_mode": bool(group), "steps": steps, "seconds": dt,
-            "instances_per_s": n_shard / dt, "results_ok": bool((res == expect).all()), "digests": digests.cpu().numpy().view(np.uint64).reshape(n_shard, 2),
-            "inputs": inputs, "sampled": 0}
+def run_shard(pkg, *args, **kwargs):
+    """the product's shard streamer (bls-verify-gadget_amd/sharding.py: stream_shard)"""
+    return importlib.import_module("bls-verify-gadget_amd.sharding").stream_shard(pkg, *args, **kwargs)
 
 
 def check_sample(pkg, oracle, out, frac=0.01, threads=8):
