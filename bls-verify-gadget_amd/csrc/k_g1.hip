@@ -1,5 +1,5 @@
 // libblsw.so, one translation unit per kernel family (see kcommon.cuh, build.py).
-#ifdef BLSW_CHAINS_INLINED  // build variant: the chain programs inlined into the kernel (fp.cuh: BLSW_FN)
+#if defined(BLSW_CHAINS_INLINED) || defined(BLSW_INL_G1)  // build variant: the chain programs inlined into the kernel (fp.cuh: BLSW_FN)
 #define BLSW_INLINE_CHAINS 1
 #endif
 #include "kcommon.cuh"

@@ -92,8 +92,32 @@ BLSW_HD Fp2 v_poly(const Fp2* k, int n, const Fp2& x) {  // sum k[i] x^i, powers
     }
     return result;
 }
+// a^c1, c1 = (p^2 - 9) / 16 (hasher.rs:242): the circuit squares and multiplies over the 758 bits of c1 (every step is a witness);
+// as a value, a^p = conj(a) in Fp2, so with c1 = e1 p + e0 the power is conj(a)^e1 * a^e0 — one joint ladder over 381 bits with
+// the table {a, conj(a), a conj(a)} (the norm lies in Fp: two products instead of three). Same field element, canonical limbs.
+BLSW_HD Fp2 v_pow_c1(const Fp2& a) {
+    constexpr uint32_t E0[12] = BLSW_SSWU_E0_WORDS;
+    constexpr uint32_t E1[12] = BLSW_SSWU_E1_WORDS;
+    const Fp norm = fp_add(fp_sqr(a.c0), fp_sqr(a.c1));
+    Fp2 r = fp2_one();
+    bool started = false;
+#pragma unroll 1
+    for (int i = BLSW_SSWU_E_NBITS - 1; i >= 0; i--) {
+        if (started) r = v_sqr(r);
+        const uint32_t idx = ((E0[i >> 5] >> (i & 31)) & 1u) | (((E1[i >> 5] >> (i & 31)) & 1u) << 1);
+        if (idx == 0) continue;
+        if (!started) {
+            r = idx == 1 ? a : (idx == 2 ? fp2_conj(a) : Fp2{norm, fp_zero()});
+            started = true;
+        } else if (idx == 3) {
+            r = fp2_mul_fp(r, norm);
+        } else {
+            r = fp2_mul_inl(r, idx == 1 ? a : fp2_conj(a));
+        }
+    }
+    return r;
+}
 BLSW_HD Proj<OpsFp2> v_map_to_curve(const Fp2& u) {
-    constexpr uint32_t C1[24] = BLSW_SSWU_C1_WORDS;
     const Fp2 Z = K_SSWU_Z(), A = K_SSWU_A(), B = K_SSWU_B(), C2 = K_SSWU_C2(), C3 = K_SSWU_C3(), C4 = K_SSWU_C4(), C5 = K_SSWU_C5();
     Fp2 tv1 = v_sqr(u);
     Fp2 tv3 = fp2_mul_inl(Z, tv1);
@@ -115,12 +139,7 @@ BLSW_HD Proj<OpsFp2> v_map_to_curve(const Fp2& u) {
     tv2 = fp2_mul_inl(tv2, gx1);
     tv4 = v_sqr(tv4);
     tv4 = fp2_mul_inl(tv2, tv4);
-    Fp2 y = tv4;  // y = tv4 ^ c1 (bits 759, 758 are zero, bit 757 is the leading one)
-#pragma unroll 1
-    for (int i = BLSW_SSWU_C1_NBITS - 4; i >= 0; i--) {
-        y = v_sqr(y);
-        if (bit_of(C1, i)) y = fp2_mul_inl(y, tv4);
-    }
+    Fp2 y = v_pow_c1(tv4);
     y = fp2_mul_inl(y, tv2);
     tv4 = fp2_mul_inl(y, C2);
     y = v_sel(v_eq(fp2_mul_inl(v_sqr(tv4), gxd), gx1), tv4, y);

@@ -154,6 +154,51 @@ def test_hash_to_g2_batch(pkg, oracle):
         assert np.array_equal(aff, out[i])
 
 
+@pytest.mark.parametrize("msg_len", [32, 55, 120])
+def test_hash_to_g2_batch_ragged_multi_wave(pkg, oracle, msg_len):
+    """blsw_hash_to_g2_batch over several waves with a ragged tail (n = 200 = 3 full waves + 8 lanes per one-lane kernel, 6 + 16 for
+    the two-lane map kernel): every point against the oracle. The value-only kernels (k_map_values, k_cofactor_values: SSWU without
+    witnesses, psi-based cofactor clearing) must give the point of hash_to_g2_with_cons (hasher.rs:727-740, :1004-1026)."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+
+    n = 200
+    msgs = np.stack([np.frombuffer((synth._h(0x5EED, b"rg", i) * 4)[:msg_len], dtype=np.uint8) for i in range(n)])
+    out = pkg.hash_to_g2_batch(torch.from_numpy(msgs).cuda())
+    torch.cuda.synchronize()
+    out = out.cpu().numpy().view(np.uint64)
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        want = list(ex.map(lambda i: oracle.hash_to_g2(msgs[i].tobytes())[1], range(n)))
+    bad = [i for i in range(n) if not np.array_equal(want[i], out[i])]
+    assert bad == [], bad[:8]
+
+
+def test_sign_batch_ragged_multi_wave(pkg, oracle):
+    """blsw_sign_batch over several waves (n = 200): sig = sk * H(m) through the four-digit psi ladder and pk = sk * g1 through the
+    fixed-base windows (vsign.cuh), scalars with special digit patterns and random ones, against the oracle's signer."""
+    import random
+
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+
+    r_mod = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+    z = 0xD201000000010000
+    rng = random.Random(11)
+    n = 200
+    sks = [1, 2, 15, 16, z - 1, z, z + 1, z * z, z * z - 1, z ** 3, z ** 3 + z * z + z + 1, r_mod - 1, r_mod - 2, (1 << 254) + 1]
+    sks += [rng.randrange(1, r_mod) for _ in range(n - len(sks))]
+    msgs = [synth._h(0x5EED, b"sg", i) for i in range(n)]
+    sk = np.frombuffer(b"".join(s.to_bytes(32, "little") for s in sks), dtype=np.uint8).reshape(-1, 32).copy()
+    msg = np.frombuffer(b"".join(msgs), dtype=np.uint8).reshape(-1, 32).copy()
+    r = pkg.sign_batch(torch.from_numpy(sk).cuda(), torch.from_numpy(msg).cuda())
+    assert (r["status"].cpu().numpy() == 0).all()
+    sig, pk = r["sig96"].cpu().numpy(), r["pk48"].cpu().numpy()
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        want = list(ex.map(lambda i: (oracle.sign(sks[i], msgs[i]), oracle.sk_to_pk(sks[i])), range(n)))
+    bad = [i for i in range(n) if sig[i].tobytes() != want[i][0] or pk[i].tobytes() != want[i][1]]
+    assert bad == [], bad[:8]
+
+
 def test_hash_to_curve_reference_strings(pkg, oracle):
     """hasher.rs:1004-1026 (test_hash_to_curve) on the GPU: the reference's five messages — lengths 0, 3, 7, 23 and 251 bytes,
     i.e. up to five SHA-256 blocks of msg' — through blsw_hash_to_g2_batch, against the frozen oracle outputs."""
