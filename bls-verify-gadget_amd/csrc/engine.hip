@@ -60,6 +60,8 @@ inline int stream_device(hipStream_t st) {
 // consumer has released its output's previous user, so the 34 MB vectors exist only between expansion and consumption and
 // the output ring can be smaller than a group. A step can also leave in compact form (its slices of the staging, copied).
 #define BLSW_MAX_BUFFERS 32
+#define BLSW_MILLER_CHUNK_DEFAULT 12   // pairs per lane of the pair-parallel Miller product (blsw_verify_multi_batch)
+#define BLSW_MILLER_PAR_MIN_PAIRS 8  // below: the serial six-lane team kernel
 #define BLSW_DEFAULT_EXPAND_VARIANT 0  // 384 x 8: the geometry that stays fast beside every chain build (profiles/r02_ab_fpmul_expand.txt)
 #define BLSW_MAX_TIMED 1024
 #define BLSW_MAX_CONSUMED 64
@@ -795,7 +797,7 @@ int blsw_layout_multi(uint32_t msg_len, uint32_t n_pairs, blsw_layout_t* out) {
 int blsw_verify_multi_workspace_bytes(uint64_t n, uint32_t msg_len, uint32_t n_pairs, uint64_t* bytes) {
     blsw_layout_t L;
     if (!bytes || n == 0 || blsw_layout_multi(msg_len, n_pairs, &L)) return BLSW_ERR_ARG;
-    *bytes = 256 + carve(nullptr, n * n_pairs, L, false, DEFAULT_MODES, n).total_bytes;
+    *bytes = 256 + carve(nullptr, n * n_pairs, L, false, DEFAULT_MODES, n).total_bytes + miller_par_bytes(n, n_pairs, BLSW_MILLER_CHUNK_DEFAULT);
     return BLSW_OK;
 }
 int blsw_verify_multi_batch(const uint64_t* d_pks_xy, const uint8_t* d_msgs, uint32_t msg_len, uint32_t n_pairs, const uint64_t* d_sig_xy, uint64_t n,
@@ -807,7 +809,8 @@ int blsw_verify_multi_batch(const uint64_t* d_pks_xy, const uint8_t* d_msgs, uin
     if (d_witness && witness_stride < L.n_witness) return BLSW_ERR_ARG;
     StepDesc* d_desc = reinterpret_cast<StepDesc*>(d_workspace);
     Workspace ws = carve(reinterpret_cast<char*>(d_workspace) + 256, NP, L, false, DEFAULT_MODES, n);
-    if (ws.total_bytes + 256 > workspace_bytes) return BLSW_ERR_WORKSPACE;
+    const bool par = n_pairs >= BLSW_MILLER_PAR_MIN_PAIRS;  // pairs in parallel (miller_par.cuh); few pairs: one team walks the chain
+    if (ws.total_bytes + 256 + (par ? miller_par_bytes(n, n_pairs, BLSW_MILLER_CHUNK_DEFAULT) : 0) > workspace_bytes) return BLSW_ERR_WORKSPACE;
     Group gp = direct_group(n, n_pairs, msg_len, L, d_desc, ws);  // per-pair work: N = n * n_pairs lanes
     Group gs = direct_group(n, 1, msg_len, L, d_desc, ws);        // per-signature work: N = n lanes
     hipStream_t st = reinterpret_cast<hipStream_t>(stream_);
@@ -864,7 +867,29 @@ int blsw_verify_multi_batch(const uint64_t* d_pks_xy, const uint8_t* d_msgs, uin
         hipStreamWaitEvent(st, ev_join[0], 0);
         hipStreamWaitEvent(st, ev_join[1], 0);
     }
-    hipLaunchKernelGGL(k_pairing_team_multi, dim3((unsigned)((n + BLSW_TEAMS_PER_WAVE - 1) / BLSW_TEAMS_PER_WAVE)), dim3(64), 0, st, gs, n_pairs, NP);
+    if (!par) {
+        hipLaunchKernelGGL(k_pairing_team_multi, dim3((unsigned)((n + BLSW_TEAMS_PER_WAVE - 1) / BLSW_TEAMS_PER_WAVE)), dim3(64), 0, st, gs, n_pairs, NP);
+        return hip_ok(hipGetLastError(), "launch");
+    }
+    MillerParArgs ma;
+    ma.K = n_pairs;
+    ma.B = BLSW_MILLER_CHUNK_DEFAULT;
+    ma.C = (n_pairs + ma.B - 1) / ma.B;
+    ma.n_h = NP;
+    {
+        char* p = reinterpret_cast<char*>(d_workspace) + align_up(256 + ws.total_bytes, 256);
+        auto take = [&](uint64_t items) {
+            Fp* r = reinterpret_cast<Fp*>(p);
+            p += align_up(items * 12 * sizeof(Fp), 256);
+            return r;
+        };
+        ma.cprod = take(n * 68 * ma.C);
+        ma.q = take(n * 68 * ma.C);
+        ma.t = take(n * 68);
+        ma.f1 = take(n * 68);
+        ma.ffinal = take(n);
+    }
+    launch_miller_par(gs, ma, st, forked ? s_sig : nullptr, ev_fork, ev_join[0]);
     return hip_ok(hipGetLastError(), "launch");
 }
 

@@ -264,6 +264,21 @@ __global__ void k_bench_fpmul(uint32_t iters, uint32_t* out);
 __global__ void k_bench_fpmul32(uint32_t iters, uint32_t* out);
 __global__ void k_bench_fpinv(uint32_t iters, uint32_t* out);
 __global__ void k_bench_fp2mulw(uint32_t iters, uint32_t* out);
+// pair-parallel Miller product (k_miller_par.hip, miller_par.cuh): value stores of n instances, element-major Fp12 rows
+struct MillerParArgs {
+    Fp* cprod;   // [12][n * 68 * C] chunk products
+    Fp* q;       // [12][n * 68 * C] prefixes over the chunks of a step
+    Fp* t;       // [12][n * 68]     product of all pairs of a step
+    Fp* f1;      // [12][n * 68]     the running value after ell(sig) of a step
+    Fp* ffinal;  // [12][n]          conj(f) after the loop
+    uint32_t K, B, C;  // pairs, pairs per chunk, chunks
+    uint64_t n_h;      // n * K: lanes of the per-pair launches (where the pairs' line coefficients / prepared keys live)
+};
+inline uint64_t miller_par_bytes(uint64_t n, uint32_t K, uint32_t B) {
+    const uint64_t C = (K + B - 1) / B;
+    return (2 * n * 68 * C + 2 * n * 68 + n) * 12 * sizeof(Fp) + 5 * 256;
+}
+void launch_miller_par(const Group& gs, const MillerParArgs& a, hipStream_t st, hipStream_t side, hipEvent_t ev_spine, hipEvent_t ev_side);
 // host-side launch helpers that live next to their (templated) kernels
 void launch_expand(uint32_t variant, uint32_t store, unsigned lds, hipStream_t st, ExpandArgs a, unsigned n_y);
 void launch_pairing(const Group& g, const Modes& m, hipStream_t st);

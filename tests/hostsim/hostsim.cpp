@@ -9,6 +9,7 @@
 #include "../../bls-verify-gadget_amd/csrc/layout.h"
 #include "../../bls-verify-gadget_amd/csrc/team.cuh"
 #include "../../bls-verify-gadget_amd/csrc/vsign.cuh"
+#include "../../bls-verify-gadget_amd/csrc/miller_par.cuh"
 #include <array>
 
 using namespace blsw;
@@ -100,6 +101,7 @@ struct TeamHost {
     }
 };
 static int g_use_team = 0;
+static uint32_t g_miller_chunk = 2;  // pairs per chunk of the pair-parallel Miller product (mode 2)
 // G2 allocation with the scalar multiplication of the subgroup check on the team program (lanes 0..2 own x, y, z)
 static void g2_alloc_segment(uint32_t* base, const blsw_layout_t& L, const Fp2& sx, const Fp2& sy) {
     if (!g_use_team) {
@@ -146,6 +148,7 @@ struct ParkHost {
 };
 extern "C" {
 void hostsim_use_team(int on) { g_use_team = on; }
+void hostsim_miller_chunk(uint32_t b) { g_miller_chunk = b ? b : 1; }
 int hostsim_layout(uint32_t msg_len, blsw_layout_t* L) {
     make_layout(msg_len, L);
     return 0;
@@ -234,6 +237,19 @@ int hostsim_witness_multi(const uint64_t* pks_xy, const uint8_t* msgs, uint32_t 
     bool sinf = fp2_is_zero(sx) && fp2_is_zero(sy);
     Proj<OpsFp2> sp = {sinf ? fp2_zero() : sx, sinf ? fp2_one() : sy, sinf ? fp2_zero() : fp2_one()};
     chain_prepare_g2({base, L.off_prep_sig}, sp, CoeffLinear{cs.data()});
+    if (g_use_team == 2) {  // miller_par.cuh: the four phases of the pair-parallel Miller product, tasks run one after the other
+        HostPairs hp = {&ch, &pk};
+        const uint32_t B = g_miller_chunk, C = miller_chunks(K, B), S = BLSW_MILLER_STEPS;
+        std::vector<Fp> cprod(12 * S * C), q(12 * S * C), tt(12 * S), f1(12 * S);
+        Fp12Rows Cp = {cprod.data(), (uint64_t)S * C}, Q = {q.data(), (uint64_t)S * C}, T = {tt.data(), S}, F1 = {f1.data(), S};
+        for (uint32_t k = 0; k < S; k++)
+            for (uint32_t c = 0; c < C; c++) Cp.st((uint64_t)k * C + c, miller_m1(hp, K, B, k, c));
+        for (uint32_t k = 0; k < S; k++) miller_m1b(Cp, Q, T, (uint64_t)k * C, k, C);
+        Fp12 fm = miller_m2(Emitter{base, L.off_miller}, K, CoeffLinear{cs.data()}, T, F1, 0);
+        for (uint32_t k = 0; k < S; k++)
+            for (uint32_t c = 0; c < C; c++) miller_m3(Emitter{base, L.off_miller}, hp, K, B, k, c, F1.ld(k), Q, (uint64_t)k * C + c);
+        return chain_final_exp_is_one({base, L.off_final_exp}, {base, L.off_is_one}, fm) ? 1 : 0;
+    }
     if (!g_use_team) {
         HostPairs hp = {&ch, &pk};
         Fp12 fm = chain_miller_multi({base, L.off_miller}, K, hp, CoeffLinear{cs.data()});

@@ -738,6 +738,21 @@ def test_verify_multi_small(pkg, oracle):
             assert len(bad) == 0, "K=%d instance %d: first mismatching witness index %d" % (K, i, bad[0])
 
 
+def test_verify_multi_pair_parallel_batch(pkg, oracle):
+    """The pair-parallel Miller product (miller_par.cuh; K >= 8) on a BATCH: three instances of K = 20 pairs (two chunks of 12 and
+    8 pairs; one instance with a tampered message) — every witness element of every instance against the oracle."""
+    K = 20
+    cases = [synth.make_multi(oracle, K, tamper=t, start=11 * a) for a, t in enumerate([None, 13, None])]
+    got, wit = _multi_run(pkg, np.stack([c[0] for c in cases]), np.stack([c[1] for c in cases]), np.stack([c[2] for c in cases]))
+    assert got.tolist() == [c[3] for c in cases]
+    for i, c in enumerate(cases):
+        n, res, _, ow = oracle.witness_multi(c[0], c[1], c[2])
+        w = wit[i].cpu().numpy().view(np.uint64)
+        assert n == w.shape[0] and res == c[3]
+        bad = np.nonzero((ow != w).any(axis=1))[0]
+        assert len(bad) == 0, "instance %d: first mismatching witness index %d" % (i, bad[0])
+
+
 def test_verify_multi_128_pairs(pkg, oracle):
     """BASELINE configs[3]: ONE signature over 128 (pk, msg) pairs, a 129-pair Miller product — all 87 295 138 witness
     elements (4.2 GB) against the oracle, plus the tampered variant's result."""

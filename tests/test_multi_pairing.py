@@ -59,3 +59,22 @@ def test_other_message_length(oracle):
     n, res, _, w = oracle.witness_multi(pks, msgs, sig)
     r, out, lay = hostsim_lib.witness_multi(pks, msgs, sig)
     assert res and r == 1 and lay["n_witness"] == n and np.array_equal(w, out)
+
+
+@pytest.mark.parametrize("K,chunk,tamper", [(1, 2, None), (3, 2, None), (5, 2, 3), (5, 3, None), (4, 12, None)])
+def test_pair_parallel_miller_on_host_matches_oracle(oracle, K, chunk, tamper):
+    """miller_par.cuh: the Miller product cut into chunks of pairs (chunk products, prefixes over the chunks, the serial spine of
+    squares and ell(sig), the chunks' witnesses from their prefix) gives the serial chain's witnesses bit for bit — chunk
+    boundaries inside and at the end of the pair list, one chunk, more pairs than a chunk."""
+    pks, msgs, sig, expect = synth.make_multi(oracle, K, tamper=tamper)
+    n, res, _, w = oracle.witness_multi(pks, msgs, sig)
+    lib = hostsim_lib.load()
+    lib.hostsim_use_team(2)
+    lib.hostsim_miller_chunk(chunk)
+    try:
+        r, out, hl = hostsim_lib.witness_multi(pks, msgs, sig)
+    finally:
+        lib.hostsim_use_team(0)
+    assert r == int(expect) == int(res) and hl["n_witness"] == n
+    bad = np.nonzero((w != out).any(axis=1))[0]
+    assert len(bad) == 0, "first mismatching witness index %d (miller segment starts at %d)" % (bad[0], hl["off_miller"])
