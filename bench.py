@@ -224,11 +224,11 @@ def allgather_leg_compact(args, pkg, sharding, dist, dev, inputs, lay, world):
     eng = pkg.WitnessEngine(n, 32, max_steps=group, device=dev, n_buffers=max(2, min(3, (steps + group - 1) // group)), consumer_mode=1)
     cbufs = eng.new_compact_buffer(ring)
     results = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(ring)]
-    gathered = torch.empty((world, eng.compact_bytes()), dtype=torch.uint8, device=dev)
     wit = eng.new_witness_tensor()
     dig = torch.empty((n, 2), dtype=torch.int64, device=dev)
     acc = torch.zeros(2, dtype=torch.int64, device=dev)
     consumer = torch.cuda.Stream(device=dev)
+    comm = torch.cuda.Stream(device=dev)
     d_pk, d_msg, d_sig = inputs
     state = {"next": 0}
 
@@ -236,16 +236,18 @@ def allgather_leg_compact(args, pkg, sharding, dist, dev, inputs, lay, world):
         eng.expand_compact(c, wit, stream=consumer)
         return wit
 
-    def consume(w, r):
+    def consume(w, r, k):
         acc.add_(pkg.witness_digest(w, out=dig, stream=consumer).sum(dim=0))
+
+    # double-buffered: the RCCL all-gather of step k + 1 runs on the communication stream while every rank's part of step k is
+    # expanded and digested on the consumer stream (two gathered buffers)
+    pipe = sharding.CompactGatherPipeline(world, eng.compact_bytes(), dev, expand, consume, comm_stream=comm, consumer_stream=consumer)
 
     def drain():
         while state["next"] < eng.materialised():
             s = state["next"]
-            eng.wait_step(s, consumer)
-            with torch.cuda.stream(consumer):
-                sharding.stream_allgather_compact(cbufs[s % ring], expand, consume, buffer=gathered)
-            eng.output_consumed(cbufs[s % ring], consumer)
+            buf = cbufs[s % ring]
+            pipe.push(buf, before=lambda st, s=s: eng.wait_step(s, st), after=lambda st, buf=buf: eng.output_consumed(buf, st))
             state["next"] += 1
 
     def run(k_steps):
@@ -262,6 +264,8 @@ def allgather_leg_compact(args, pkg, sharding, dist, dev, inputs, lay, world):
         eng.flush()
         while state["next"] < goal:
             drain()
+        pipe.flush()
+        comm.synchronize()
         consumer.synchronize()
         torch.cuda.synchronize()
 
@@ -277,7 +281,9 @@ def allgather_leg_compact(args, pkg, sharding, dist, dev, inputs, lay, world):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     cb = eng.compact_bytes()
     eng.close()
-    return float(t.item()), steps, {"form": "compact", "group_steps": group, "ring": ring, "consumer_mode": True, "wire_bytes_per_instance": cb / n,
+    return float(t.item()), steps, {"form": "compact", "world": world, "rccl_ranks": dist.get_world_size(), "group_steps": group, "ring": ring, "consumer_mode": True,
+                                    "overlap": "all-gather of step k + 1 on a communication stream beside expansion + digest of step k (two gathered buffers)",
+                                    "wire_bytes_per_instance": cb / n,
                                     "bytes_received_per_gpu_per_step": (world - 1) * cb,
                                     "bytes_expanded_per_gpu_per_step": world * n * lay["n_witness"] * 48,
                                     "consumer": "blsw_witness_digest over every expanded batch (all ranks' batches, on every rank)"}

@@ -824,8 +824,8 @@ int blsw_verify_multi_batch(const uint64_t* d_pks_xy, const uint8_t* d_msgs, uin
     // per host thread and device and kept (an event is re-recorded per call; a wait refers to the record that preceded it).
     struct Side {
         int device = -1;
-        hipStream_t aux[2] = {nullptr, nullptr};
-        hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+        hipStream_t aux[3] = {nullptr, nullptr, nullptr};
+        hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
         bool ok = false;
     };
     static thread_local std::map<int, Side> sides;  // per host thread and device ordinal (the device that owns `stream`)
@@ -833,8 +833,9 @@ int blsw_verify_multi_batch(const uint64_t* d_pks_xy, const uint8_t* d_msgs, uin
     if (sd.device != dev) {
         sd.device = dev;
         sd.ok = hipStreamCreateWithFlags(&sd.aux[0], hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&sd.aux[1], hipStreamNonBlocking) == hipSuccess &&
-                hipEventCreateWithFlags(&sd.ev_fork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&sd.ev_join[0], hipEventDisableTiming) == hipSuccess &&
-                hipEventCreateWithFlags(&sd.ev_join[1], hipEventDisableTiming) == hipSuccess;
+                hipStreamCreateWithFlags(&sd.aux[2], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&sd.ev_fork, hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&sd.ev_join[0], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&sd.ev_join[1], hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&sd.ev_join[2], hipEventDisableTiming) == hipSuccess;
     }
     const bool forked = sd.ok;
     hipEvent_t ev_fork = sd.ev_fork;
@@ -848,24 +849,31 @@ int blsw_verify_multi_batch(const uint64_t* d_pks_xy, const uint8_t* d_msgs, uin
     hipLaunchKernelGGL(k_g2_alloc, dim3(s1), dim3(64), 0, s_sig, gs);
     hipLaunchKernelGGL(k_prepare, dim3(s1), dim3(64), 0, s_sig, gs, 1);
     hipLaunchKernelGGL(k_g1, dim3(p1), dim3(64), 0, s_keys, gp);
-    hipLaunchKernelGGL(k_sha, dim3(p1), dim3(64), 0, st, gp, d_witness ? 1 : 0, 1);
+    // the SHA witness bits and their expansion (92 % of the output bytes) need only the messages: their own stream, beside the curve
+    // chains; the chains start from the value-only hash_to_field
+    hipStream_t s_exp = forked ? sd.aux[2] : st;
+    if (forked) hipStreamWaitEvent(s_exp, ev_fork, 0);
     if (d_witness) {
+        hipLaunchKernelGGL(k_sha, dim3(p1), dim3(64), 0, s_exp, gp, 1, 0);
         // blockIdx.y = flat (instance, pair); grid.y <= 65535: several launches for larger batches
         const uint64_t per_launch = (65535 / n_pairs) * (uint64_t)n_pairs;
         for (uint64_t first = 0; first < NP; first += per_launch) {
             const uint64_t cnt = NP - first < per_launch ? NP - first : per_launch;
             ExpandArgs xa = {ws.bits, ws.sha_words, first, L.sha_bits, L.off_expand, d_witness + (first / n_pairs) * witness_stride * 6, witness_stride, n_pairs, L.stride_hash, 0};
-            launch_expand(BLSW_DEFAULT_EXPAND_VARIANT, 0, 0, st, xa, (unsigned)cnt);
+            launch_expand(BLSW_DEFAULT_EXPAND_VARIANT, 0, 0, s_exp, xa, (unsigned)cnt);
         }
     }
+    hipLaunchKernelGGL(k_sha_values, dim3(p1), dim3(64), 0, st, gp);
     hipLaunchKernelGGL(k_map, dim3(p2), dim3(64), 0, st, gp);
     hipLaunchKernelGGL(k_cofactor, dim3(p1), dim3(64), 0, st, gp);
     hipLaunchKernelGGL(k_prepare, dim3(p1), dim3(64), 0, st, gp, 0);
     if (forked) {
         hipEventRecord(ev_join[0], s_sig);
         hipEventRecord(ev_join[1], s_keys);
+        hipEventRecord(ev_join[2], s_exp);
         hipStreamWaitEvent(st, ev_join[0], 0);
         hipStreamWaitEvent(st, ev_join[1], 0);
+        hipStreamWaitEvent(st, ev_join[2], 0);
     }
     if (!par) {
         hipLaunchKernelGGL(k_pairing_team_multi, dim3((unsigned)((n + BLSW_TEAMS_PER_WAVE - 1) / BLSW_TEAMS_PER_WAVE)), dim3(64), 0, st, gs, n_pairs, NP);

@@ -78,6 +78,82 @@ def stream_allgather_compact(local_compact, expand, consume, group=None, buffer=
     return world
 
 
+class CompactGatherPipeline:
+    """Double-buffered all-gather of batches in compact wire form: the gather of batch k + 1 (communication stream) runs while
+    every rank's part of batch k is expanded and consumed (consumer stream) — two `gathered` buffers, one event pair per buffer.
+
+        pipe = CompactGatherPipeline(world, nbytes, device, expand, consume, comm_stream=..., consumer_stream=...)
+        pipe.push(local_compact, before=lambda comm: engine.wait_step(s, comm), after=lambda comm: engine.output_consumed(buf, comm))
+        ...
+        pipe.flush()
+
+    push() issues the gather of its batch FIRST and only then the expansion + consumption of the previous batch, so the device
+    has both in flight. `expand(compact_r)` -> witness tensor, `consume(witness, rank, batch_index)`; both run under the consumer
+    stream. Streams may be None (CPU tensors with gloo: everything is synchronous, the order of operations is the same)."""
+
+    def __init__(self, world, nbytes, device, expand, consume, group=None, comm_stream=None, consumer_stream=None):
+        import torch
+
+        self.torch, self.world, self.group = torch, world, group
+        self.expand, self.consume = expand, consume
+        self.comm, self.consumer = comm_stream, consumer_stream
+        self.gathered = [torch.empty((world, nbytes), dtype=torch.uint8, device=device) for _ in range(2)]
+        cuda = comm_stream is not None
+        self.ev_gathered = [torch.cuda.Event() for _ in range(2)] if cuda else None
+        self.ev_free = [torch.cuda.Event() for _ in range(2)] if cuda else None
+        self.used = [False, False]
+        self.pending = None  # (slot, batch index)
+        self.k = 0
+        self.order = []  # ("gather", k) / ("consume", k): what was issued, in order (tests)
+
+    def _ctx(self, stream):
+        import contextlib
+
+        return self.torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
+
+    def push(self, local_compact, before=None, after=None):
+        import torch.distributed as dist
+
+        torch = self.torch
+        slot = self.k % 2
+        flat = local_compact.reshape(-1)
+        dst = self.gathered[slot].reshape(-1)
+        src = flat
+        if flat.dtype.itemsize == 1 and flat.numel() % 8 == 0 and flat.data_ptr() % 8 == 0 and dst.data_ptr() % 8 == 0:
+            src, dst = flat.view(torch.int64), dst.view(torch.int64)  # a batch is > 2^31 bytes: keep the element count small
+        if before is not None:
+            before(self.comm)  # e.g. the engine's wait_step on the communication stream
+        with self._ctx(self.comm):
+            if self.comm is not None and self.used[slot]:
+                self.comm.wait_event(self.ev_free[slot])  # the buffer's previous batch has been consumed
+            dist.all_gather_into_tensor(dst, src, group=self.group)
+            if self.comm is not None:
+                self.ev_gathered[slot].record(self.comm)
+        self.order.append(("gather", self.k))
+        if after is not None:
+            after(self.comm)  # e.g. release the local compact buffer to the engine
+        prev, self.pending = self.pending, (slot, self.k)
+        self.used[slot] = True
+        self.k += 1
+        if prev is not None:
+            self._consume(*prev)
+
+    def _consume(self, slot, index):
+        with self._ctx(self.consumer):
+            if self.consumer is not None:
+                self.consumer.wait_event(self.ev_gathered[slot])
+            for r in range(self.world):
+                self.consume(self.expand(self.gathered[slot][r]), r, index)
+            if self.consumer is not None:
+                self.ev_free[slot].record(self.consumer)
+        self.order.append(("consume", index))
+
+    def flush(self):
+        if self.pending is not None:
+            prev, self.pending = self.pending, None
+            self._consume(*prev)
+
+
 def stream_shard(pkg, n_shard=8192, batch=1024, ring=2, rank=0, world=8, buffers=6, seed=0x5EED, device=None, group=None):
     """One rank's shard of a sharded batch (BASELINE configs[2]: 65 536 instances over 8 GPUs = 8 192 per rank) streamed in
     micro-batches of `batch` instances through a ring of `ring` witness tensors: every tensor is drained by a consumer (the digest

@@ -108,6 +108,53 @@ def test_other_message_lengths(pkg, oracle, msg_len):
     _compare(oracle, pk, msg.reshape(2, msg_len), sig, got, w, range(2))
 
 
+@pytest.mark.parametrize("msg_len", [55, 56, 119, 120, 251])
+def test_engine_grouped_padding_boundary_lengths(pkg, oracle, msg_len):
+    """The witness path on long and block-boundary messages through the GROUPED engine (staging, streamed expansion and
+    placement): msg' = Z_pad || msg || ... of expand_message (hasher.rs:110-173) crosses SHA-256 padding boundaries at 55 / 56
+    and 119 / 120 bytes, and 251 bytes is the longest of the reference's own strings (hasher.rs:1006-1012). Two steps of 70
+    instances fused into one group (140 lanes: two full waves and a ragged one); valid and tampered signatures; every
+    fifth vector and the ragged tail, element by element, against the oracle."""
+    import torch
+
+    n, steps = 70, 2
+    pk16, _, _, _ = synth.make_batch(oracle, 16)
+    sks = [int.from_bytes(synth._h(0x5EED, b"sk", k), "big") % synth.R_MOD or 1 for k in range(16)]
+    total = n * steps
+    msg = np.stack([np.frombuffer((synth._h(0x5EED, b"pb", i) * 8)[:msg_len], dtype=np.uint8) for i in range(total)]).copy()
+    pk = np.stack([pk16[i % 16] for i in range(total)])
+    sig = np.zeros((total, 24), dtype=np.uint64)
+    signed = {}
+    for i in range(total):  # a few distinct valid signatures (CPU hash-to-G2 is the slow part); the rest reuse them on other messages
+        j = i % 7
+        if j not in signed:
+            st, sxy, _ = oracle.g2_decompress(oracle.sign(sks[j % 16], msg[j].tobytes()))
+            assert st == 0
+            signed[j] = sxy
+        sig[i] = signed[j]
+    expect = np.array([i < 7 for i in range(total)])  # instance i < 7 carries its own signature under key i % 16 = i
+    dev = torch.device("cuda:0")
+    eng = pkg.WitnessEngine(n, msg_len, max_steps=2, device=dev, n_buffers=2)
+    outs, ress, keep = [], [], []
+    for k in range(steps):
+        sl = slice(k * n, (k + 1) * n)
+        d = (torch.from_numpy(pk[sl].view(np.int64)).to(dev), torch.from_numpy(sig[sl].view(np.int64)).to(dev), torch.from_numpy(msg[sl]).to(dev))
+        w, r = eng.new_witness_tensor(), torch.empty(n, dtype=torch.int32, device=dev)
+        eng.submit(d[0], d[1], d[2], witness=w, result=r)
+        outs.append(w)
+        ress.append(r)
+        keep.append(d)
+    eng.flush()
+    torch.cuda.synchronize()
+    for k in range(steps):
+        sl = slice(k * n, (k + 1) * n)
+        got = ress[k].cpu().numpy().astype(bool)
+        assert np.array_equal(got, expect[sl])
+        w = outs[k].cpu().numpy().view(np.uint64)
+        _compare(oracle, pk[sl], msg[sl], sig[sl], got, w, sorted(set(range(0, n, 5)) | {n - 1, n - 2, 63, 64}))
+    eng.close()
+
+
 def test_engine_grouped_batches(pkg, oracle):
     # engine mode: 5 different batches of 8 instances, fused 3 per launch group (3 + 2: both ping-pong buffers, staging,
     # per-step placement), each with its own witness tensor

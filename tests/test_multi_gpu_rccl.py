@@ -1,0 +1,34 @@
+"""The real multi-GPU path: engine + compact all-gather over RCCL with one process per GPU. Runs only where the box has
+two or more GPUs (the builder's box has one: skipped there; the driver's 8-GPU node exercises it). Ranks are FRESH child processes
+(python -m torch.distributed.run): this pytest process may have initialised the GPU and must not exec another program."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_engine_and_compact_allgather_over_rccl():
+    import torch
+
+    ndev = torch.cuda.device_count()  # counting devices does not initialise the GPU
+    if ndev < 2:
+        pytest.skip("needs >= 2 GPUs (found %d)" % ndev)
+    world = 2 if ndev < 4 else 4  # at most 4 ranks on the card's process budget
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "tests", "rccl_worker.py")], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert p.returncode == 0 and lines, p.stderr[-2000:]
+    out = json.loads(lines[-1])
+    assert out["world_size"] == world and out["backend"] == "nccl" and out["all_ranks_ok"] and out["mismatches_rank0"] == []
+    assert out["order"][:3] == [["gather", 0], ["gather", 1], ["consume", 0]]

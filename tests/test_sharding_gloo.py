@@ -46,8 +46,16 @@ def _worker(rank, world, port, n_total, q):
     comp = torch.arange(40, dtype=torch.uint8) + 100 * rank
     cseen = []
     nb = sharding.stream_allgather_compact(comp, lambda c: c.to(torch.int64) * 2, lambda w, r: cseen.append((r, int(w[0]), int(w[-1]), w.numel())))
+    # the double-buffered order of the all-gather leg (CompactGatherPipeline): the gather of batch k + 1 is issued before batch k
+    # is expanded and consumed; three batches through two gathered buffers
+    pseen = []
+    pipe = sharding.CompactGatherPipeline(world, 16, torch.device("cpu"), lambda c: c.to(torch.int64) + 1, lambda w, r, k: pseen.append((k, r, int(w[0]))))
+    hooks = []
+    for k in range(3):
+        pipe.push(torch.full((16,), 10 * k + rank, dtype=torch.uint8), before=lambda st, k=k: hooks.append(("before", k)), after=lambda st, k=k: hooks.append(("after", k)))
+    pipe.flush()
     if rank == 0:
-        q.put((full.numpy().astype(bool).tolist(), expect.tolist(), gathered[:, 0, 0].tolist(), nmb, seen, nb, cseen))
+        q.put((full.numpy().astype(bool).tolist(), expect.tolist(), gathered[:, 0, 0].tolist(), nmb, seen, nb, cseen, pseen, pipe.order, hooks))
     dist.destroy_process_group()
 
 
@@ -72,7 +80,7 @@ def test_two_rank_gloo_gather():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, n_total, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got, expect, gathered, nmb, seen, nb, cseen = q.get(timeout=120)
+    got, expect, gathered, nmb, seen, nb, cseen, pseen, porder, hooks = q.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -81,3 +89,6 @@ def test_two_rank_gloo_gather():
     assert nb == 2 and cseen == [(0, 0, 78, 40), (1, 200, 278, 40)]
     assert nmb == 3 and [(c0, rows) for c0, rows, _ in seen] == [(0, 2), (2, 2), (4, 1)]
     assert seen[0][2] == [0, 24, 1000, 1024] and seen[2][2] == [96, 1096]
+    assert pseen == [(0, 0, 1), (0, 1, 2), (1, 0, 11), (1, 1, 12), (2, 0, 21), (2, 1, 22)]  # (batch, rank, first element + 1)
+    assert porder == [("gather", 0), ("gather", 1), ("consume", 0), ("gather", 2), ("consume", 1), ("consume", 2)]
+    assert hooks == [("before", 0), ("after", 0), ("before", 1), ("after", 1), ("before", 2), ("after", 2)]
