@@ -42,7 +42,7 @@ FPMUL_PER_INV = 570
 # what the kernels execute instead of a Fermat inversion: one safegcd inversion = 26.9 Fp-product times (blsw_microbench 2 / 1);
 # 636 of the 940 cofactor-chain inversions are shared with a neighbour (Montgomery's trick: +9 products each, -1 inversion)
 FPMUL_PER_INV_EXECUTED = 27
-TRAFFIC_FILES = ("r02_traffic.json", "r01_traffic.json")
+TRAFFIC_FILES = ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json")
 
 
 def parse_args():
@@ -430,10 +430,12 @@ def main():
     opc = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_opcount.json")))
     # HBM bytes per k_sha_expand launch from the PMC passes committed under profiles/ (rocprofv3 --pmc cannot be combined
     # with the timed run); only quoted for the workload it was collected on
-    traffic, traffic_source, whole_step = None, None, None
+    traffic, traffic_source, whole_step, whole_step_file = None, None, None, None
     for name in TRAFFIC_FILES:
         try:
-            whole_step = whole_step or json.load(open(os.path.join(ROOT, "profiles", name))).get("whole_step")
+            if whole_step is None:
+                whole_step = json.load(open(os.path.join(ROOT, "profiles", name))).get("whole_step")
+                whole_step_file = name if whole_step else None
             tr = json.load(open(os.path.join(ROOT, "profiles", name)))["k_sha_expand"]
             if tr["instances_per_launch"] == n and lay["msg_len"] == 32:
                 traffic = (tr["write_kib"] + tr["fetch_kib"]) * 1024.0
@@ -479,7 +481,7 @@ def main():
         # the path as a whole — the expansion's own figure above is lower because the other kernels' traffic runs beside it
         tot = whole_step["write_bytes"] + whole_step["fetch_bytes"]
         out["roofline_hbm_total"] = {"bound": "hbm", "traffic_per_step": tot, "achieved": tot / (dt / args.steps) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                     "frac": tot / (dt / args.steps) / 1e9 / HBM_PEAK_GBPS, "source": "profiles/r02_traffic.json whole_step (rocprofv3 --pmc passes)"}
+                                     "frac": tot / (dt / args.steps) / 1e9 / HBM_PEAK_GBPS, "source": "profiles/%s whole_step (rocprofv3 --pmc passes)" % whole_step_file}
     out["witness_ok"] = witness_ok  # digests of the ring tensors after the timed region == a direct-mode engine's on the same batch
     if consumer:
         out["value_consumer_mode"] = consumer.get("value")

@@ -884,6 +884,7 @@ int blsw_verify_multi_batch(const uint64_t* d_pks_xy, const uint8_t* d_msgs, uin
     ma.B = BLSW_MILLER_CHUNK_DEFAULT;
     ma.C = (n_pairs + ma.B - 1) / ma.B;
     ma.n_h = NP;
+    ma.spine_lane = 0;
     {
         char* p = reinterpret_cast<char*>(d_workspace) + align_up(256 + ws.total_bytes, 256);
         auto take = [&](uint64_t items) {

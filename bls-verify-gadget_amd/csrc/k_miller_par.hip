@@ -3,7 +3,7 @@
 // final exponentiation + is_one of the six-lane team program started from the stored Miller value.
 #include "kcommon.cuh"
 #include "miller_par.cuh"
-#include "team.cuh"
+#include "team_multi.cuh"
 
 namespace blsw {
 
@@ -54,6 +54,67 @@ __global__ __launch_bounds__(64) void k_miller_m3(Group gs, MillerParArgs a) {
     const Fp12 f1 = Fp12Rows{a.f1, gs.N * BLSW_MILLER_STEPS}.ld(inst * BLSW_MILLER_STEPS + k);
     miller_m3(EMIT(gs, id, off_miller), pairs_of(gs, a, inst), a.K, a.B, k, c, f1, Fp12Rows{a.q, gs.N * per_inst}, t);
 }
+// the serial spine on the six-lane team program (the single-lane k_miller_m2 takes 23 ms for its 68 steps: 62 squares, 67 ell(sig), 68
+// full products; a team does the same in a fraction): squares and ell(sig) with their witnesses, f1 stored, the product with T[k]
+// as a value (no cursor). Leaves conj(f) for k_final_team.
+__global__ __launch_bounds__(64) void k_miller_spine_team(Group gs, MillerParArgs a) {
+    __shared__ Fp2 lds[BLSW_TEAMS_PER_WAVE * TS_NSLOTS];
+    constexpr MillerStepInfo info = miller_step_info();
+    const uint32_t team = threadIdx.x / 6, j = threadIdx.x % 6;
+    const uint64_t I0 = (uint64_t)blockIdx.x * BLSW_TEAMS_PER_WAVE + team;
+    const bool active = team < BLSW_TEAMS_PER_WAVE && I0 < gs.N;
+    const uint64_t I = active ? I0 : 0, steps = gs.N * BLSW_MILLER_STEPS;
+    LaneId id = lane_id(gs, I);
+    TeamLanesMulti t;
+    t.slots = lds + (active ? team : 0) * TS_NSLOTS;
+    t.j = j;
+    t.active = active;
+    t.coeff_h = {nullptr, 0};
+    t.coeff_sig = {gs.ws.coeff_sig + I, gs.ws.n_sig};
+    t.coeff_h_all = nullptr;
+    t.pkaff = nullptr;
+    t.n_h = 0;
+    t.flat0 = 0;
+    t.e = EMIT(gs, id, off_miller);
+    if (!active) t.e.base = nullptr;
+    uint32_t* const base = t.e.base;
+    const uint32_t pos0 = t.e.pos;
+    if (active && j == 0) team_st(t.slots, TS_XYC, {K_G1_GEN_NEG_Y(), fp_zero()});
+    team_sync();
+    Fp2 f = fp2_zero();
+#pragma unroll 1
+    for (uint32_t k = 0; k < BLSW_MILLER_STEPS; k++) {
+        const uint64_t item = I * BLSW_MILLER_STEPS + k;
+        t.e.pos = pos0 + miller_step_pos(info, k, a.K);
+#pragma unroll 1
+        for (int ph = info.dbl[k] ? 0 : 1; ph < 3; ph++) {
+            Fp2 other = f;
+            if (ph == 1) {
+                t.load_coeff_sig(k);
+                if (k == 0) {
+                    f = t.first_f();  // f = 1 is a constant: the first ell is a linear combination
+                    continue;
+                }
+            }
+            if (ph == 2) {  // f1 = value after ell(sig): what the chunks of this step start from; then the step's pairs as one value product
+                if (active) {
+                    st_fp(a.f1 + (uint64_t)(2 * j) * steps + item, f.c0);
+                    st_fp(a.f1 + (uint64_t)(2 * j + 1) * steps + item, f.c1);
+                }
+                other = {ld_fp(a.t + (uint64_t)(2 * j) * steps + item), ld_fp(a.t + (uint64_t)(2 * j + 1) * steps + item)};
+                t.e.base = nullptr;
+            }
+            const TeamOp& T = ph == 0 ? TEAM_OP_SQR : (ph == 1 ? TEAM_OP_ELLC : TEAM_OP_MUL);
+            f = t.exec_hot(T, f, other);
+            if (ph == 2) t.e.base = base;
+        }
+    }
+    f = t.conj(f);
+    if (active) {
+        st_fp(a.ffinal + (uint64_t)(2 * j) * gs.N + I, f.c0);
+        st_fp(a.ffinal + (uint64_t)(2 * j + 1) * gs.N + I, f.c1);
+    }
+}
 // final exponentiation + is_one of the stored Miller values, six lanes per instance (team.cuh)
 __global__ __launch_bounds__(64) void k_final_team(Group gs, MillerParArgs a) {
     __shared__ Fp2 lds[BLSW_TEAMS_PER_WAVE * TS_NSLOTS];
@@ -83,7 +144,10 @@ void launch_miller_par(const Group& gs, const MillerParArgs& a, hipStream_t st, 
     const uint64_t tasks = gs.N * BLSW_MILLER_STEPS * a.C, steps = gs.N * BLSW_MILLER_STEPS;
     hipLaunchKernelGGL(k_miller_m1, dim3((unsigned)((tasks + 63) / 64)), dim3(64), 0, st, gs, a);
     hipLaunchKernelGGL(k_miller_m1b, dim3((unsigned)((steps + 63) / 64)), dim3(64), 0, st, gs, a);
-    hipLaunchKernelGGL(k_miller_m2, dim3((unsigned)((gs.N + 63) / 64)), dim3(64), 0, st, gs, a);
+    if (a.spine_lane)
+        hipLaunchKernelGGL(k_miller_m2, dim3((unsigned)((gs.N + 63) / 64)), dim3(64), 0, st, gs, a);
+    else
+        hipLaunchKernelGGL(k_miller_spine_team, dim3((unsigned)((gs.N + BLSW_TEAMS_PER_WAVE - 1) / BLSW_TEAMS_PER_WAVE)), dim3(64), 0, st, gs, a);
     // the final exponentiation needs only the spine's value: it runs beside the chunks' witness pass
     hipStream_t fe = side ? side : st;
     if (side) {

@@ -1,6 +1,6 @@
 // libblsw.so, one translation unit per kernel family (see kcommon.cuh, build.py).
 #include "kcommon.cuh"
-#include "team.cuh"
+#include "team_multi.cuh"
 
 namespace blsw {
 
@@ -70,25 +70,6 @@ __global__ __launch_bounds__(64) void k_g2_alloc_team(Group g) {
 // N+1-pair product (blsw_verify_multi_batch): one team per instance, K pairs per instance. `gs` is the per-signature view
 // (N = instances), the per-pair values (prepare_g1(pk_j), line coefficients of H(m_j)) live at flat index I * K + j of the
 // per-pair launch of n_h = N * K lanes.
-struct TeamLanesMulti : TeamLanes<CoeffStrided> {
-    const Fp* coeff_h_all;
-    const Fp* pkaff;
-    uint64_t n_h, flat0;
-    BLSW_TEAM_DEV void load_coeff_sig(uint32_t k) {
-        if (active) team_load_coeff_sig_lane(j, slots, coeff_sig, k);
-        team_sync();
-    }
-    BLSW_TEAM_DEV void load_pair(uint32_t jp, uint32_t k) {
-        if (active) {
-            const uint64_t t = flat0 + jp;
-            Fp px = fp_zero(), py = fp_zero();
-            if (j == 5) px = ld_fp(pkaff + t);
-            if (j == 4) py = ld_fp(pkaff + n_h + t);
-            team_load_pair_lane(j, slots, CoeffStrided{const_cast<Fp*>(coeff_h_all) + t, n_h}, k, px, py);
-        }
-        team_sync();
-    }
-};
 __global__ __launch_bounds__(64) void k_pairing_team_multi(Group gs, uint32_t K, uint64_t n_h) {
     __shared__ Fp2 lds[BLSW_TEAMS_PER_WAVE * TS_NSLOTS];
     const uint32_t team = threadIdx.x / 6, j = threadIdx.x % 6;

@@ -273,6 +273,7 @@ struct MillerParArgs {
     Fp* ffinal;  // [12][n]          conj(f) after the loop
     uint32_t K, B, C;  // pairs, pairs per chunk, chunks
     uint64_t n_h;      // n * K: lanes of the per-pair launches (where the pairs' line coefficients / prepared keys live)
+    uint32_t spine_lane;  // 1: the single-lane spine kernel (k_miller_m2; the statement shared with the host harness) instead of the team kernel
 };
 inline uint64_t miller_par_bytes(uint64_t n, uint32_t K, uint32_t B) {
     const uint64_t C = (K + B - 1) / B;

@@ -11,7 +11,7 @@ import sys
 
 
 def short(name):
-    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    name = name.replace("(anonymous namespace)::", "").replace("blsw::", "").replace("void ", "")
     return re.sub(r"\(.*", "", name)[:34]
 
 

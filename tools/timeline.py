@@ -11,7 +11,7 @@ def load(path):
     t0 = min(int(r["Start_Timestamp"]) for r in rows)
     ev = []
     for r in rows:
-        name = r["Kernel_Name"].replace("(anonymous namespace)::", "")
+        name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("blsw::", "")
         name = re.sub(r"\(.*", "", name).replace("void ", "")
         ev.append(((int(r["Start_Timestamp"]) - t0) / 1e6, (int(r["End_Timestamp"]) - t0) / 1e6, name, r["Queue_Id"], r["Stream_Id"], r["Grid_Size_X"]))
     ev.sort()
