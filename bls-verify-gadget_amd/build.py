@@ -15,6 +15,8 @@ OBJ = os.path.join(HERE, "build_obj")
 SOURCES = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 HOST_SOURCES = ["r1cs.cpp"]  # host-only C++: compiled by g++, linked into the same library
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith((".cuh", ".h")))
+# the one-instance-per-lane chain units are compiled a second time with their programs inlined (kernels *_inl: kcommon.cuh)
+DUAL = ["k_sha.hip", "k_g1.hip", "k_g2.hip", "k_map.hip", "k_cofactor.hip", "k_prepare.hip"]
 HIP_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 
 
@@ -49,8 +51,9 @@ def build(force=False, verbose=False, out=None, defines=(), only=None):
     hdr_time = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
     hdr_time = max(hdr_time, os.path.getmtime(os.path.join(HERE, "..", "include", "blsw.h")))
     jobs, objs = [], []
-    for src in HOST_SOURCES + SOURCES:
-        obj = os.path.join(OBJ, "%s.%s.o" % (os.path.splitext(src)[0], tag))
+    units = [(src, ()) for src in HOST_SOURCES + SOURCES] + [(src, ("-DBLSW_KVARIANT_INL",)) for src in DUAL]
+    for src, extra in units:
+        obj = os.path.join(OBJ, "%s%s.%s.o" % (os.path.splitext(src)[0], "_inl" if extra else "", tag))
         objs.append(obj)
         path = os.path.join(CSRC, src)
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), hdr_time):
@@ -59,7 +62,7 @@ def build(force=False, verbose=False, out=None, defines=(), only=None):
             cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas", "-c", path, "-o", obj]
             jobs.append((cmd, None))
         else:
-            cmd = [hipcc] + HIP_FLAGS + list(defines) + ["-c", path, "-o", obj, "-Rpass-analysis=kernel-resource-usage"]
+            cmd = [hipcc] + HIP_FLAGS + list(defines) + list(extra) + ["-c", path, "-o", obj, "-Rpass-analysis=kernel-resource-usage"]
             jobs.append((cmd, obj + ".log"))
     if verbose:
         print("compiling %d units" % len(jobs), file=sys.stderr)

@@ -107,6 +107,7 @@ struct blsw_engine {
     bool consumed_live[BLSW_MAX_CONSUMED];  // a release has been recorded and not yet waited for
     bool held[BLSW_MAX_CONSUMED];           // consumer mode: a step was materialised into this output and it has not been released
     bool staged = false;  // false: direct mode (max_steps == 1, no staging; witnesses written in place by the chains)
+    bool chains_inlined = false;  // which compilation of the chain kernels (options.chain_variant; kcommon.cuh: BLSW_K)
 };
 
 static void engine_free(blsw_engine* e) {
@@ -266,6 +267,7 @@ static int launch_group(blsw_engine* e) {
     g.chain_prio = e->opt.prio_mode == 0;
     const unsigned g1 = (unsigned)((g.N + 63) / 64), g2 = (unsigned)((2 * g.N + 63) / 64);
     const unsigned gt = (unsigned)((g.N + BLSW_TEAMS_PER_WAVE - 1) / BLSW_TEAMS_PER_WAVE);
+    const ChainKernels ck = chain_kernels(e->chains_inlined);
     hipStream_t st = b.st[0];
     // inputs of every step are ready once its submitting stream reached the point of the submit
     for (uint32_t s = 0; s < steps; s++) hipStreamWaitEvent(st, b.ev_in[s], 0);
@@ -280,25 +282,25 @@ static int launch_group(blsw_engine* e) {
     hipStreamWaitEvent(b.st[1], b.ev_start, 0);
     // sha: the witness bits of the in-circuit SHA-256 (first: the expansion stream is waiting for them)
     hipStreamWaitEvent(e->sha, b.ev_start, 0);
-    if (any_out) hipLaunchKernelGGL(k_sha, dim3(g1), dim3(64), 0, e->sha, g, 1, 0);
+    if (any_out) hipLaunchKernelGGL(ck.sha, dim3(g1), dim3(64), 0, e->sha, g, 1, 0);
     hipEventRecord(b.ev_sha, e->sha);
     // main, first part: the hash-to-G2 critical path
     if (!(dbg_skip & 1)) {
     hipLaunchKernelGGL(k_sha_values, dim3(g1), dim3(64), 0, st, g);
-    hipLaunchKernelGGL(k_map, dim3(g2), dim3(64), 0, st, g);
-    hipLaunchKernelGGL(k_cofactor, dim3(g1), dim3(64), 0, st, g);
-    hipLaunchKernelGGL(k_prepare, dim3(g1), dim3(64), 0, st, g, 0);
+    hipLaunchKernelGGL(ck.map, dim3(g2), dim3(64), 0, st, g);
+    hipLaunchKernelGGL(ck.cofactor, dim3(g1), dim3(64), 0, st, g);
+    hipLaunchKernelGGL(ck.prepare, dim3(g1), dim3(64), 0, st, g, 0);
     // aux: prepare_g2(sig) and the group allocations (53 ms alone beside the 86 ms of the main stream's first part)
-    hipLaunchKernelGGL(k_prepare, dim3(g1), dim3(64), 0, b.st[1], g, 1);
+    hipLaunchKernelGGL(ck.prepare, dim3(g1), dim3(64), 0, b.st[1], g, 1);
     if (e->L.n_keys) {  // aggregate_verify: one lane per (instance, key) allocates, then mapped_aggregate + pk != 0 + prepare_g1 per instance
-        hipLaunchKernelGGL(k_agg_keys, dim3((unsigned)((g.N * e->L.n_keys + 63) / 64)), dim3(64), 0, b.st[1], g, g.ws.keyproj);
-        hipLaunchKernelGGL(k_agg_sum, dim3(g1), dim3(64), 0, b.st[1], g, (const Fp*)g.ws.keyproj);
+        hipLaunchKernelGGL(ck.agg_keys, dim3((unsigned)((g.N * e->L.n_keys + 63) / 64)), dim3(64), 0, b.st[1], g, g.ws.keyproj);
+        hipLaunchKernelGGL(ck.agg_sum, dim3(g1), dim3(64), 0, b.st[1], g, (const Fp*)g.ws.keyproj);
     } else
-        hipLaunchKernelGGL(k_g1, dim3(g1), dim3(64), 0, b.st[1], g);
+        hipLaunchKernelGGL(ck.g1, dim3(g1), dim3(64), 0, b.st[1], g);
     if (e->modes.g2_team)
         hipLaunchKernelGGL(k_g2_alloc_team, dim3(gt), dim3(64), 0, b.st[1], g);
     else
-        hipLaunchKernelGGL(k_g2_alloc, dim3(g1), dim3(64), 0, b.st[1], g);
+        hipLaunchKernelGGL(ck.g2_alloc, dim3(g1), dim3(64), 0, b.st[1], g);
     }
     hipEventRecord(b.ev_aux, b.st[1]);
     // main, second part: the pairing
@@ -342,6 +344,7 @@ int blsw_engine_options_default(blsw_engine_options_t* o) {
     o->place_lds = 0;
     o->consumer_mode = 0;
     o->output_form = 0;
+    o->chain_variant = 0;
     return BLSW_OK;
 }
 
@@ -376,7 +379,7 @@ int blsw_engine_create_ex(blsw_engine_t** out, uint64_t n, uint32_t msg_len, uin
     // place while the chains run and could not honour a held output
     if (options->consumer_mode > 1 || (options->consumer_mode == 1 && max_steps == 1 && n_buffers == 1)) return BLSW_ERR_ARG;
     if (options->pairing_mode > 1 || options->g2_mode > 1 || (options->g2_mode == 1 && options->pairing_mode != 0) || options->expand_store > 3 ||
-        options->prio_mode > 2 || options->output_form > 1 || (options->expand_variant & 0xff) > 5 || (options->expand_variant >> 9) || options->n_keys > 65535 ||
+        options->prio_mode > 2 || options->output_form > 1 || options->chain_variant > 2 || (options->expand_variant & 0xff) > 5 || (options->expand_variant >> 9) || options->n_keys > 65535 ||
         (options->n_keys && options->g2_mode))
         return BLSW_ERR_ARG;
     *out = nullptr;
@@ -414,6 +417,7 @@ int blsw_engine_create_ex(blsw_engine_t** out, uint64_t n, uint32_t msg_len, uin
     e->device = dev;
     e->modes = {options->pairing_mode == 0, options->g2_mode == 1};
     e->staged = max_steps > 1 || n_buffers > 1;
+    e->chains_inlined = options->chain_variant == 2 || (options->chain_variant == 0 && !e->staged);
     make_layout(msg_len, &e->L, options->n_keys);
     e->LS = staging_layout(e->L, e->modes);
     for (int i = 0; i < BLSW_MAX_CONSUMED; i++) {
@@ -764,23 +768,24 @@ int blsw_aggregate_verify_batch(const uint64_t* d_pks_xy, const uint8_t* d_bitma
     StepDesc* d_desc = reinterpret_cast<StepDesc*>(base + off_desc);
     Fp* keyproj = reinterpret_cast<Fp*>(base + off_keyproj);
     Group g = direct_group(n, 1, msg_len, L, d_desc, carve(base + off_ws, n, L, false, DEFAULT_MODES));
+    const ChainKernels ck = chain_kernels(true);  // direct mode: few waves, latency-bound
     hipStream_t st = reinterpret_cast<hipStream_t>(stream_);
     DeviceGuard guard(stream_device(st));  // the device that owns `stream`
     StepDesc h = {nullptr, d_sig_xy, d_msg, d_witness, witness_stride, d_result, d_pks_xy, d_bitmap, d_count};
     if (int rc = put_desc(d_desc, h, st)) return rc;
     const unsigned g1 = (unsigned)((n + 63) / 64), g2 = (unsigned)((2 * n + 63) / 64), gk = (unsigned)((n * n_keys + 63) / 64);
-    hipLaunchKernelGGL(k_agg_keys, dim3(gk), dim3(64), 0, st, g, keyproj);
-    hipLaunchKernelGGL(k_agg_sum, dim3(g1), dim3(64), 0, st, g, (const Fp*)keyproj);
-    hipLaunchKernelGGL(k_g2_alloc, dim3(g1), dim3(64), 0, st, g);
-    hipLaunchKernelGGL(k_prepare, dim3(g1), dim3(64), 0, st, g, 1);
-    hipLaunchKernelGGL(k_sha, dim3(g1), dim3(64), 0, st, g, d_witness ? 1 : 0, 1);
+    hipLaunchKernelGGL(ck.agg_keys, dim3(gk), dim3(64), 0, st, g, keyproj);
+    hipLaunchKernelGGL(ck.agg_sum, dim3(g1), dim3(64), 0, st, g, (const Fp*)keyproj);
+    hipLaunchKernelGGL(ck.g2_alloc, dim3(g1), dim3(64), 0, st, g);
+    hipLaunchKernelGGL(ck.prepare, dim3(g1), dim3(64), 0, st, g, 1);
+    hipLaunchKernelGGL(ck.sha, dim3(g1), dim3(64), 0, st, g, d_witness ? 1 : 0, 1);
     if (d_witness) {
         ExpandArgs xa = {g.ws.bits, g.ws.sha_words, 0, g.L.sha_bits, g.L.off_expand, d_witness, witness_stride, 1u, 0u, 0};
         launch_expand(BLSW_DEFAULT_EXPAND_VARIANT, 0, 0, st, xa, (unsigned)n);
     }
-    hipLaunchKernelGGL(k_map, dim3(g2), dim3(64), 0, st, g);
-    hipLaunchKernelGGL(k_cofactor, dim3(g1), dim3(64), 0, st, g);
-    hipLaunchKernelGGL(k_prepare, dim3(g1), dim3(64), 0, st, g, 0);
+    hipLaunchKernelGGL(ck.map, dim3(g2), dim3(64), 0, st, g);
+    hipLaunchKernelGGL(ck.cofactor, dim3(g1), dim3(64), 0, st, g);
+    hipLaunchKernelGGL(ck.prepare, dim3(g1), dim3(64), 0, st, g, 0);
     launch_pairing(g, DEFAULT_MODES, st);
     return hip_ok(hipGetLastError(), "launch");
 }
@@ -813,6 +818,7 @@ int blsw_verify_multi_batch(const uint64_t* d_pks_xy, const uint8_t* d_msgs, uin
     if (ws.total_bytes + 256 + (par ? miller_par_bytes(n, n_pairs, BLSW_MILLER_CHUNK_DEFAULT) : 0) > workspace_bytes) return BLSW_ERR_WORKSPACE;
     Group gp = direct_group(n, n_pairs, msg_len, L, d_desc, ws);  // per-pair work: N = n * n_pairs lanes
     Group gs = direct_group(n, 1, msg_len, L, d_desc, ws);        // per-signature work: N = n lanes
+    const ChainKernels ck = chain_kernels(true);                  // direct mode: few waves, latency-bound
     hipStream_t st = reinterpret_cast<hipStream_t>(stream_);
     const int dev = stream_device(st);  // the device that owns `stream`
     DeviceGuard guard(dev);
@@ -846,15 +852,15 @@ int blsw_verify_multi_batch(const uint64_t* d_pks_xy, const uint8_t* d_msgs, uin
         hipStreamWaitEvent(s_sig, ev_fork, 0);
         hipStreamWaitEvent(s_keys, ev_fork, 0);
     }
-    hipLaunchKernelGGL(k_g2_alloc, dim3(s1), dim3(64), 0, s_sig, gs);
-    hipLaunchKernelGGL(k_prepare, dim3(s1), dim3(64), 0, s_sig, gs, 1);
-    hipLaunchKernelGGL(k_g1, dim3(p1), dim3(64), 0, s_keys, gp);
+    hipLaunchKernelGGL(ck.g2_alloc, dim3(s1), dim3(64), 0, s_sig, gs);
+    hipLaunchKernelGGL(ck.prepare, dim3(s1), dim3(64), 0, s_sig, gs, 1);
+    hipLaunchKernelGGL(ck.g1, dim3(p1), dim3(64), 0, s_keys, gp);
     // the SHA witness bits and their expansion (92 % of the output bytes) need only the messages: their own stream, beside the curve
     // chains; the chains start from the value-only hash_to_field
     hipStream_t s_exp = forked ? sd.aux[2] : st;
     if (forked) hipStreamWaitEvent(s_exp, ev_fork, 0);
     if (d_witness) {
-        hipLaunchKernelGGL(k_sha, dim3(p1), dim3(64), 0, s_exp, gp, 1, 0);
+        hipLaunchKernelGGL(ck.sha, dim3(p1), dim3(64), 0, s_exp, gp, 1, 0);
         // blockIdx.y = flat (instance, pair); grid.y <= 65535: several launches for larger batches
         const uint64_t per_launch = (65535 / n_pairs) * (uint64_t)n_pairs;
         for (uint64_t first = 0; first < NP; first += per_launch) {
@@ -864,9 +870,9 @@ int blsw_verify_multi_batch(const uint64_t* d_pks_xy, const uint8_t* d_msgs, uin
         }
     }
     hipLaunchKernelGGL(k_sha_values, dim3(p1), dim3(64), 0, st, gp);
-    hipLaunchKernelGGL(k_map, dim3(p2), dim3(64), 0, st, gp);
-    hipLaunchKernelGGL(k_cofactor, dim3(p1), dim3(64), 0, st, gp);
-    hipLaunchKernelGGL(k_prepare, dim3(p1), dim3(64), 0, st, gp, 0);
+    hipLaunchKernelGGL(ck.map, dim3(p2), dim3(64), 0, st, gp);
+    hipLaunchKernelGGL(ck.cofactor, dim3(p1), dim3(64), 0, st, gp);
+    hipLaunchKernelGGL(ck.prepare, dim3(p1), dim3(64), 0, st, gp, 0);
     if (forked) {
         hipEventRecord(ev_join[0], s_sig);
         hipEventRecord(ev_join[1], s_keys);

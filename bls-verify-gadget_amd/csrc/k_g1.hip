@@ -1,5 +1,5 @@
 // libblsw.so, one translation unit per kernel family (see kcommon.cuh, build.py).
-#if defined(BLSW_CHAINS_INLINED) || defined(BLSW_INL_G1)  // build variant: the chain programs inlined into the kernel (fp.cuh: BLSW_FN)
+#if defined(BLSW_KVARIANT_INL) || defined(BLSW_CHAINS_INLINED) || defined(BLSW_INL_G1)  // build variant: the chain programs inlined into the kernel (fp.cuh: BLSW_FN)
 #define BLSW_INLINE_CHAINS 1
 #endif
 #include "kcommon.cuh"
@@ -11,7 +11,7 @@
 
 namespace blsw {
 
-__global__ __launch_bounds__(64) BLSW_CHAIN_ATTR void k_g1(Group g) {
+__global__ __launch_bounds__(64) BLSW_CHAIN_ATTR void BLSW_K(k_g1)(Group g) {
     if (g.chain_prio) __builtin_amdgcn_s_setprio(3);  // latency-critical chain: win VALU issue arbitration against the streaming placement waves
     uint64_t I = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (I >= g.N) return;
@@ -24,7 +24,7 @@ __global__ __launch_bounds__(64) BLSW_CHAIN_ATTR void k_g1(Group g) {
 }
 
 // aggregate_verify: lane t = k * N + I allocates key k of instance I (N * n_keys lanes), result to ws.keyproj
-__global__ __launch_bounds__(64) BLSW_CHAIN_ATTR void k_agg_keys(Group g, Fp* keyproj) {
+__global__ __launch_bounds__(64) BLSW_CHAIN_ATTR void BLSW_K(k_agg_keys)(Group g, Fp* keyproj) {
     if (g.chain_prio) __builtin_amdgcn_s_setprio(3);
     uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t N = g.N, nk = g.L.n_keys;
@@ -47,7 +47,7 @@ struct KeyProjSrc {
     }
 };
 // aggregate_verify: bitmap booleans, mapped_aggregate, then pk != 0 and prepare_g1 on the aggregated key
-__global__ __launch_bounds__(64) BLSW_CHAIN_ATTR void k_agg_sum(Group g, const Fp* keyproj) {
+__global__ __launch_bounds__(64) BLSW_CHAIN_ATTR void BLSW_K(k_agg_sum)(Group g, const Fp* keyproj) {
     if (g.chain_prio) __builtin_amdgcn_s_setprio(3);
     uint64_t I = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (I >= g.N) return;

@@ -1,5 +1,5 @@
 // libblsw.so, one translation unit per kernel family (see kcommon.cuh, build.py).
-#if defined(BLSW_CHAINS_INLINED) || defined(BLSW_INL_G2)  // build variant: the chain programs inlined into the kernel (fp.cuh: BLSW_FN)
+#if defined(BLSW_KVARIANT_INL) || defined(BLSW_CHAINS_INLINED) || defined(BLSW_INL_G2)  // build variant: the chain programs inlined into the kernel (fp.cuh: BLSW_FN)
 #define BLSW_INLINE_CHAINS 1
 #endif
 #include "kcommon.cuh"
@@ -11,7 +11,7 @@
 
 namespace blsw {
 
-__global__ __launch_bounds__(64) BLSW_CHAIN_ATTR void k_g2_alloc(Group g) {
+__global__ __launch_bounds__(64) BLSW_CHAIN_ATTR void BLSW_K(k_g2_alloc)(Group g) {
     if (g.chain_prio) __builtin_amdgcn_s_setprio(3);  // latency-critical chain: win VALU issue arbitration against the streaming placement waves
     uint64_t I = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (I >= g.N) return;

@@ -1,5 +1,5 @@
 // libblsw.so, one translation unit per kernel family (see kcommon.cuh, build.py).
-#if defined(BLSW_CHAINS_INLINED) || defined(BLSW_INL_MAP)  // build variant: the chain programs inlined into the kernel (fp.cuh: BLSW_FN)
+#if defined(BLSW_KVARIANT_INL) || defined(BLSW_CHAINS_INLINED) || defined(BLSW_INL_MAP)  // build variant: the chain programs inlined into the kernel (fp.cuh: BLSW_FN)
 #define BLSW_INLINE_CHAINS 1
 #endif
 #include "kcommon.cuh"
@@ -12,7 +12,7 @@
 namespace blsw {
 
 // lanes [0, N): u0 -> Q0 ; lanes [N, 2N): u1 -> Q1
-__global__ __launch_bounds__(64) BLSW_CHAIN_ATTR void k_map(Group g) {
+__global__ __launch_bounds__(64) BLSW_CHAIN_ATTR void BLSW_K(k_map)(Group g) {
     if (g.chain_prio) __builtin_amdgcn_s_setprio(3);  // latency-critical chain: win VALU issue arbitration against the streaming placement waves
     uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= 2 * g.N) return;

@@ -1,5 +1,5 @@
 // libblsw.so, one translation unit per kernel family (see kcommon.cuh, build.py).
-#if defined(BLSW_CHAINS_INLINED) || defined(BLSW_INL_SHA)  // build variant: the chain programs inlined into the kernel (fp.cuh: BLSW_FN)
+#if defined(BLSW_KVARIANT_INL) || defined(BLSW_CHAINS_INLINED) || defined(BLSW_INL_SHA)  // build variant: the chain programs inlined into the kernel (fp.cuh: BLSW_FN)
 #define BLSW_INLINE_CHAINS 1
 #endif
 #include "kcommon.cuh"
@@ -13,7 +13,7 @@ namespace blsw {
 
 // ---------------------------------------------------------------- kernels (one instance per lane)
 // SHA-256 witness bits of expand_message (+ the message bits themselves)
-__global__ __launch_bounds__(64) BLSW_CHAIN_ATTR void k_sha(Group g, int want_bits, int write_u) {
+__global__ __launch_bounds__(64) BLSW_CHAIN_ATTR void BLSW_K(k_sha)(Group g, int want_bits, int write_u) {
     __shared__ uint32_t sha_lds[BLSW_BITS_CHUNK_WORDS * 64];  // the wave's word buffer of the bit sink
     if (g.chain_prio) __builtin_amdgcn_s_setprio(3);  // latency-critical chain: win VALU issue arbitration against the streaming placement waves
     uint64_t I = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -38,6 +38,7 @@ __global__ __launch_bounds__(64) BLSW_CHAIN_ATTR void k_sha(Group g, int want_bi
         for (int j = 0; j < 4; j++) st_fp(g.ws.u + (uint64_t)j * g.N + I, hash_to_field_elem(uw + 16 * j));
 }
 
+#ifndef BLSW_KVARIANT_INL
 // value-only expand_message + hash_to_field: hands u0, u1 to k_map without waiting for the witness-bit pass
 __global__ __launch_bounds__(64) void k_sha_values(Group g) {
     if (g.chain_prio) __builtin_amdgcn_s_setprio(3);  // latency-critical chain: win VALU issue arbitration against the streaming placement waves
@@ -48,5 +49,7 @@ __global__ __launch_bounds__(64) void k_sha_values(Group g) {
     expand_message_values(g.desc[id.s].msg + (uint64_t)id.f * g.msg_len, g.msg_len, uw);
     for (int j = 0; j < 4; j++) st_fp(g.ws.u + (uint64_t)j * g.N + I, hash_to_field_elem(uw + 16 * j));
 }
+
+#endif
 
 }  // namespace blsw

@@ -230,6 +230,17 @@ struct ExpandArgs {
 
 #define BLSW_TEAMS_PER_WAVE 10
 #define BLSW_ATTR_W2 __attribute__((amdgpu_waves_per_eu(2, 2)))  // register budget of a kernel: two waves per SIMD
+// The one-instance-per-lane chain units (k_sha, k_g1, k_g2, k_map, k_cofactor, k_prepare) are compiled TWICE (build.py):
+//   k_map      the chain programs out of line (BLSW_FN functions): 410-420 registers per kernel, which leaves room for a few waves of the
+//              streaming kernels on the same SIMD — what the grouped engine wants beside its HBM-bound expansion / placement
+//   k_map_inl  (-DBLSW_KVARIANT_INL) the programs inlined into the kernel: the whole 512-register file, 0.1-0.7 KB of stack instead of
+//              1.2-3.9 KB (no argument / callee-saved traffic through scratch): 1.2-3.5x shorter under HBM load (k_map 32.8 -> 9.2 ms,
+//              k_g1 22 -> 8.5 ms in blsw_verify_multi_batch) — what the direct-mode entries want (few waves, latency-bound)
+#ifdef BLSW_KVARIANT_INL
+#define BLSW_K(name) name##_inl
+#else
+#define BLSW_K(name) name
+#endif
 #ifndef BLSW_PLACE_ITERS
 #define BLSW_PLACE_ITERS 8
 #endif
@@ -237,6 +248,7 @@ struct ExpandArgs {
 
 // ---------------------------------------------------------------- kernels (defined in k_*.hip, launched by engine.hip)
 __global__ void k_sha(Group g, int want_bits, int write_u);
+__global__ void k_sha_inl(Group g, int want_bits, int write_u);
 __global__ void k_sha_values(Group g);
 __global__ void k_place_field(const Fp* __restrict__ staging, const Fp* __restrict__ pair, uint64_t first, uint32_t off_expand, uint32_t sha_bits,
                               uint32_t staging_rows, uint32_t split_row, uint64_t* __restrict__ d_witness, uint64_t stride, uint32_t n_inst, uint32_t moved_lo,
@@ -244,14 +256,21 @@ __global__ void k_place_field(const Fp* __restrict__ staging, const Fp* __restri
 __global__ void k_canonical_rows(uint64_t* __restrict__ d_witness, uint64_t stride, uint32_t off_expand, uint32_t sha_bits, uint32_t rows);
 __global__ void k_digest(const uint64_t* __restrict__ w, uint64_t stride, uint64_t n_words, uint64_t* __restrict__ digest);
 __global__ void k_g1(Group g);
+__global__ void k_g1_inl(Group g);
 __global__ void k_agg_keys(Group g, Fp* keyproj);
+__global__ void k_agg_keys_inl(Group g, Fp* keyproj);
 __global__ void k_agg_sum(Group g, const Fp* keyproj);
+__global__ void k_agg_sum_inl(Group g, const Fp* keyproj);
 __global__ void k_g2_alloc(Group g);
+__global__ void k_g2_alloc_inl(Group g);
 __global__ void k_map(Group g);
+__global__ void k_map_inl(Group g);
 __global__ void k_cofactor(Group g);
+__global__ void k_cofactor_inl(Group g);
 __global__ void k_map_values(Group g);
 __global__ void k_cofactor_values(Group g);
 __global__ void k_prepare(Group g, int which);
+__global__ void k_prepare_inl(Group g, int which);
 __global__ void k_pairing(Group g);
 __global__ void k_pairing_team(Group g);
 __global__ void k_g2_alloc_team(Group g);
@@ -280,6 +299,21 @@ inline uint64_t miller_par_bytes(uint64_t n, uint32_t K, uint32_t B) {
     return (2 * n * 68 * C + 2 * n * 68 + n) * 12 * sizeof(Fp) + 5 * 256;
 }
 void launch_miller_par(const Group& gs, const MillerParArgs& a, hipStream_t st, hipStream_t side, hipEvent_t ev_spine, hipEvent_t ev_side);
+// the two compilations of the chain units as one table
+struct ChainKernels {
+    void (*sha)(Group, int, int);
+    void (*g1)(Group);
+    void (*agg_keys)(Group, Fp*);
+    void (*agg_sum)(Group, const Fp*);
+    void (*g2_alloc)(Group);
+    void (*map)(Group);
+    void (*cofactor)(Group);
+    void (*prepare)(Group, int);
+};
+inline ChainKernels chain_kernels(bool inlined) {
+    if (inlined) return {k_sha_inl, k_g1_inl, k_agg_keys_inl, k_agg_sum_inl, k_g2_alloc_inl, k_map_inl, k_cofactor_inl, k_prepare_inl};
+    return {k_sha, k_g1, k_agg_keys, k_agg_sum, k_g2_alloc, k_map, k_cofactor, k_prepare};
+}
 // host-side launch helpers that live next to their (templated) kernels
 void launch_expand(uint32_t variant, uint32_t store, unsigned lds, hipStream_t st, ExpandArgs a, unsigned n_y);
 void launch_pairing(const Group& g, const Modes& m, hipStream_t st);

@@ -122,6 +122,10 @@ typedef struct {
                               little-endian — what CanonicalSerialize writes for an Fq (a prover in another process, a file).
                               The compact wire form is the same for both; blsw_engine_expand_compact follows the expanding
                               engine's option */
+    uint32_t chain_variant; /* which compilation of the one-instance-per-lane chain kernels: 0 (default) = out of line in the grouped
+                              engine (they leave registers to the streaming kernels that share their SIMDs), inlined in direct mode
+                              (max_steps == 1 and n_buffers == 1: shorter under load, the whole register file); 1 = out of line;
+                              2 = inlined. Same witnesses either way. */
 } blsw_engine_options_t;
 /* the defaults (pure: the library reads no environment variable; measurement scripts set the fields they want to vary) */
 int blsw_engine_options_default(blsw_engine_options_t* out);

@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--agg-steps", type=int, default=9)
     ap.add_argument("--agg-coalesce", type=int, default=3)
     ap.add_argument("--multi-pairs", type=int, default=128)
-    ap.add_argument("--multi-n", type=int, default=40)  # 40 x 4.19 GB of witnesses per call
+    ap.add_argument("--multi-n", type=int, default=48)  # 48 x 4.19 GB of witnesses per call (the rest of HBM stays free for the runtime's per-queue scratch)
     args = ap.parse_args()
     import torch
 
