@@ -62,6 +62,10 @@ def parse_args():
     ap.add_argument("--allgather-steps", type=int, default=32, help="steps of the generation + all-gather leg (0 = skip; runs when a process group exists)")
     ap.add_argument("--allgather-chunk", type=int, default=64, help="instances per rank in one all-gathered micro-batch (form full)")
     ap.add_argument("--allgather-group", type=int, default=16, help="steps per launch group in the all-gather leg (consumer-mode engine)")
+    ap.add_argument("--allgather-overlap", type=int, default=-1,
+                    help="compact form: 1 = the gather of step k + 1 on a communication stream beside expansion + digest of step k; 0 = one stream; -1 = 1 when there "
+                         "is something to overlap (world > 1): at world 1 the gather is a local copy and the second stream only adds contention (48.5 k vs 44.2 k instances/s)")
+    ap.add_argument("--consumer-steady-shard", type=int, default=32768, help="a second, longer consumer-mode run (steady state: HBM-bound rather than chain-latency-bound; 0 = skip)")
     ap.add_argument("--allgather-form", choices=("compact", "full"), default="compact",
                     help="what travels in the all-gather leg: the compact wire form, expanded by every receiver, or the full witness tensors")
     return ap.parse_args()
@@ -241,7 +245,8 @@ def allgather_leg_compact(args, pkg, sharding, dist, dev, inputs, lay, world):
 
     # double-buffered: the RCCL all-gather of step k + 1 runs on the communication stream while every rank's part of step k is
     # expanded and digested on the consumer stream (two gathered buffers)
-    pipe = sharding.CompactGatherPipeline(world, eng.compact_bytes(), dev, expand, consume, comm_stream=comm, consumer_stream=consumer)
+    overlap = (world > 1) if args.allgather_overlap < 0 else bool(args.allgather_overlap)
+    pipe = sharding.CompactGatherPipeline(world, eng.compact_bytes(), dev, expand, consume, comm_stream=comm if overlap else consumer, consumer_stream=consumer)
 
     def drain():
         while state["next"] < eng.materialised():
@@ -282,7 +287,7 @@ def allgather_leg_compact(args, pkg, sharding, dist, dev, inputs, lay, world):
     cb = eng.compact_bytes()
     eng.close()
     return float(t.item()), steps, {"form": "compact", "world": world, "rccl_ranks": dist.get_world_size(), "group_steps": group, "ring": ring, "consumer_mode": True,
-                                    "overlap": "all-gather of step k + 1 on a communication stream beside expansion + digest of step k (two gathered buffers)",
+                                    "overlap": "all-gather of step k + 1 on a communication stream beside expansion + digest of step k (two gathered buffers)" if overlap else "none (one stream: world 1, the gather is a local copy)",
                                     "wire_bytes_per_instance": cb / n,
                                     "bytes_received_per_gpu_per_step": (world - 1) * cb,
                                     "bytes_expanded_per_gpu_per_step": world * n * lay["n_witness"] * 48,
@@ -407,8 +412,14 @@ def main():
                         "consumer": "blsw_witness_digest reads every witness tensor before the engine may overwrite it (consumer-mode engine: late materialisation)",
                         "hbm_bytes_per_instance": 2 * lay["n_witness"] * 48}
             del cs
+            if args.consumer_steady_shard >= 4 * n:
+                torch.cuda.empty_cache()
+                cs = sharding.stream_shard(pkg, args.consumer_steady_shard // n * n, n, 2, 0, 1, device=dev)
+                consumer["steady"] = {"value": cs["instances_per_s"], "shard_instances": cs["n_shard"], "steps": cs["steps"], "group_steps": cs["group_steps"], "seconds": cs["seconds"],
+                                      "results_ok": cs["results_ok"], "hbm_GBps_written_plus_read": cs["instances_per_s"] * 2 * lay["n_witness"] * 48 / 1e9}
+                del cs
         except Exception as exc:  # noqa: BLE001 (reported in the JSON line)
-            consumer = {"error": "%s: %s" % (type(exc).__name__, exc)}
+            consumer = dict(consumer or {}, error="%s: %s" % (type(exc).__name__, exc))
         torch.cuda.empty_cache()
 
     ag = None
@@ -485,6 +496,7 @@ def main():
     out["witness_ok"] = witness_ok  # digests of the ring tensors after the timed region == a direct-mode engine's on the same batch
     if consumer:
         out["value_consumer_mode"] = consumer.get("value")
+        out["value_consumer_mode_steady"] = (consumer.get("steady") or {}).get("value")
         out["consumer_mode"] = consumer
     if ag:
         ag_dt, ag_steps, ag_info = ag
