@@ -28,7 +28,7 @@ class blsw_layout_t(ctypes.Structure):
 
 
 class blsw_engine_options_t(ctypes.Structure):
-    _fields_ = [("device", ctypes.c_int32)] + [(n, ctypes.c_uint32) for n in "n_keys pairing_mode g2_mode expand_variant expand_store prio_mode place_lds consumer_mode output_form chain_variant".split()]
+    _fields_ = [("device", ctypes.c_int32)] + [(n, ctypes.c_uint32) for n in "n_keys pairing_mode g2_mode expand_variant expand_store prio_mode place_lds consumer_mode output_form chain_variant n_pairs".split()]
 
 
 class blsw_matrices_info_t(ctypes.Structure):
@@ -97,6 +97,7 @@ def lib():
         L.blsw_verify_multi_batch.argtypes = [vp, vp, u32, u32, vp, u64, vp, u64, vp, vp, u64, vp]
         L.blsw_engine_destroy.argtypes = [vp]
         L.blsw_engine_submit.argtypes = [vp, vp, vp, vp, vp, u64, vp, vp]
+        L.blsw_engine_submit_multi.argtypes = [vp, vp, vp, vp, vp, u64, vp, vp]
         L.blsw_engine_submit_bytes.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, u64, vp, vp]
         L.blsw_engine_flush.argtypes = [vp, vp]
         L.blsw_engine_expand_stats.argtypes = [vp, ctypes.POINTER(u32), ctypes.POINTER(ctypes.c_float)]
@@ -113,7 +114,7 @@ def lib():
 
 
 EXPORTED_SYMBOLS = ["blsw_version", "blsw_layout", "blsw_engine_options_default", "blsw_engine_workspace_bytes", "blsw_engine_workspace_bytes_ex", "blsw_engine_create",
-                    "blsw_engine_create_ex", "blsw_engine_destroy", "blsw_engine_submit", "blsw_engine_submit_bytes", "blsw_engine_submit_aggregate", "blsw_engine_flush", "blsw_engine_submitted", "blsw_engine_launched", "blsw_engine_materialised", "blsw_engine_wait_step",
+                    "blsw_engine_create_ex", "blsw_engine_destroy", "blsw_engine_submit", "blsw_engine_submit_bytes", "blsw_engine_submit_multi", "blsw_engine_submit_aggregate", "blsw_engine_flush", "blsw_engine_submitted", "blsw_engine_launched", "blsw_engine_materialised", "blsw_engine_wait_step",
                     "blsw_engine_output_consumed", "blsw_engine_compact_bytes", "blsw_engine_submit_compact", "blsw_engine_submit_aggregate_compact", "blsw_engine_expand_compact", "blsw_engine_expand_stats", "blsw_witness_digest", "blsw_hash_to_g2_workspace_bytes", "blsw_hash_to_g2_batch",
                     "blsw_decode_batch", "blsw_layout_aggregate", "blsw_aggregate_workspace_bytes", "blsw_aggregate_verify_batch", "blsw_layout_multi",
                     "blsw_verify_multi_workspace_bytes", "blsw_verify_multi_batch", "blsw_matrices_info", "blsw_matrices_fill", "blsw_sign_batch", "blsw_microbench"]
@@ -185,7 +186,8 @@ class WitnessEngine:
         opt = engine_options(**options)
         opt.device = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.n_keys = int(opt.n_keys)
-        self.layout = layout_aggregate(msg_len, self.n_keys) if self.n_keys else layout(msg_len)
+        self.n_pairs = int(opt.n_pairs) if opt.n_pairs > 1 else 1
+        self.layout = layout_aggregate(msg_len, self.n_keys) if self.n_keys else (layout_multi(msg_len, self.n_pairs) if self.n_pairs > 1 else layout(msg_len))
         self.n_witness = self.layout["n_witness"]
         wb = ctypes.c_uint64(0)
         rc = lib().blsw_engine_workspace_bytes_ex(self.n, self.msg_len, self.max_steps, self.n_buffers, ctypes.byref(opt), ctypes.byref(wb))
@@ -256,6 +258,23 @@ class WitnessEngine:
         self._keep.append((pk48, sig96, msg, pk_xy, sig_xy, status, witness, result))
         self._keep = self._keep[-(self.n_buffers + 1) * self.max_steps:]
         return seq, pk_xy, sig_xy, status
+
+    def submit_multi(self, pks_xy, msgs, sig_xy, witness=None, result=None, stream=None):
+        """N+1-pair product batch (engine created with n_pairs=K): pks_xy [n, K, 12] int64, msgs [n, K, msg_len] uint8, sig_xy [n, 24] -> step number"""
+        K = self.n_pairs
+        assert K > 1 and pks_xy.shape == (self.n, K, 12) and msgs.shape == (self.n, K, self.msg_len) and sig_xy.shape == (self.n, 24)
+        assert pks_xy.is_contiguous() and msgs.is_contiguous() and sig_xy.is_contiguous()
+        if witness is not None:
+            assert witness.is_contiguous() and witness.shape[0] == self.n and witness.shape[1] >= self.n_witness
+        seq = self.submitted()
+        rc = lib().blsw_engine_submit_multi(self._e, pks_xy.data_ptr(), msgs.data_ptr() if self.msg_len else None, sig_xy.data_ptr(),
+                                            witness.data_ptr() if witness is not None else None, witness.shape[1] if witness is not None else 0,
+                                            result.data_ptr() if result is not None else None, self._stream(stream))
+        if rc:
+            raise (BlswBusy if rc == ERR_BUSY else BlswError)("blsw_engine_submit_multi failed: %d" % rc)
+        self._keep.append((pks_xy, msgs, sig_xy, witness, result))
+        self._keep = self._keep[-(self.n_buffers + 1) * self.max_steps:]
+        return seq
 
     def submit_aggregate(self, pks_xy, bitmap, sig_xy, msg, witness=None, result=None, count=None, stream=None):
         """aggregate_verify batch (engine created with n_keys=K): pks_xy [n, K, 12] int64, bitmap [n, K] uint8 -> step number"""

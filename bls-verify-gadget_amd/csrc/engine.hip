@@ -151,6 +151,34 @@ static void launch_place(blsw_engine* e, hipStream_t st, const Fp* staging, cons
     hipLaunchKernelGGL(k_place_field, grid2, dim3(256), 0, st, staging, pair, first, e->L.off_expand, e->L.sha_bits, rows, split_row, out, out_stride, (uint32_t)e->n,
                        e->L.off_sig_alloc, e->modes.g2_team ? e->L.off_pk_not_zero - e->L.off_sig_alloc : 0u, e->LS.off_sig_alloc);
 }
+// N+1-pair product: a step's pair tiles, instance tiles and instance-major rows -> their places in the n instance vectors
+static void launch_place_multi(blsw_engine* e, hipStream_t st, const Workspace& ws, uint32_t s, uint64_t* out, uint64_t out_stride) {
+    const blsw_layout_t& L = e->L;
+    const blsw_layout_t& S = e->LS;
+    const uint32_t K = L.n_pairs, n = (uint32_t)e->n;
+    PlaceRuns pr = {};
+    pr.n_runs = 6;
+    const uint32_t src[7] = {S.off_msg, S.off_pk_alloc, S.off_pk_not_zero, S.off_map0, S.off_prep_h, S.off_prep_pk, ws.rows_p};
+    const uint32_t dst[6] = {L.off_msg, L.off_pk_alloc, L.off_pk_not_zero, L.off_map0, L.off_prep_h, L.off_prep_pk};
+    const uint32_t str[6] = {L.stride_msg, L.stride_pk_alloc, L.stride_pk_not_zero, L.stride_hash, L.stride_prep_h, L.stride_prep_pk};
+    for (int r = 0; r < 7; r++) pr.src_row[r] = src[r];
+    for (int r = 0; r < 6; r++) pr.dst_off[r] = dst[r], pr.dst_stride[r] = str[r];
+    auto blocks = [](uint32_t rows, uint32_t n_y) {
+        const unsigned chunks = (rows * 3 + 256 * BLSW_PLACE_ITERS - 1) / (256 * BLSW_PLACE_ITERS);
+        return dim3(8 * ((chunks + 7) / 8) * n_y);
+    };
+    hipLaunchKernelGGL(k_place_runs, blocks(ws.rows_p, n * K), dim3(256), 0, st, (const Fp*)ws.staging, (uint64_t)s * n * K, ws.rows_p, pr, out, out_stride, n * K, K);
+    PlaceRuns pi = {};
+    pi.n_runs = 2;
+    pi.src_row[0] = S.off_sig_alloc;
+    pi.src_row[1] = S.off_prep_sig;
+    pi.src_row[2] = ws.rows_i;
+    pi.dst_off[0] = L.off_sig_alloc;
+    pi.dst_off[1] = L.off_prep_sig;
+    hipLaunchKernelGGL(k_place_runs, blocks(ws.rows_i, n), dim3(256), 0, st, (const Fp*)ws.staging_inst, (uint64_t)s * n, ws.rows_i, pi, out, out_stride, n, 1u);
+    const unsigned chunks = (ws.pair_rows * 3 + 256 * BLSW_PLACE_ITERS - 1) / (256 * BLSW_PLACE_ITERS);
+    hipLaunchKernelGGL(k_place_rows, dim3(chunks, n), dim3(256), 0, st, (const Fp*)(ws.pair + (uint64_t)s * n * ws.pair_rows), ws.pair_rows, L.off_miller, out, out_stride);
+}
 static void launch_canonical(blsw_engine* e, hipStream_t st, uint64_t* out, uint64_t out_stride) {
     const uint32_t rows = e->L.n_witness - e->L.sha_bits;
     hipLaunchKernelGGL(k_canonical_rows, dim3((rows + 255) / 256, (unsigned)e->n), dim3(256), 0, st, out, out_stride, e->L.off_expand, e->L.sha_bits, rows);
@@ -202,8 +230,9 @@ static void materialise(blsw_engine* e, int k, uint32_t s) {
         wait_released(e, e->expand, d.out);
         const bool timed = e->n_timed < BLSW_MAX_TIMED;
         if (timed) hipEventRecord(e->ev_exp[2 * e->n_timed], e->expand);
-        ExpandArgs xa = {ws.bits, ws.sha_words, (uint64_t)s * e->n, e->L.sha_bits, e->L.off_expand, d.out, d.out_stride, 1u, 0u, 0, (int)e->opt.output_form};
-        if (!(dbg_skip & 4)) launch_expand(e->opt.expand_variant, e->opt.expand_store, e->opt.place_lds, e->expand, xa, (unsigned)e->n);
+        const uint32_t K = e->L.n_pairs;  // 1 except for the N+1-pair product: one SHA segment per (instance, pair)
+        ExpandArgs xa = {ws.bits, ws.sha_words, (uint64_t)s * e->n * K, e->L.sha_bits, e->L.off_expand, d.out, d.out_stride, K, K > 1 ? e->L.stride_hash : 0u, 0, (int)e->opt.output_form};
+        if (!(dbg_skip & 4)) launch_expand(e->opt.expand_variant, e->opt.expand_store, e->opt.place_lds, e->expand, xa, (unsigned)(e->n * K));
         if (timed) {
             hipEventRecord(e->ev_exp[2 * e->n_timed + 1], e->expand);
             e->n_timed++;
@@ -217,7 +246,12 @@ static void materialise(blsw_engine* e, int k, uint32_t s) {
         hipMemcpyAsync(dst + cf.off_staging, ws.staging + (uint64_t)s * (e->n / 64) * ws.split_row * 64, cf.staging_bytes, hipMemcpyDeviceToDevice, e->place);
         if (cf.pair_bytes) hipMemcpyAsync(dst + cf.off_pair, ws.pair + (uint64_t)s * e->n * ws.pair_rows, cf.pair_bytes, hipMemcpyDeviceToDevice, e->place);
     }
-    if (d.out && e->staged && !(dbg_skip & 2)) launch_place(e, e->place, ws.staging, ws.pair, ws.split_row, (uint64_t)s * e->n, d.out, d.out_stride);
+    if (d.out && e->staged && !(dbg_skip & 2)) {
+        if (e->L.n_pairs > 1)
+            launch_place_multi(e, e->place, ws, s, d.out, d.out_stride);
+        else
+            launch_place(e, e->place, ws.staging, ws.pair, ws.split_row, (uint64_t)s * e->n, d.out, d.out_stride);
+    }
     if (d.out && e->opt.output_form) launch_canonical(e, e->place, d.out, d.out_stride);  // direct mode: the chains wrote the rows in place
     hipEventRecord(b.ev_step[s], e->place);
 }
@@ -255,15 +289,16 @@ static int launch_group(blsw_engine* e) {
     GroupBuf& b = e->buf[e->cur];
     const uint32_t steps = e->pending;
     if (steps == 0) return BLSW_OK;
-    Group g;
-    g.N = (uint64_t)steps * e->n;
+    const uint32_t K = e->L.n_pairs;  // (pk, msg) pairs per instance: 1 except for the N+1-pair product
+    Group g;  // per-pair view: one lane per (instance, pair)
+    g.N = (uint64_t)steps * e->n * K;
     g.n = (uint32_t)e->n;
-    g.K = 1;
+    g.K = K;
     g.msg_len = e->msg_len;
     g.desc = b.d_desc;
     g.L = e->L;
     g.LS = e->LS;
-    g.ws = carve(b.base, g.N, e->L, e->staged, e->modes);
+    g.ws = carve(b.base, g.N, e->L, e->staged, e->modes, (uint64_t)steps * e->n);
     g.chain_prio = e->opt.prio_mode == 0;
     const unsigned g1 = (unsigned)((g.N + 63) / 64), g2 = (unsigned)((2 * g.N + 63) / 64);
     const unsigned gt = (unsigned)((g.N + BLSW_TEAMS_PER_WAVE - 1) / BLSW_TEAMS_PER_WAVE);
@@ -284,6 +319,43 @@ static int launch_group(blsw_engine* e) {
     hipStreamWaitEvent(e->sha, b.ev_start, 0);
     if (any_out) hipLaunchKernelGGL(ck.sha, dim3(g1), dim3(64), 0, e->sha, g, 1, 0);
     hipEventRecord(b.ev_sha, e->sha);
+    if (K > 1) {  // N+1-pair product: per-pair chains on N = steps * n * K lanes, per-signature chains and the Miller product on steps * n
+        Group gs = g;
+        gs.N = (uint64_t)steps * e->n;
+        gs.K = 1;
+        const unsigned s1 = (unsigned)((gs.N + 63) / 64);
+        hipLaunchKernelGGL(k_sha_values, dim3(g1), dim3(64), 0, st, g);
+        hipLaunchKernelGGL(ck.map, dim3(g2), dim3(64), 0, st, g);
+        hipLaunchKernelGGL(ck.cofactor, dim3(g1), dim3(64), 0, st, g);
+        hipLaunchKernelGGL(ck.prepare, dim3(g1), dim3(64), 0, st, g, 0);
+        hipLaunchKernelGGL(ck.g2_alloc, dim3(s1), dim3(64), 0, b.st[1], gs);
+        hipLaunchKernelGGL(ck.prepare, dim3(s1), dim3(64), 0, b.st[1], gs, 1);
+        hipLaunchKernelGGL(ck.g1, dim3(g1), dim3(64), 0, b.st[1], g);
+        hipEventRecord(b.ev_aux, b.st[1]);
+        hipStreamWaitEvent(st, b.ev_aux, 0);
+        if (K < BLSW_MILLER_PAR_MIN_PAIRS) {
+            hipLaunchKernelGGL(k_pairing_team_multi, dim3((unsigned)((gs.N + BLSW_TEAMS_PER_WAVE - 1) / BLSW_TEAMS_PER_WAVE)), dim3(64), 0, st, gs, K, g.N);
+        } else {
+            MillerParArgs ma;
+            ma.K = K;
+            ma.B = BLSW_MILLER_CHUNK_DEFAULT;
+            ma.C = (K + ma.B - 1) / ma.B;
+            ma.n_h = g.N;
+            ma.spine_lane = 0;
+            char* p = reinterpret_cast<char*>(b.base) + align_up(g.ws.total_bytes, 256);
+            auto take = [&](uint64_t items) {
+                Fp* r = reinterpret_cast<Fp*>(p);
+                p += align_up(items * 12 * sizeof(Fp), 256);
+                return r;
+            };
+            ma.cprod = take(gs.N * 68 * ma.C);
+            ma.q = take(gs.N * 68 * ma.C);
+            ma.t = take(gs.N * 68);
+            ma.f1 = take(gs.N * 68);
+            ma.ffinal = take(gs.N);
+            launch_miller_par(gs, ma, st, nullptr, nullptr, nullptr);  // one stream: other groups run beside this one
+        }
+    } else
     // main, first part: the hash-to-G2 critical path
     if (!(dbg_skip & 1)) {
     hipLaunchKernelGGL(k_sha_values, dim3(g1), dim3(64), 0, st, g);
@@ -302,10 +374,12 @@ static int launch_group(blsw_engine* e) {
     else
         hipLaunchKernelGGL(ck.g2_alloc, dim3(g1), dim3(64), 0, b.st[1], g);
     }
-    hipEventRecord(b.ev_aux, b.st[1]);
-    // main, second part: the pairing
-    hipStreamWaitEvent(st, b.ev_aux, 0);
-    if (!(dbg_skip & 1)) launch_pairing(g, e->modes, st);
+    if (K == 1) {
+        hipEventRecord(b.ev_aux, b.st[1]);
+        // main, second part: the pairing
+        hipStreamWaitEvent(st, b.ev_aux, 0);
+        if (!(dbg_skip & 1)) launch_pairing(g, e->modes, st);
+    }
     hipStreamWaitEvent(st, b.ev_sha, 0);
     hipEventRecord(b.ev_chains, st);
     // expansion + placement of the group's steps: queued, issued in submission order (at once unless a consumer holds an output)
@@ -345,22 +419,26 @@ int blsw_engine_options_default(blsw_engine_options_t* o) {
     o->consumer_mode = 0;
     o->output_form = 0;
     o->chain_variant = 0;
+    o->n_pairs = 0;
     return BLSW_OK;
 }
 
 int blsw_engine_workspace_bytes_ex(uint64_t n, uint32_t msg_len, uint32_t max_steps, uint32_t n_buffers, const blsw_engine_options_t* options, uint64_t* bytes) {
-    if (!bytes || n == 0 || max_steps == 0 || n_buffers == 0 || n_buffers > BLSW_MAX_BUFFERS || msg_len > 65535 || !options || options->n_keys > 65535)
+    if (!bytes || n == 0 || max_steps == 0 || n_buffers == 0 || n_buffers > BLSW_MAX_BUFFERS || msg_len > 65535 || !options || options->n_keys > 65535 ||
+        options->n_pairs > 4096 || (options->n_pairs > 1 && options->n_keys))
         return BLSW_ERR_ARG;
     blsw_layout_t L;
-    make_layout(msg_len, &L, options->n_keys);
+    const uint32_t K = options->n_pairs > 1 ? options->n_pairs : 1;
+    make_layout(msg_len, &L, options->n_keys, K);
     const bool staged = max_steps > 1 || n_buffers > 1;
     // the same workspace serves every kernel variant: the largest carve of the three mode combinations
     uint64_t need = 0;
     const Modes all[3] = {{true, false}, {true, true}, {false, false}};
     for (const Modes& m : all) {
-        uint64_t t = carve(nullptr, n * max_steps, L, staged, m).total_bytes;
+        uint64_t t = carve(nullptr, n * max_steps * K, L, staged, m, n * max_steps).total_bytes;
         need = t > need ? t : need;
     }
+    if (K > 1) need = align_up(need, 256) + miller_par_bytes(n * max_steps, K, BLSW_MILLER_CHUNK_DEFAULT);  // value stores of the pair-parallel Miller product
     *bytes = (uint64_t)n_buffers * align_up(need, 4096);
     return BLSW_OK;
 }
@@ -380,7 +458,11 @@ int blsw_engine_create_ex(blsw_engine_t** out, uint64_t n, uint32_t msg_len, uin
     if (options->consumer_mode > 1 || (options->consumer_mode == 1 && max_steps == 1 && n_buffers == 1)) return BLSW_ERR_ARG;
     if (options->pairing_mode > 1 || options->g2_mode > 1 || (options->g2_mode == 1 && options->pairing_mode != 0) || options->expand_store > 3 ||
         options->prio_mode > 2 || options->output_form > 1 || options->chain_variant > 2 || (options->expand_variant & 0xff) > 5 || (options->expand_variant >> 9) || options->n_keys > 65535 ||
-        (options->n_keys && options->g2_mode))
+        (options->n_keys && options->g2_mode) || options->n_pairs > 4096)
+        return BLSW_ERR_ARG;
+    // N+1-pair product (options.n_pairs = K > 1): a staged engine with the default kernel modes; its expansion launch has one row of
+    // workgroups per (instance, pair)
+    if (options->n_pairs > 1 && (options->n_keys || options->pairing_mode || options->g2_mode || options->output_form || !(max_steps > 1 || n_buffers > 1) || n * options->n_pairs > 65535))
         return BLSW_ERR_ARG;
     *out = nullptr;
     int ndev = 0;
@@ -418,8 +500,8 @@ int blsw_engine_create_ex(blsw_engine_t** out, uint64_t n, uint32_t msg_len, uin
     e->modes = {options->pairing_mode == 0, options->g2_mode == 1};
     e->staged = max_steps > 1 || n_buffers > 1;
     e->chains_inlined = options->chain_variant == 2 || (options->chain_variant == 0 && !e->staged);
-    make_layout(msg_len, &e->L, options->n_keys);
-    e->LS = staging_layout(e->L, e->modes);
+    make_layout(msg_len, &e->L, options->n_keys, options->n_pairs > 1 ? options->n_pairs : 1);
+    e->LS = e->L.n_pairs > 1 ? staging_layout_multi(e->L).LS : staging_layout(e->L, e->modes);
     for (int i = 0; i < BLSW_MAX_CONSUMED; i++) {
         e->consumed_ptr[i] = nullptr;
         e->consumed_ev[i] = nullptr;
@@ -467,7 +549,7 @@ int blsw_engine_create_ex(blsw_engine_t** out, uint64_t n, uint32_t msg_len, uin
     // a queue makes the runtime grow that queue's scratch, which stalls the queue for ~60 ms (measured: the pairing of the
     // first group of every buffer started 60 ms late). One launch of the same grid with N = 0 (every wave exits at once)
     // per main stream pays that here instead of in the caller's first groups.
-    if (rc == BLSW_OK) {
+    if (rc == BLSW_OK && e->L.n_pairs == 1) {
         Group g0;
         memset(&g0, 0, sizeof(g0));
         g0.n = (uint32_t)n;
@@ -524,8 +606,16 @@ static int engine_submit(blsw_engine_t* e, const StepDesc& step, void* stream_) 
 }
 int blsw_engine_submit(blsw_engine_t* e, const uint64_t* d_pk_xy, const uint64_t* d_sig_xy, const uint8_t* d_msg, uint64_t* d_witness,
                        uint64_t witness_stride, int32_t* d_result, void* stream_) {
-    if (!e || e->L.n_keys || !d_pk_xy || !d_sig_xy || (!d_msg && e->msg_len)) return BLSW_ERR_ARG;
+    if (!e || e->L.n_keys || e->L.n_pairs > 1 || !d_pk_xy || !d_sig_xy || (!d_msg && e->msg_len)) return BLSW_ERR_ARG;
     StepDesc d = {d_pk_xy, d_sig_xy, d_msg, d_witness, witness_stride, d_result, nullptr, nullptr, nullptr, nullptr, nullptr};
+    return engine_submit(e, d, stream_);
+}
+// N+1-pair product through the engine (an engine created with options.n_pairs = K): one batch of n instances, each ONE signature
+// over K (pk, msg) pairs; same grouping / staging / streaming placement / consumer mode as blsw_engine_submit
+int blsw_engine_submit_multi(blsw_engine_t* e, const uint64_t* d_pks_xy, const uint8_t* d_msgs, const uint64_t* d_sig_xy, uint64_t* d_witness, uint64_t witness_stride,
+                             int32_t* d_result, void* stream_) {
+    if (!e || e->L.n_pairs < 2 || !d_pks_xy || !d_sig_xy || (!d_msgs && e->msg_len)) return BLSW_ERR_ARG;
+    StepDesc d = {d_pks_xy, d_sig_xy, d_msgs, d_witness, witness_stride, d_result, nullptr, nullptr, nullptr, nullptr, nullptr};
     return engine_submit(e, d, stream_);
 }
 // One call from compressed bytes: decode on `stream`, then the step; result[i] = gadget Boolean AND both points decoded
@@ -533,7 +623,7 @@ int blsw_engine_submit(blsw_engine_t* e, const uint64_t* d_pk_xy, const uint64_t
 // and the case must come out false). The decoded coordinates live in caller buffers (they are the step's inputs).
 int blsw_engine_submit_bytes(blsw_engine_t* e, const uint8_t* d_pk48, const uint8_t* d_sig96, const uint8_t* d_msg, uint64_t* d_pk_xy, uint64_t* d_sig_xy,
                              int32_t* d_status, uint64_t* d_witness, uint64_t witness_stride, int32_t* d_result, void* stream_) {
-    if (!e || e->L.n_keys || !d_pk48 || !d_sig96 || !d_pk_xy || !d_sig_xy || !d_status || (!d_msg && e->msg_len)) return BLSW_ERR_ARG;
+    if (!e || e->L.n_keys || e->L.n_pairs > 1 || !d_pk48 || !d_sig96 || !d_pk_xy || !d_sig_xy || !d_status || (!d_msg && e->msg_len)) return BLSW_ERR_ARG;
     if (d_witness && witness_stride < e->L.n_witness) return BLSW_ERR_ARG;
     DeviceGuard guard(e->device);
     // the decode is issued only if the step can be taken (same conditions as engine_submit: nothing may be half done on BUSY)
@@ -556,13 +646,13 @@ int blsw_engine_submit_aggregate(blsw_engine_t* e, const uint64_t* d_pks_xy, con
 // Compact wire form (the all-gather of full witness vectors is capped by xGMI at a fraction of the generation
 // rate; 2.6 MB per instance travel instead of 34 MB and the receiver expands them).
 int blsw_engine_compact_bytes(blsw_engine_t* e, uint64_t* bytes) {
-    if (!e || !bytes || !e->staged || e->n % 64) return BLSW_ERR_ARG;
+    if (!e || !bytes || !e->staged || e->n % 64 || e->L.n_pairs > 1) return BLSW_ERR_ARG;
     *bytes = compact_form(e->n, carve(nullptr, e->n, e->L, true, e->modes)).total;
     return BLSW_OK;
 }
 int blsw_engine_submit_compact(blsw_engine_t* e, const uint64_t* d_pk_xy, const uint64_t* d_sig_xy, const uint8_t* d_msg, void* d_compact, int32_t* d_result,
                                void* stream_) {
-    if (!e || e->L.n_keys || !e->staged || e->n % 64 || !d_compact || !d_pk_xy || !d_sig_xy || (!d_msg && e->msg_len)) return BLSW_ERR_ARG;
+    if (!e || e->L.n_keys || e->L.n_pairs > 1 || !e->staged || e->n % 64 || !d_compact || !d_pk_xy || !d_sig_xy || (!d_msg && e->msg_len)) return BLSW_ERR_ARG;
     StepDesc d = {d_pk_xy, d_sig_xy, d_msg, nullptr, 0, d_result, nullptr, nullptr, nullptr, d_compact};
     return engine_submit(e, d, stream_);
 }
@@ -575,7 +665,7 @@ int blsw_engine_submit_aggregate_compact(blsw_engine_t* e, const uint64_t* d_pks
 // receiver side: one batch in compact form -> its n witness vectors, on `stream` (the expansion and placement kernels of the
 // engine's own steps, pointed at the compact buffer)
 int blsw_engine_expand_compact(blsw_engine_t* e, const void* d_compact, uint64_t* d_witness, uint64_t witness_stride, void* stream_) {
-    if (!e || !e->staged || e->n % 64 || !d_compact || !d_witness || witness_stride < e->L.n_witness) return BLSW_ERR_ARG;
+    if (!e || !e->staged || e->n % 64 || e->L.n_pairs > 1 || !d_compact || !d_witness || witness_stride < e->L.n_witness) return BLSW_ERR_ARG;
     DeviceGuard guard(e->device);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream_);
     const Workspace w = carve(nullptr, e->n, e->L, true, e->modes);

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(64) BLSW_CHAIN_ATTR void BLSW_K(k_agg_keys)(Group g
     uint32_t k = (uint32_t)(t / N);
     LaneId id = lane_id(g, t - (uint64_t)k * N);
     const Fp* p = reinterpret_cast<const Fp*>(g.desc[id.s].keys + ((uint64_t)id.i * nk + k) * 12);
-    Proj<OpsFp> r = chain_g1_alloc_only(emitter(g, id, g.L.off_keys + k * SEG_PK_ALLOC, g.LS.off_keys + k * SEG_PK_ALLOC), ld_fp(p), ld_fp(p + 1));
+    Proj<OpsFp> r = chain_g1_alloc_only(emitter(g, id, g.L.off_keys + k * SEG_PK_ALLOC, g.LS.off_keys + k * SEG_PK_ALLOC, false), ld_fp(p), ld_fp(p + 1));
     Fp* o = keyproj + t;
     st_fp(o, r.x);
     st_fp(o + N * nk, r.y);

@@ -175,6 +175,46 @@ __global__ __launch_bounds__(256) void k_place_field(const Fp* __restrict__ stag
     }
 }
 
+// N+1-pair product in the grouped engine: the staged rows of a step go to their places in the instance vectors.
+// k_place_runs: lanes first .. first + n_y of tile-major staging (pair tiles with K pairs per instance, or instance tiles with K = 1);
+// a lane's rows are up to six runs of consecutive rows (PlaceRuns). Same gather shape and XCD-aware block order as k_place_field.
+__global__ __launch_bounds__(256) void k_place_runs(const Fp* __restrict__ tiles, uint64_t first, uint32_t rows, PlaceRuns runs, uint64_t* __restrict__ d_witness,
+                                                    uint64_t stride, uint32_t n_y, uint32_t K) {
+    const uint32_t L = blockIdx.x, s_in_xcd = L >> 3;
+    const uint32_t chunk = (L & 7) + 8 * (s_in_xcd / n_y);
+    const uint32_t y = s_in_xcd % n_y;
+    const uint32_t npieces = rows * 3;
+    if (chunk * (256u * BLSW_PLACE_ITERS) >= npieces) return;
+    const uint64_t lane = first + y;
+    const uint32_t inst = y / K, j = y - inst * K;
+    const uint4* src = reinterpret_cast<const uint4*>(tiles + (lane >> 6) * (uint64_t)rows * 64 + (lane & 63));
+    uint4* out = reinterpret_cast<uint4*>(d_witness + (uint64_t)inst * stride * 6);
+    const uint32_t q0 = chunk * (256 * BLSW_PLACE_ITERS) + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < BLSW_PLACE_ITERS; k++) {
+        const uint32_t q = q0 + k * 256;
+        if (q < npieces) {
+            const uint32_t e = q / 3, c = q - e * 3;
+            uint32_t r = 0;
+#pragma unroll
+            for (int t = 1; t < 6; t++) r += (t < (int)runs.n_runs && e >= runs.src_row[t]) ? 1u : 0u;
+            const uint32_t dst_e = runs.dst_off[r] + j * runs.dst_stride[r] + (e - runs.src_row[r]);
+            out[(uint64_t)dst_e * 3 + c] = src[(uint64_t)e * 64 * 3 + c];
+        }
+    }
+}
+// k_place_rows: instance-major rows (Miller loop, final exponentiation, is_one) -> one contiguous run of each vector. grid (chunks, n)
+__global__ __launch_bounds__(256) void k_place_rows(const Fp* __restrict__ rows, uint32_t n_rows, uint32_t dst_off, uint64_t* __restrict__ d_witness, uint64_t stride) {
+    const uint64_t inst = blockIdx.y;
+    const uint4* src = reinterpret_cast<const uint4*>(rows + inst * n_rows);
+    uint4* out = reinterpret_cast<uint4*>(d_witness + (inst * stride + dst_off) * 6);
+    const uint32_t npieces = n_rows * 3;
+    uint32_t q = blockIdx.x * (256 * BLSW_PLACE_ITERS) + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < BLSW_PLACE_ITERS; k++, q += 256)
+        if (q < npieces) out[q] = src[q];
+}
+
 // Digest of witness vectors (blsw_witness_digest): d[c] = sum_k mix64(w_k + (k + 1) * C_c) over the instance's u64 words.
 // grid (chunks, n); 256 threads, each 16 bytes per iteration; block partial sums -> two atomics per block.
 __device__ __forceinline__ uint64_t mix64(uint64_t z) {

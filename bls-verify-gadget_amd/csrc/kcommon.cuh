@@ -24,10 +24,13 @@ struct Workspace {
     Fp* coeff_sig;   // [272][n_sig]  line coefficients of prepare_g2(sig)
     uint64_t n_sig;  // = N for the single-key circuit; = instances (not pairs) for the N+1-pair product
     Fp* keyproj;     // [3][N * n_keys] allocated keys of the aggregate_verify circuit (projective), else nullptr
-    Fp* staging;     // [N/64][split_row][64] field witnesses (engine mode), or nullptr (direct mode): each wave of 64
-                     // instances owns one contiguous tile and appends 3 KiB rows to it (sequential HBM writes per wave)
+    Fp* staging;     // [N/64][rows_p][64] field witnesses (engine mode), or nullptr (direct mode): each wave of 64
+                     // lanes owns one contiguous tile and appends 3 KiB rows to it (sequential HBM writes per wave)
+    Fp* staging_inst;  // [n_sig/64][rows_i][64] the per-signature rows of the N+1-pair product staged the same way (sig allocation,
+                       // prepare_g2(sig)); = staging (one lane is one instance) for the single-key and aggregate circuits
+    uint32_t rows_p, rows_i;  // rows per tile of the two areas (= split_row when they are one)
     uint64_t staging_rows;
-    Fp* pair;            // [N][pair_rows]: rows >= split_row of the staging coordinates (Miller loop, final exponentiation,
+    Fp* pair;            // [n_sig][pair_rows]: rows >= split_row of the staging coordinates (Miller loop, final exponentiation,
     uint32_t split_row;  // is_one), instance-major: the six-lane pairing kernel appends each instance's segment sequentially
     uint32_t pair_rows;  // (split_row = staging_rows, pair_rows = 0 when the single-lane pairing kernel is in use)
     uint64_t sha_words;
@@ -55,6 +58,47 @@ inline blsw_layout_t staging_layout(const blsw_layout_t& L, const Modes& m) {
     }
     return S;
 }
+// Staging coordinates of the N+1-pair product in the grouped engine (K = L.n_pairs > 1): a PAIR lane stages the rows of its (pk, msg)
+// pair — msg bits, key allocation, pk != 0, map0, map1, add, cofactor, prepare(H), prepare(pk) — in that order in its column of the
+// pair tiles; an INSTANCE lane stages sig allocation and prepare(sig) in the instance tiles; Miller loop, final exponentiation and
+// is_one are instance-major rows from `split` on. Strides are 0: a pair's copy is found by its lane, not by an offset.
+struct MultiStaging {
+    blsw_layout_t LS;
+    uint32_t rows_p, rows_i, split, pair_rows;
+};
+inline MultiStaging staging_layout_multi(const blsw_layout_t& L) {
+    MultiStaging m;
+    m.LS = L;
+    blsw_layout_t& S = m.LS;
+    uint32_t o = 0;
+    S.off_msg = o;
+    o += L.stride_msg;
+    S.off_pk_alloc = o;
+    o += L.stride_pk_alloc;
+    S.off_pk_not_zero = o;
+    o += L.stride_pk_not_zero;
+    S.off_map0 = o;
+    S.off_map1 = o + (L.off_map1 - L.off_map0);
+    S.off_add = o + (L.off_add - L.off_map0);
+    S.off_cofactor = o + (L.off_cofactor - L.off_map0);
+    o += L.stride_hash - L.sha_bits;
+    S.off_prep_h = o;
+    o += L.stride_prep_h;
+    S.off_prep_pk = o;
+    o += L.stride_prep_pk;
+    m.rows_p = o;
+    S.off_sig_alloc = 0;
+    S.off_prep_sig = L.off_pk_not_zero - L.off_sig_alloc;  // after the sig allocation segment
+    m.rows_i = S.off_prep_sig + (L.off_miller - L.off_prep_sig);
+    m.split = m.rows_p > m.rows_i ? m.rows_p : m.rows_i;
+    S.off_miller = m.split;
+    S.off_final_exp = m.split + (L.off_final_exp - L.off_miller);
+    S.off_is_one = m.split + (L.off_is_one - L.off_miller);
+    m.pair_rows = L.n_witness - L.off_miller;
+    S.off_expand = 0xffffffffu;  // never staged
+    S.stride_msg = S.stride_pk_alloc = S.stride_pk_not_zero = S.stride_hash = S.stride_prep_h = S.stride_prep_pk = 0;
+    return m;
+}
 // N lanes of per-(pk, msg) work, n_sig lanes of per-signature work (n_sig = N except for the N+1-pair product)
 inline Workspace carve(void* base, uint64_t N, const blsw_layout_t& L, bool with_staging, const Modes& m, uint64_t n_sig = 0) {
     Workspace w;
@@ -76,9 +120,23 @@ inline Workspace carve(void* base, uint64_t N, const blsw_layout_t& L, bool with
     w.n_sig = n_sig;
     w.keyproj = L.n_keys ? reinterpret_cast<Fp*>(take(3ull * N * L.n_keys * sizeof(Fp))) : nullptr;
     w.staging_rows = L.n_witness - L.sha_bits;
+    if (L.n_pairs > 1 && with_staging) {  // N+1-pair product in the grouped engine: pair tiles, instance tiles, instance-major rows
+        const MultiStaging ms = staging_layout_multi(L);
+        w.rows_p = ms.rows_p;
+        w.rows_i = ms.rows_i;
+        w.split_row = ms.split;
+        w.pair_rows = ms.pair_rows;
+        w.staging = reinterpret_cast<Fp*>(take((uint64_t)w.rows_p * align_up(N, 64) * sizeof(Fp)));
+        w.staging_inst = reinterpret_cast<Fp*>(take((uint64_t)w.rows_i * align_up(n_sig, 64) * sizeof(Fp)));
+        w.pair = reinterpret_cast<Fp*>(take((uint64_t)w.pair_rows * n_sig * sizeof(Fp)));
+        w.total_bytes = off;
+        return w;
+    }
     w.split_row = m.pairing_team ? staging_layout(L, m).off_miller : (uint32_t)w.staging_rows;
     w.pair_rows = (uint32_t)w.staging_rows - w.split_row;
+    w.rows_p = w.rows_i = w.split_row;
     w.staging = with_staging ? reinterpret_cast<Fp*>(take((uint64_t)w.split_row * align_up(N, 64) * sizeof(Fp))) : nullptr;
+    w.staging_inst = w.staging;
     w.pair = with_staging && w.pair_rows ? reinterpret_cast<Fp*>(take((uint64_t)w.pair_rows * N * sizeof(Fp))) : nullptr;
     w.total_bytes = off;
     return w;
@@ -168,16 +226,19 @@ __device__ __forceinline__ LaneId lane_id(const Group& g, uint64_t I) {
     return r;
 }
 // witness cursor for a segment: staging row (engine mode), the instance's dense vector (direct mode), or value-only
-__device__ __forceinline__ Emitter emitter(const Group& g, const LaneId& id, uint32_t off_full, uint32_t off_staging) {
+// per_pair: the segment belongs to a (pk, msg) pair (the lane is a pair lane) — else to the instance / signature
+__device__ __forceinline__ Emitter emitter(const Group& g, const LaneId& id, uint32_t off_full, uint32_t off_staging, bool per_pair) {
     Emitter e;
     if (g.ws.staging) {
-        if (off_staging >= g.ws.split_row) {  // instance-major rows of the pairing segments
+        if (!per_pair && off_staging >= g.ws.split_row) {  // instance-major rows of the pairing segments
             e.base = reinterpret_cast<uint32_t*>(g.ws.pair + id.I * g.ws.pair_rows);
             e.pos = off_staging - g.ws.split_row;
             e.stride = 12;
             return e;
         }
-        e.base = reinterpret_cast<uint32_t*>(g.ws.staging + (id.I >> 6) * (uint64_t)g.ws.split_row * 64 + (id.I & 63));
+        Fp* tiles = per_pair ? g.ws.staging : g.ws.staging_inst;
+        const uint32_t rows = per_pair ? g.ws.rows_p : g.ws.rows_i;
+        e.base = reinterpret_cast<uint32_t*>(tiles + (id.I >> 6) * (uint64_t)rows * 64 + (id.I & 63));
         e.pos = off_staging;
         e.stride = 64 * 12;
         return e;
@@ -188,9 +249,10 @@ __device__ __forceinline__ Emitter emitter(const Group& g, const LaneId& id, uin
     e.stride = 12;
     return e;
 }
-#define EMIT(g, id, field) emitter(g, id, (g).L.field, (g).LS.field)
-// segment that exists once per pair: pair j's copy starts j * stride further (staged groups always have K = 1)
-#define EMITJ(g, id, field, stride) emitter(g, id, (g).L.field + (id).j * (g).L.stride, (g).LS.field + (id).j * (g).L.stride)
+#define EMIT(g, id, field) emitter(g, id, (g).L.field, (g).LS.field, false)
+// segment that exists once per pair: in the vector pair j's copy starts j * stride further; in the staging a pair is a lane of its own
+// (LS.stride = 0) unless the staging IS the vector (direct mode: LS = L)
+#define EMITJ(g, id, field, stride) emitter(g, id, (g).L.field + (id).j * (g).L.stride, (g).LS.field + (id).j * (g).LS.stride, true)
 
 __device__ __forceinline__ Proj<OpsFp2> ld_proj2(const Fp* p, uint64_t n) {
     Proj<OpsFp2> r;
@@ -299,6 +361,16 @@ inline uint64_t miller_par_bytes(uint64_t n, uint32_t K, uint32_t B) {
     return (2 * n * 68 * C + 2 * n * 68 + n) * 12 * sizeof(Fp) + 5 * 256;
 }
 void launch_miller_par(const Group& gs, const MillerParArgs& a, hipStream_t st, hipStream_t side, hipEvent_t ev_spine, hipEvent_t ev_side);
+// Placement of the N+1-pair product's staged rows (k_stream.hip): up to six runs of consecutive staging rows of a lane, each going to
+// dst_off + j * dst_stride of the lane's instance vector (j = pair index of the lane; 0 for instance lanes)
+struct PlaceRuns {
+    uint32_t n_runs;
+    uint32_t src_row[7];  // first staging row of run r; src_row[n_runs] = rows of the tile
+    uint32_t dst_off[6], dst_stride[6];
+};
+__global__ void k_place_runs(const Fp* __restrict__ tiles, uint64_t first, uint32_t rows, PlaceRuns runs, uint64_t* __restrict__ d_witness, uint64_t stride, uint32_t n_y,
+                             uint32_t K);
+__global__ void k_place_rows(const Fp* __restrict__ rows, uint32_t n_rows, uint32_t dst_off, uint64_t* __restrict__ d_witness, uint64_t stride);
 // the two compilations of the chain units as one table
 struct ChainKernels {
     void (*sha)(Group, int, int);

@@ -126,6 +126,9 @@ typedef struct {
                               engine (they leave registers to the streaming kernels that share their SIMDs), inlined in direct mode
                               (max_steps == 1 and n_buffers == 1: shorter under load, the whole register file); 1 = out of line;
                               2 = inlined. Same witnesses either way. */
+    uint32_t n_pairs;      /* 0 / 1 = the single-key circuit; K > 1 = the N+1-pair product (blsw_layout_multi): one signature over K (pk, msg)
+                              pairs per instance, batches through blsw_engine_submit_multi. Staged engines only (max_steps > 1 or
+                              n_buffers > 1), default kernel modes, Montgomery output form, n * K <= 65535; no compact wire form yet */
 } blsw_engine_options_t;
 /* the defaults (pure: the library reads no environment variable; measurement scripts set the fields they want to vary) */
 int blsw_engine_options_default(blsw_engine_options_t* out);
@@ -175,6 +178,13 @@ int blsw_engine_submit_bytes(blsw_engine_t* e, const uint8_t* d_pk48, const uint
  *   d_witness [n][witness_stride] (stride >= blsw_layout_aggregate().n_witness; may be NULL), d_result [n] int32, d_count [n] uint32 (may be NULL) */
 int blsw_engine_submit_aggregate(blsw_engine_t* e, const uint64_t* d_pks_xy, const uint8_t* d_bitmap, const uint64_t* d_sig_xy, const uint8_t* d_msg,
                                  uint64_t* d_witness, uint64_t witness_stride, int32_t* d_result, uint32_t* d_count, void* stream);
+/* The N+1-pair product (blsw_verify_multi_batch's circuit) through the engine, for an engine created with options.n_pairs = K: one
+ * batch of n instances, same grouping / staging / streaming placement / consumer mode as blsw_engine_submit — more instances are in
+ * flight than output tensors exist (a vector is 4.19 GB at K = 128), which the direct call cannot do.
+ *   d_pks_xy [n][K][12] u64, d_msgs [n][K][msg_len] bytes, d_sig_xy [n][24]
+ *   d_witness [n][witness_stride] (stride >= blsw_layout_multi().n_witness; may be NULL), d_result [n] int32 */
+int blsw_engine_submit_multi(blsw_engine_t* e, const uint64_t* d_pks_xy, const uint8_t* d_msgs, const uint64_t* d_sig_xy, uint64_t* d_witness,
+                             uint64_t witness_stride, int32_t* d_result, void* stream);
 /* Issues everything pending and makes `stream` wait for all batches submitted so far (asynchronous for the host). In consumer
  * mode: for all steps written so far (blsw_engine_materialised); the rest follow as their outputs are released. */
 int blsw_engine_flush(blsw_engine_t* e, void* stream);

@@ -800,6 +800,65 @@ def test_verify_multi_pair_parallel_batch(pkg, oracle):
         assert len(bad) == 0, "instance %d: first mismatching witness index %d" % (i, bad[0])
 
 
+@pytest.mark.parametrize("K,n,consumer", [(3, 2, 0), (20, 3, 0), (20, 2, 1)])
+def test_engine_multi_grouped(pkg, oracle, K, n, consumer):
+    """The N+1-pair product through the GROUPED engine (options.n_pairs = K; blsw_engine_submit_multi): pair tiles, instance tiles and
+    instance-major rows staged per group, expansion of K SHA segments per instance and placement per step. Five steps of n instances
+    fused two per group (2 + 2 + 1; pair lanes of a step start inside a 64-lane tile), valid and tampered instances, K = 3 (the
+    serial team Miller chain) and K = 20 (the pair-parallel one); free running with one tensor per step, and consumer mode through a
+    ring of two tensors. Every witness element of every instance against the oracle."""
+    import torch
+
+    steps = 5
+    dev = torch.device("cuda:0")
+    cases = [synth.make_multi(oracle, K, tamper=(a % K if a % 3 == 1 else None), start=5 * a) for a in range(steps * n)]
+    eng = pkg.WitnessEngine(n, 32, max_steps=2, device=dev, n_buffers=2, n_pairs=K, consumer_mode=consumer)
+    assert eng.n_witness == pkg.layout_multi(32, K)["n_witness"]
+    ring = 2 if consumer else steps
+    outs = [eng.new_witness_tensor() for _ in range(ring)]
+    ress = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(steps)]
+    got_w, keep = {}, []
+    state = {"next": 0}
+
+    def drain():
+        while state["next"] < eng.materialised():
+            s = state["next"]
+            eng.wait_step(s)
+            torch.cuda.synchronize()
+            got_w[s] = outs[s % ring].cpu().numpy().view(np.uint64).copy()
+            eng.output_consumed(outs[s % ring])
+            state["next"] += 1
+
+    for k in range(steps):
+        sl = cases[k * n:(k + 1) * n]
+        d = (torch.from_numpy(np.stack([c[0] for c in sl]).view(np.int64)).to(dev), torch.from_numpy(np.stack([c[1] for c in sl])).to(dev),
+             torch.from_numpy(np.stack([c[2] for c in sl]).view(np.int64)).to(dev))
+        keep.append(d)
+        while True:
+            try:
+                eng.submit_multi(d[0], d[1], d[2], witness=outs[k % ring], result=ress[k])
+                break
+            except pkg.BlswBusy:
+                drain()
+        if consumer:
+            drain()
+    eng.flush()
+    if consumer:
+        while state["next"] < steps:
+            drain()
+    torch.cuda.synchronize()
+    for k in range(steps):
+        w = got_w[k] if consumer else outs[k].cpu().numpy().view(np.uint64)
+        got = ress[k].cpu().numpy().astype(bool)
+        for i in range(n):
+            c = cases[k * n + i]
+            nw, res, _, ow = oracle.witness_multi(c[0], c[1], c[2])
+            assert nw == w.shape[1] and res == c[3] == bool(got[i]), (k, i)
+            bad = np.nonzero((ow != w[i]).any(axis=1))[0]
+            assert len(bad) == 0, "step %d instance %d: first mismatching witness index %d" % (k, i, bad[0])
+    eng.close()
+
+
 def test_verify_multi_128_pairs(pkg, oracle):
     """BASELINE configs[3]: ONE signature over 128 (pk, msg) pairs, a 129-pair Miller product — all 87 295 138 witness
     elements (4.2 GB) against the oracle, plus the tampered variant's result."""

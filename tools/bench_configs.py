@@ -24,6 +24,9 @@ def main():
     ap.add_argument("--agg-steps", type=int, default=9)
     ap.add_argument("--agg-coalesce", type=int, default=3)
     ap.add_argument("--multi-pairs", type=int, default=128)
+    ap.add_argument("--multi-engine-n", type=int, default=16, help="instances per step of the grouped-engine configs[3] run (ring of two output tensors of n x 4.19 GB)")
+    ap.add_argument("--multi-engine-steps", type=int, default=24)
+    ap.add_argument("--multi-engine-coalesce", type=int, default=4)
     ap.add_argument("--multi-n", type=int, default=48)  # 48 x 4.19 GB of witnesses per call (the rest of HBM stays free for the runtime's per-queue scratch)
     args = ap.parse_args()
     import torch
@@ -151,6 +154,27 @@ def main():
         print(json.dumps({"workload": "configs[3]: one signature over %d (pk, msg) pairs, %d-pair Miller product (blsw_verify_multi_batch)" % (Kp, Kp + 1), "instances": nm,
                           "pairs": Kp * nm, "witness_written": want, "n_witness": pkg.layout_multi(32, Kp)["n_witness"], "seconds": dt, "value": nm / dt, "unit": "instances/s",
                           "pairs_per_s": Kp * nm / dt}))
+
+    torch.cuda.empty_cache()
+    # the same circuit through the grouped engine (options.n_pairs): groups of `coalesce` steps of n instances, three groups in flight,
+    # ring of two output tensors, free running (every step writes its n x 4.19 GB) — more instances in flight than output tensors
+    ne, st, co = args.multi_engine_n, args.multi_engine_steps, args.multi_engine_coalesce
+    eng = pkg.WitnessEngine(ne, 32, max_steps=co, device=dev, n_buffers=3, n_pairs=Kp)
+    outs = [eng.new_witness_tensor() for _ in range(2)]
+    ress = [torch.empty(ne, dtype=torch.int32, device=dev) for _ in range(2)]
+    epks, emsg, esig = mpks[:ne].contiguous(), mmsg[:ne].contiguous(), msig[:ne].contiguous()
+
+    def run_multi(k_steps):
+        for k in range(k_steps):
+            eng.submit_multi(epks, emsg, esig, witness=outs[k % 2], result=ress[k % 2])
+        eng.flush()
+
+    run_multi(co)
+    dt, _ = timed(lambda: run_multi(st))
+    print(json.dumps({"workload": "configs[3] through the grouped engine: one signature over %d pairs, %d instances per step, %d steps per group, 3 groups in flight, ring of 2 tensors, free running" % (Kp, ne, co),
+                      "instances": ne * st, "pairs": Kp * ne * st, "witness_written": True, "seconds": dt, "value": ne * st / dt, "unit": "instances/s", "pairs_per_s": Kp * ne * st / dt,
+                      "output_GBps": ne * st * eng.n_witness * 48 / dt / 1e9}))
+    eng.close()
 
 
 if __name__ == "__main__":
