@@ -155,6 +155,7 @@ def main():
                           "pairs": Kp * nm, "witness_written": want, "n_witness": pkg.layout_multi(32, Kp)["n_witness"], "seconds": dt, "value": nm / dt, "unit": "instances/s",
                           "pairs_per_s": Kp * nm / dt}))
 
+    del res, _  # the direct call's 201 GB witness tensor
     torch.cuda.empty_cache()
     # the same circuit through the grouped engine (options.n_pairs): groups of `coalesce` steps of n instances, three groups in flight,
     # ring of two output tensors, free running (every step writes its n x 4.19 GB) — more instances in flight than output tensors
@@ -162,7 +163,9 @@ def main():
     eng = pkg.WitnessEngine(ne, 32, max_steps=co, device=dev, n_buffers=3, n_pairs=Kp)
     outs = [eng.new_witness_tensor() for _ in range(2)]
     ress = [torch.empty(ne, dtype=torch.int32, device=dev) for _ in range(2)]
-    epks, emsg, esig = mpks[:ne].contiguous(), mmsg[:ne].contiguous(), msig[:ne].contiguous()
+    epks = mr["pk_xy"].unsqueeze(0).repeat(ne, 1, 1).contiguous()
+    emsg = torch.from_numpy(mm).to(dev).unsqueeze(0).repeat(ne, 1, 1).contiguous()
+    esig = mr["sig_xy"][0:1].repeat(ne, 1).contiguous()
 
     def run_multi(k_steps):
         for k in range(k_steps):
