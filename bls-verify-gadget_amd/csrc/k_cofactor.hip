@@ -7,6 +7,7 @@
 #define BLSW_INLINE_CHAINS 1
 #endif
 #include "kcommon.cuh"
+#include "cofactor_par.cuh"
 #if !defined(BLSW_KVARIANT_INL) && defined(BLSW_W2_COFACTOR)
 #define BLSW_CHAIN_ATTR BLSW_ATTR_W2
 #else
@@ -23,6 +24,36 @@ __global__ __launch_bounds__(64) BLSW_CHAIN_ATTR void BLSW_K(k_cofactor)(Group g
     const uint64_t N = g.N;
     Proj<OpsFp2> q0 = ld_proj2(g.ws.q + I, N), q1 = ld_proj2(g.ws.q + 6 * N + I, N);
     Proj<OpsFp2> h = chain_cofactor(EMITJ(g, id, off_add, stride_hash), EMITJ(g, id, off_cofactor, stride_hash), q0, q1);
+    Fp* o = g.ws.h + I;
+    st_fp(o, h.x.c0);
+    st_fp(o + N, h.x.c1);
+    st_fp(o + 2 * N, h.y.c0);
+    st_fp(o + 3 * N, h.y.c1);
+    st_fp(o + 4 * N, h.z.c0);
+    st_fp(o + 5 * N, h.z.c1);
+}
+
+// The same segment with the three 255-bit chunks of the scalar on three lanes (cofactor_par.cuh): lanes [0, N) run chunk 0 (and emit
+// Q0 + Q1 and the to_affine of the sum), [N, 2N) chunk 1, [2N, 3N) chunk 2 — waves are chunk-homogeneous, so a wave still appends
+// whole 3 KiB rows to its tile; what the chunks leave for the join is parked in the line-coefficient rows of prepare_g2(H(m)),
+// which that kernel writes afterwards.
+__global__ __launch_bounds__(64) BLSW_CHAIN_ATTR void BLSW_K(k_cofactor_chunk)(Group g) {
+    if (g.chain_prio) __builtin_amdgcn_s_setprio(3);
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, N = g.N;
+    if (t >= 3 * N) return;
+    const int c = t >= 2 * N ? 2 : (t >= N ? 1 : 0);
+    const uint64_t I = t - (uint64_t)c * N;
+    LaneId id = lane_id(g, I);
+    Proj<OpsFp2> q0 = ld_proj2(g.ws.q + I, N), q1 = ld_proj2(g.ws.q + 6 * N + I, N);
+    chain_cofactor_chunk(EMITJ(g, id, off_add, stride_hash), EMITJ(g, id, off_cofactor, stride_hash), q0, q1, c, CoeffStrided{g.ws.coeff_h + I, N});
+}
+__global__ __launch_bounds__(64) BLSW_CHAIN_ATTR void BLSW_K(k_cofactor_join)(Group g) {
+    if (g.chain_prio) __builtin_amdgcn_s_setprio(3);
+    uint64_t I = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (I >= g.N) return;
+    LaneId id = lane_id(g, I);
+    const uint64_t N = g.N;
+    Proj<OpsFp2> h = chain_cofactor_join(EMITJ(g, id, off_cofactor, stride_hash), CoeffStrided{g.ws.coeff_h + I, N});
     Fp* o = g.ws.h + I;
     st_fp(o, h.x.c0);
     st_fp(o + N, h.x.c1);

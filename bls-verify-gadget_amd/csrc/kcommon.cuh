@@ -329,6 +329,10 @@ __global__ void k_map(Group g);
 __global__ void k_map_inl(Group g);
 __global__ void k_cofactor(Group g);
 __global__ void k_cofactor_inl(Group g);
+__global__ void k_cofactor_chunk(Group g);
+__global__ void k_cofactor_chunk_inl(Group g);
+__global__ void k_cofactor_join(Group g);
+__global__ void k_cofactor_join_inl(Group g);
 __global__ void k_map_values(Group g);
 __global__ void k_cofactor_values(Group g);
 __global__ void k_prepare(Group g, int which);
@@ -381,10 +385,22 @@ struct ChainKernels {
     void (*map)(Group);
     void (*cofactor)(Group);
     void (*prepare)(Group, int);
+    void (*cofactor_chunk)(Group);  // the cofactor segment with its three chunks on three lanes, and the join (cofactor_par.cuh)
+    void (*cofactor_join)(Group);
 };
+// clear_cofactor2 of N lanes on `st`: chunked (three lanes per (pk, msg) pair + the join) or as one chain per lane
+inline void launch_cofactor(const ChainKernels& ck, bool chunked, const Group& g, hipStream_t st) {
+    const unsigned g1 = (unsigned)((g.N + 63) / 64), g3 = (unsigned)((3 * g.N + 63) / 64);
+    if (chunked) {
+        hipLaunchKernelGGL(ck.cofactor_chunk, dim3(g3), dim3(64), 0, st, g);
+        hipLaunchKernelGGL(ck.cofactor_join, dim3(g1), dim3(64), 0, st, g);
+    } else {
+        hipLaunchKernelGGL(ck.cofactor, dim3(g1), dim3(64), 0, st, g);
+    }
+}
 inline ChainKernels chain_kernels(bool inlined) {
-    if (inlined) return {k_sha_inl, k_g1_inl, k_agg_keys_inl, k_agg_sum_inl, k_g2_alloc_inl, k_map_inl, k_cofactor_inl, k_prepare_inl};
-    return {k_sha, k_g1, k_agg_keys, k_agg_sum, k_g2_alloc, k_map, k_cofactor, k_prepare};
+    if (inlined) return {k_sha_inl, k_g1_inl, k_agg_keys_inl, k_agg_sum_inl, k_g2_alloc_inl, k_map_inl, k_cofactor_inl, k_prepare_inl, k_cofactor_chunk_inl, k_cofactor_join_inl};
+    return {k_sha, k_g1, k_agg_keys, k_agg_sum, k_g2_alloc, k_map, k_cofactor, k_prepare, k_cofactor_chunk, k_cofactor_join};
 }
 // host-side launch helpers that live next to their (templated) kernels
 void launch_expand(uint32_t variant, uint32_t store, unsigned lds, hipStream_t st, ExpandArgs a, unsigned n_y);

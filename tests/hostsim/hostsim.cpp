@@ -10,6 +10,7 @@
 #include "../../bls-verify-gadget_amd/csrc/team.cuh"
 #include "../../bls-verify-gadget_amd/csrc/vsign.cuh"
 #include "../../bls-verify-gadget_amd/csrc/miller_par.cuh"
+#include "../../bls-verify-gadget_amd/csrc/cofactor_par.cuh"
 #include <array>
 
 using namespace blsw;
@@ -101,6 +102,7 @@ struct TeamHost {
     }
 };
 static int g_use_team = 0;
+static int g_cofactor_par = 0;  // 1: clear_cofactor2 through cofactor_par.cuh (chunks in the order 2, 0, 1, then the join)
 static uint32_t g_miller_chunk = 2;  // pairs per chunk of the pair-parallel Miller product (mode 2)
 // G2 allocation with the scalar multiplication of the subgroup check on the team program (lanes 0..2 own x, y, z)
 static void g2_alloc_segment(uint32_t* base, const blsw_layout_t& L, const Fp2& sx, const Fp2& sy) {
@@ -146,8 +148,16 @@ struct ParkHost {
     void st(int slot, const Jac2& v) const { p[slot] = v; }
     Jac2 ld(int slot) const { return p[slot]; }
 };
+static Proj<OpsFp2> run_cofactor(Emitter e_add, Emitter e, const Proj<OpsFp2>& q0, const Proj<OpsFp2>& q1) {
+    if (!g_cofactor_par) return chain_cofactor(e_add, e, q0, q1);
+    Fp rows[BLSW_COFACTOR_ROWS];
+    const int order[3] = {2, 0, 1};  // the chunks do not depend on each other
+    for (int k = 0; k < 3; k++) chain_cofactor_chunk(e_add, e, q0, q1, order[k], CoeffLinear{rows});
+    return chain_cofactor_join(e, CoeffLinear{rows});
+}
 extern "C" {
 void hostsim_use_team(int on) { g_use_team = on; }
+void hostsim_cofactor_par(int on) { g_cofactor_par = on; }
 void hostsim_miller_chunk(uint32_t b) { g_miller_chunk = b ? b : 1; }
 int hostsim_layout(uint32_t msg_len, blsw_layout_t* L) {
     make_layout(msg_len, L);
@@ -180,7 +190,7 @@ int hostsim_witness(const uint64_t* pk_xy, const uint8_t* msg, uint32_t msg_len,
     Fp2 u1 = {hash_to_field_elem(uw + 32), hash_to_field_elem(uw + 48)};
     Proj<OpsFp2> q0 = chain_map_to_curve({base, L.off_map0}, u0);
     Proj<OpsFp2> q1 = chain_map_to_curve({base, L.off_map1}, u1);
-    Proj<OpsFp2> h = chain_cofactor({base, L.off_add}, {base, L.off_cofactor}, q0, q1);
+    Proj<OpsFp2> h = run_cofactor({base, L.off_add}, {base, L.off_cofactor}, q0, q1);
     std::vector<Fp> ch(68 * 4), cs(68 * 4);
     chain_prepare_g2({base, L.off_prep_h}, h, CoeffLinear{ch.data()});
     bool sinf = fp2_is_zero(sx) && fp2_is_zero(sy);
@@ -228,7 +238,7 @@ int hostsim_witness_multi(const uint64_t* pks_xy, const uint8_t* msgs, uint32_t 
         Fp2 u1 = {hash_to_field_elem(uw + 32), hash_to_field_elem(uw + 48)};
         Proj<OpsFp2> q0 = chain_map_to_curve({base, L.off_map0 + ho}, u0);
         Proj<OpsFp2> q1 = chain_map_to_curve({base, L.off_map1 + ho}, u1);
-        Proj<OpsFp2> h = chain_cofactor({base, L.off_add + ho}, {base, L.off_cofactor + ho}, q0, q1);
+        Proj<OpsFp2> h = run_cofactor({base, L.off_add + ho}, {base, L.off_cofactor + ho}, q0, q1);
         chain_prepare_g2({base, L.off_prep_h + j * L.stride_prep_h}, h, CoeffLinear{ch[j].data()});
     }
     Fp2 sx = {load_fp(sig_xy), load_fp(sig_xy + 6)}, sy = {load_fp(sig_xy + 12), load_fp(sig_xy + 18)};
@@ -304,7 +314,7 @@ int hostsim_witness_aggregate(const uint64_t* pks_xy, const uint8_t* bitmap, uin
     Fp2 u1 = {hash_to_field_elem(uw + 32), hash_to_field_elem(uw + 48)};
     Proj<OpsFp2> q0 = chain_map_to_curve({base, L.off_map0}, u0);
     Proj<OpsFp2> q1 = chain_map_to_curve({base, L.off_map1}, u1);
-    Proj<OpsFp2> hh = chain_cofactor({base, L.off_add}, {base, L.off_cofactor}, q0, q1);
+    Proj<OpsFp2> hh = run_cofactor({base, L.off_add}, {base, L.off_cofactor}, q0, q1);
     std::vector<Fp> ch(68 * 4), cs(68 * 4);
     chain_prepare_g2({base, L.off_prep_h}, hh, CoeffLinear{ch.data()});
     bool sinf = fp2_is_zero(sx) && fp2_is_zero(sy);
@@ -397,6 +407,24 @@ void hostsim_hash_to_g2_values(const uint8_t* msg, uint32_t msg_len, uint64_t* o
     memcpy(out_xy + 6, x.c1.l, 48);
     memcpy(out_xy + 12, y.c0.l, 48);
     memcpy(out_xy + 18, y.c1.l, 48);
+}
+// clear_cofactor2 of a given pair (Q0, Q1) of affine points (z = 1; all zero = the identity (0, 0, 0)): the serial chain and the
+// chunked one write their "add" + "cofactor" segments (36 + 8979 elements each) and results; returns 1 if everything is equal
+int hostsim_cofactor_compare(const uint64_t* q0_xy, const uint64_t* q1_xy, uint64_t* out_serial, uint64_t* out_chunked) {
+    auto load = [](const uint64_t* p) {
+        Proj<OpsFp2> q = {{load_fp(p), load_fp(p + 6)}, {load_fp(p + 12), load_fp(p + 18)}, fp2_one()};
+        if (fp2_is_zero(q.x) && fp2_is_zero(q.y)) q.z = fp2_zero();
+        return q;
+    };
+    Proj<OpsFp2> q0 = load(q0_xy), q1 = load(q1_xy);
+    Proj<OpsFp2> a = chain_cofactor({reinterpret_cast<uint32_t*>(out_serial), 0}, {reinterpret_cast<uint32_t*>(out_serial), SEG_ADD}, q0, q1);
+    Fp rows[BLSW_COFACTOR_ROWS];
+    Emitter e_add = {reinterpret_cast<uint32_t*>(out_chunked), 0}, e = {reinterpret_cast<uint32_t*>(out_chunked), SEG_ADD};
+    const int order[3] = {1, 2, 0};
+    for (int k = 0; k < 3; k++) chain_cofactor_chunk(e_add, e, q0, q1, order[k], CoeffLinear{rows});
+    Proj<OpsFp2> b = chain_cofactor_join(e, CoeffLinear{rows});
+    bool same = fp_eq(a.x.c0, b.x.c0) && fp_eq(a.x.c1, b.x.c1) && fp_eq(a.y.c0, b.y.c0) && fp_eq(a.y.c1, b.y.c1) && fp_eq(a.z.c0, b.z.c0) && fp_eq(a.z.c1, b.z.c1);
+    return same && memcmp(out_serial, out_chunked, (size_t)(SEG_ADD + SEG_COFACTOR) * 48) == 0;
 }
 // field micro-checks
 void hostsim_fp_mul(const uint64_t* a, const uint64_t* b, uint64_t* r) {
