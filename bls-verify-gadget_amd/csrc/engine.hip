@@ -62,6 +62,10 @@ inline int stream_device(hipStream_t st) {
 #define BLSW_MAX_BUFFERS 32
 #define BLSW_MILLER_CHUNK_DEFAULT 12   // pairs per lane of the pair-parallel Miller product (blsw_verify_multi_batch)
 #define BLSW_MILLER_PAR_MIN_PAIRS 8  // below: the serial six-lane team kernel
+// clear_cofactor2 on three lanes per pair halves the chain's latency and costs 38 % more products in it: it pays while the launch is
+// latency-bound (an 8 192-instance shard in groups of 4: +16 %; one 128-pair instance: 88 -> 60 ms) and costs 1-4 % once the group's
+// chains fill the SIMDs (groups of 10 x 1024: profiles/r03_ab_chain_builds.txt section 6)
+#define BLSW_COFACTOR_CHUNKED_MAX_LANES 8192
 #define BLSW_DEFAULT_EXPAND_VARIANT 0  // 384 x 8: the geometry that stays fast beside every chain build (profiles/r02_ab_fpmul_expand.txt)
 #define BLSW_MAX_TIMED 1024
 #define BLSW_MAX_CONSUMED 64
@@ -108,7 +112,7 @@ struct blsw_engine {
     bool held[BLSW_MAX_CONSUMED];           // consumer mode: a step was materialised into this output and it has not been released
     bool staged = false;  // false: direct mode (max_steps == 1, no staging; witnesses written in place by the chains)
     bool chains_inlined = false;  // which compilation of the chain kernels (options.chain_variant; kcommon.cuh: BLSW_K)
-    bool cofactor_chunked = true;  // clear_cofactor2 with its three chunks on three lanes (options.cofactor_mode)
+    uint32_t cofactor_mode = 0;  // clear_cofactor2 with its three chunks on three lanes: 0 by group size, 1 never, 2 always (options.cofactor_mode)
 };
 
 static void engine_free(blsw_engine* e) {
@@ -327,7 +331,7 @@ static int launch_group(blsw_engine* e) {
         const unsigned s1 = (unsigned)((gs.N + 63) / 64);
         hipLaunchKernelGGL(k_sha_values, dim3(g1), dim3(64), 0, st, g);
         hipLaunchKernelGGL(ck.map, dim3(g2), dim3(64), 0, st, g);
-        launch_cofactor(ck, e->cofactor_chunked, g, st);
+        launch_cofactor(ck, e->cofactor_mode == 2 || (e->cofactor_mode == 0 && g.N <= BLSW_COFACTOR_CHUNKED_MAX_LANES), g, st);
         hipLaunchKernelGGL(ck.prepare, dim3(g1), dim3(64), 0, st, g, 0);
         hipLaunchKernelGGL(ck.g2_alloc, dim3(s1), dim3(64), 0, b.st[1], gs);
         hipLaunchKernelGGL(ck.prepare, dim3(s1), dim3(64), 0, b.st[1], gs, 1);
@@ -361,7 +365,7 @@ static int launch_group(blsw_engine* e) {
     if (!(dbg_skip & 1)) {
     hipLaunchKernelGGL(k_sha_values, dim3(g1), dim3(64), 0, st, g);
     hipLaunchKernelGGL(ck.map, dim3(g2), dim3(64), 0, st, g);
-    launch_cofactor(ck, e->cofactor_chunked, g, st);
+    launch_cofactor(ck, e->cofactor_mode == 2 || (e->cofactor_mode == 0 && g.N <= BLSW_COFACTOR_CHUNKED_MAX_LANES), g, st);
     hipLaunchKernelGGL(ck.prepare, dim3(g1), dim3(64), 0, st, g, 0);
     // aux: prepare_g2(sig) and the group allocations (53 ms alone beside the 86 ms of the main stream's first part)
     hipLaunchKernelGGL(ck.prepare, dim3(g1), dim3(64), 0, b.st[1], g, 1);
@@ -459,7 +463,7 @@ int blsw_engine_create_ex(blsw_engine_t** out, uint64_t n, uint32_t msg_len, uin
     // place while the chains run and could not honour a held output
     if (options->consumer_mode > 1 || (options->consumer_mode == 1 && max_steps == 1 && n_buffers == 1)) return BLSW_ERR_ARG;
     if (options->pairing_mode > 1 || options->g2_mode > 1 || (options->g2_mode == 1 && options->pairing_mode != 0) || options->expand_store > 3 ||
-        options->prio_mode > 2 || options->output_form > 1 || options->chain_variant > 2 || options->cofactor_mode > 1 || (options->expand_variant & 0xff) > 5 || (options->expand_variant >> 9) || options->n_keys > 65535 ||
+        options->prio_mode > 2 || options->output_form > 1 || options->chain_variant > 2 || options->cofactor_mode > 2 || (options->expand_variant & 0xff) > 5 || (options->expand_variant >> 9) || options->n_keys > 65535 ||
         (options->n_keys && options->g2_mode) || options->n_pairs > 4096)
         return BLSW_ERR_ARG;
     // N+1-pair product (options.n_pairs = K > 1): a staged engine with the default kernel modes; its expansion launch has one row of
@@ -501,7 +505,7 @@ int blsw_engine_create_ex(blsw_engine_t** out, uint64_t n, uint32_t msg_len, uin
     e->device = dev;
     e->modes = {options->pairing_mode == 0, options->g2_mode == 1};
     e->staged = max_steps > 1 || n_buffers > 1;
-    e->cofactor_chunked = options->cofactor_mode == 0;
+    e->cofactor_mode = options->cofactor_mode;
     e->chains_inlined = options->chain_variant == 2 || (options->chain_variant == 0 && !e->staged);
     make_layout(msg_len, &e->L, options->n_keys, options->n_pairs > 1 ? options->n_pairs : 1);
     e->LS = e->L.n_pairs > 1 ? staging_layout_multi(e->L).LS : staging_layout(e->L, e->modes);
@@ -877,7 +881,7 @@ int blsw_aggregate_verify_batch(const uint64_t* d_pks_xy, const uint8_t* d_bitma
         launch_expand(BLSW_DEFAULT_EXPAND_VARIANT, 0, 0, st, xa, (unsigned)n);
     }
     hipLaunchKernelGGL(ck.map, dim3(g2), dim3(64), 0, st, g);
-    launch_cofactor(ck, true, g, st);
+    launch_cofactor(ck, g.N <= BLSW_COFACTOR_CHUNKED_MAX_LANES, g, st);
     hipLaunchKernelGGL(ck.prepare, dim3(g1), dim3(64), 0, st, g, 0);
     launch_pairing(g, DEFAULT_MODES, st);
     return hip_ok(hipGetLastError(), "launch");
@@ -964,7 +968,7 @@ int blsw_verify_multi_batch(const uint64_t* d_pks_xy, const uint8_t* d_msgs, uin
     }
     hipLaunchKernelGGL(k_sha_values, dim3(p1), dim3(64), 0, st, gp);
     hipLaunchKernelGGL(ck.map, dim3(p2), dim3(64), 0, st, gp);
-    launch_cofactor(ck, true, gp, st);
+    launch_cofactor(ck, gp.N <= BLSW_COFACTOR_CHUNKED_MAX_LANES, gp, st);
     hipLaunchKernelGGL(ck.prepare, dim3(p1), dim3(64), 0, st, gp, 0);
     if (forked) {
         hipEventRecord(ev_join[0], s_sig);

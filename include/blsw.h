@@ -129,8 +129,9 @@ typedef struct {
     uint32_t n_pairs;      /* 0 / 1 = the single-key circuit; K > 1 = the N+1-pair product (blsw_layout_multi): one signature over K (pk, msg)
                               pairs per instance, batches through blsw_engine_submit_multi. Staged engines only (max_steps > 1 or
                               n_buffers > 1), default kernel modes, Montgomery output form, n * K <= 65535; no compact wire form yet */
-    uint32_t cofactor_mode; /* clear_cofactor2 (the longest chain): 0 (default) = the three 255-bit chunks of the scalar on three lanes and a join
-                              (half the chain's latency for 38 % more products in it), 1 = one chain per lane. Same witnesses either way. */
+    uint32_t cofactor_mode; /* clear_cofactor2 (the longest chain) with the three 255-bit chunks of its scalar on three lanes and a join: half the
+                              chain's latency for 38 % more products in it. 0 (default) = for launch groups of at most 8 192 lanes (latency-bound),
+                              one chain per lane above; 1 = never; 2 = always. Same witnesses either way. */
 } blsw_engine_options_t;
 /* the defaults (pure: the library reads no environment variable; measurement scripts set the fields they want to vary) */
 int blsw_engine_options_default(blsw_engine_options_t* out);

@@ -55,6 +55,34 @@ def test_batch_bit_exact(pkg, oracle):
     _compare(oracle, pk, msg, sig, got, w, range(n))
 
 
+@pytest.mark.parametrize("chain_variant,cofactor_mode", [(1, 1), (2, 1), (1, 2), (2, 2)])
+def test_kernel_variants_bit_exact(pkg, oracle, chain_variant, cofactor_mode):
+    """Every compilation of the chain kernels and both forms of the cofactor chain write the same bytes: out-of-line / inlined
+    (options.chain_variant) x one chain per lane / three chunks + join (options.cofactor_mode), a full wave and a ragged one, through a
+    grouped engine (two steps per group)."""
+    import torch
+
+    n, steps = 35, 2
+    pk, msg, sig, expect = synth.make_batch(oracle, n * steps)
+    dev = torch.device("cuda:0")
+    eng = pkg.WitnessEngine(n, 32, max_steps=2, device=dev, n_buffers=2, chain_variant=chain_variant, cofactor_mode=cofactor_mode)
+    outs, ress, keep = [], [], []
+    for k in range(steps):
+        sl = slice(k * n, (k + 1) * n)
+        d = (torch.from_numpy(pk[sl].view(np.int64)).to(dev), torch.from_numpy(sig[sl].view(np.int64)).to(dev), torch.from_numpy(msg[sl]).to(dev))
+        w, r = eng.new_witness_tensor(), torch.empty(n, dtype=torch.int32, device=dev)
+        eng.submit(d[0], d[1], d[2], witness=w, result=r)
+        outs.append(w), ress.append(r), keep.append(d)
+    eng.flush()
+    torch.cuda.synchronize()
+    for k in range(steps):
+        sl = slice(k * n, (k + 1) * n)
+        got = ress[k].cpu().numpy().astype(bool)
+        assert np.array_equal(got, expect[sl])
+        _compare(oracle, pk[sl], msg[sl], sig[sl], got, outs[k].cpu().numpy().view(np.uint64), range(0, n, 4))
+    eng.close()
+
+
 def test_reference_gadget_case(pkg, oracle):
     # constraints.rs:318-376: [true, false, false]
     g = LIT["gadget_verify"]
