@@ -308,6 +308,10 @@ def main():
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
     dist = None
+    # BLSW_TEST_BACKEND=gloo: rehearsal of world > 1 on a one-GPU box (every rank on device 0, which RCCL refuses); never set by the driver
+    backend = os.environ.get("BLSW_TEST_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if under_launcher:  # launched by torch.distributed.run (also with one rank)
@@ -318,7 +322,10 @@ def main():
         saved = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", device_id=dev)
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group(backend)
             dist.barrier()
             torch.cuda.synchronize()
         finally:

@@ -73,8 +73,8 @@ struct GroupBuf {
     void* base = nullptr;
     StepDesc* h_desc = nullptr;  // pinned host
     StepDesc* d_desc = nullptr;
-    hipStream_t st[2] = {nullptr, nullptr};  // main, aux
-    hipEvent_t ev_start = nullptr, ev_aux = nullptr, ev_sha = nullptr, ev_chains = nullptr, ev_done = nullptr;
+    hipStream_t st[3] = {nullptr, nullptr, nullptr};  // main, aux (G2 allocation), aux2 (prepare(sig), G1 / key chains; BLSW_AUX2 builds)
+    hipEvent_t ev_start = nullptr, ev_aux = nullptr, ev_aux2 = nullptr, ev_sha = nullptr, ev_chains = nullptr, ev_done = nullptr;
     hipEvent_t* ev_in = nullptr;    // [max_steps] inputs of step s valid (recorded on the submitting stream)
     hipEvent_t* ev_x = nullptr;     // [max_steps] expansion of step s issued and finished
     hipEvent_t* ev_step = nullptr;  // [max_steps] step s complete (witness tensor + results)
@@ -121,9 +121,9 @@ static void engine_free(blsw_engine* e) {
         GroupBuf& b = e->buf[k];
         if (b.h_desc) hipHostFree(b.h_desc);
         if (b.d_desc) hipFree(b.d_desc);
-        for (int i = 0; i < 2; i++)
+        for (int i = 0; i < 3; i++)
             if (b.st[i]) hipStreamDestroy(b.st[i]);
-        hipEvent_t single[] = {b.ev_start, b.ev_aux, b.ev_sha, b.ev_chains, b.ev_done};
+        hipEvent_t single[] = {b.ev_start, b.ev_aux, b.ev_aux2, b.ev_sha, b.ev_chains, b.ev_done};
         for (hipEvent_t ev : single)
             if (ev) hipEventDestroy(ev);
         hipEvent_t* arrays[] = {b.ev_in, b.ev_x, b.ev_step};
@@ -367,17 +367,24 @@ static int launch_group(blsw_engine* e) {
     hipLaunchKernelGGL(ck.map, dim3(g2), dim3(64), 0, st, g);
     launch_cofactor(ck, e->cofactor_mode == 2 || (e->cofactor_mode == 0 && g.N <= BLSW_COFACTOR_CHUNKED_MAX_LANES), g, st);
     hipLaunchKernelGGL(ck.prepare, dim3(g1), dim3(64), 0, st, g, 0);
-    // aux: prepare_g2(sig) and the group allocations (53 ms alone beside the 86 ms of the main stream's first part)
-    hipLaunchKernelGGL(ck.prepare, dim3(g1), dim3(64), 0, b.st[1], g, 1);
+    // aux: prepare_g2(sig) and the group allocations (53 ms alone beside the 86 ms of the main stream's first part); with a second aux
+    // stream the G2 allocation (the longest of them) runs beside the other two
+    hipStream_t sb = b.st[2] ? b.st[2] : b.st[1];
+    if (b.st[2]) hipStreamWaitEvent(sb, b.ev_start, 0);
+    hipLaunchKernelGGL(ck.prepare, dim3(g1), dim3(64), 0, sb, g, 1);
     if (e->L.n_keys) {  // aggregate_verify: one lane per (instance, key) allocates, then mapped_aggregate + pk != 0 + prepare_g1 per instance
-        hipLaunchKernelGGL(ck.agg_keys, dim3((unsigned)((g.N * e->L.n_keys + 63) / 64)), dim3(64), 0, b.st[1], g, g.ws.keyproj);
-        hipLaunchKernelGGL(ck.agg_sum, dim3(g1), dim3(64), 0, b.st[1], g, (const Fp*)g.ws.keyproj);
+        hipLaunchKernelGGL(ck.agg_keys, dim3((unsigned)((g.N * e->L.n_keys + 63) / 64)), dim3(64), 0, sb, g, g.ws.keyproj);
+        hipLaunchKernelGGL(ck.agg_sum, dim3(g1), dim3(64), 0, sb, g, (const Fp*)g.ws.keyproj);
     } else
-        hipLaunchKernelGGL(ck.g1, dim3(g1), dim3(64), 0, b.st[1], g);
+        hipLaunchKernelGGL(ck.g1, dim3(g1), dim3(64), 0, sb, g);
     if (e->modes.g2_team)
         hipLaunchKernelGGL(k_g2_alloc_team, dim3(gt), dim3(64), 0, b.st[1], g);
     else
         hipLaunchKernelGGL(ck.g2_alloc, dim3(g1), dim3(64), 0, b.st[1], g);
+    if (b.st[2]) {
+        hipEventRecord(b.ev_aux2, sb);
+        hipStreamWaitEvent(st, b.ev_aux2, 0);
+    }
     }
     if (K == 1) {
         hipEventRecord(b.ev_aux, b.st[1]);
@@ -538,7 +545,10 @@ int blsw_engine_create_ex(blsw_engine_t** out, uint64_t n, uint32_t msg_len, uin
         chk(hipMalloc(reinterpret_cast<void**>(&b.d_desc), sizeof(StepDesc) * max_steps), "desc alloc");
         chk(hipStreamCreateWithPriority(&b.st[0], hipStreamNonBlocking, main_prio), "stream create");
         chk(hipStreamCreateWithPriority(&b.st[1], hipStreamNonBlocking, aux_prio), "stream create");
-        hipEvent_t* single[] = {&b.ev_start, &b.ev_aux, &b.ev_sha, &b.ev_chains, &b.ev_done};
+#ifdef BLSW_AUX2
+        chk(hipStreamCreateWithPriority(&b.st[2], hipStreamNonBlocking, aux_prio), "stream create");
+#endif
+        hipEvent_t* single[] = {&b.ev_start, &b.ev_aux, &b.ev_aux2, &b.ev_sha, &b.ev_chains, &b.ev_done};
         for (hipEvent_t* ev : single) chk(hipEventCreateWithFlags(ev, hipEventDisableTiming), "event create");
         b.ev_in = new hipEvent_t[max_steps]();
         b.ev_x = new hipEvent_t[max_steps]();

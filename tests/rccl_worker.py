@@ -16,12 +16,17 @@ def main():
     import torch.distributed as dist
 
     rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("BLSW_TEST_BACKEND", "nccl")  # "gloo": a rehearsal of world > 1 on ONE GPU (every rank on device 0; RCCL refuses that)
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     saved = os.dup(1)  # RCCL prints its banner on stdout
     os.dup2(2, 1)
     try:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
         dist.barrier()
     finally:
         sys.stdout.flush()

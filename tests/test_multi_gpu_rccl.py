@@ -32,3 +32,21 @@ def test_engine_and_compact_allgather_over_rccl():
     out = json.loads(lines[-1])
     assert out["world_size"] == world and out["backend"] == "nccl" and out["all_ranks_ok"] and out["mismatches_rank0"] == []
     assert out["order"][:3] == [["gather", 0], ["gather", 1], ["consume", 0]]
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_rehearsal():
+    """The same worker with TWO ranks on ONE GPU (backend gloo on device tensors: RCCL refuses two ranks per device): world > 1 logic of
+    the engine + double-buffered compact gather — two different shards, every rank expands both and compares with direct-mode digests —
+    on the hardware the builder has. Not a measurement (gloo stages through the host)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, BLSW_TEST_BACKEND="gloo")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "tests", "rccl_worker.py")], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert p.returncode == 0 and lines, p.stderr[-2000:]
+    out = json.loads(lines[-1])
+    assert out["world_size"] == 2 and out["backend"] == "gloo" and out["all_ranks_ok"] and out["mismatches_rank0"] == []
