@@ -73,7 +73,8 @@ struct GroupBuf {
     void* base = nullptr;
     StepDesc* h_desc = nullptr;  // pinned host
     StepDesc* d_desc = nullptr;
-    hipStream_t st[3] = {nullptr, nullptr, nullptr};  // main, aux (G2 allocation), aux2 (prepare(sig), G1 / key chains; BLSW_AUX2 builds)
+    hipStream_t st[3] = {nullptr, nullptr, nullptr};  // main, aux, aux2 (only in -DBLSW_AUX2 builds: prepare(sig) and the G1 / key chains beside the G2
+                                                      // allocation — measured slower, profiles/r03_ab_chain_builds.txt section 7)
     hipEvent_t ev_start = nullptr, ev_aux = nullptr, ev_aux2 = nullptr, ev_sha = nullptr, ev_chains = nullptr, ev_done = nullptr;
     hipEvent_t* ev_in = nullptr;    // [max_steps] inputs of step s valid (recorded on the submitting stream)
     hipEvent_t* ev_x = nullptr;     // [max_steps] expansion of step s issued and finished
