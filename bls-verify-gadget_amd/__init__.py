@@ -98,6 +98,7 @@ def lib():
         L.blsw_engine_destroy.argtypes = [vp]
         L.blsw_engine_submit.argtypes = [vp, vp, vp, vp, vp, u64, vp, vp]
         L.blsw_engine_submit_multi.argtypes = [vp, vp, vp, vp, vp, u64, vp, vp]
+        L.blsw_engine_submit_multi_compact.argtypes = [vp, vp, vp, vp, vp, vp, vp]
         L.blsw_engine_submit_bytes.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, u64, vp, vp]
         L.blsw_engine_flush.argtypes = [vp, vp]
         L.blsw_engine_expand_stats.argtypes = [vp, ctypes.POINTER(u32), ctypes.POINTER(ctypes.c_float)]
@@ -114,7 +115,7 @@ def lib():
 
 
 EXPORTED_SYMBOLS = ["blsw_version", "blsw_layout", "blsw_engine_options_default", "blsw_engine_workspace_bytes", "blsw_engine_workspace_bytes_ex", "blsw_engine_create",
-                    "blsw_engine_create_ex", "blsw_engine_destroy", "blsw_engine_submit", "blsw_engine_submit_bytes", "blsw_engine_submit_multi", "blsw_engine_submit_aggregate", "blsw_engine_flush", "blsw_engine_submitted", "blsw_engine_launched", "blsw_engine_materialised", "blsw_engine_wait_step",
+                    "blsw_engine_create_ex", "blsw_engine_destroy", "blsw_engine_submit", "blsw_engine_submit_bytes", "blsw_engine_submit_multi", "blsw_engine_submit_multi_compact", "blsw_engine_submit_aggregate", "blsw_engine_flush", "blsw_engine_submitted", "blsw_engine_launched", "blsw_engine_materialised", "blsw_engine_wait_step",
                     "blsw_engine_output_consumed", "blsw_engine_compact_bytes", "blsw_engine_submit_compact", "blsw_engine_submit_aggregate_compact", "blsw_engine_expand_compact", "blsw_engine_expand_stats", "blsw_witness_digest", "blsw_hash_to_g2_workspace_bytes", "blsw_hash_to_g2_batch",
                     "blsw_decode_batch", "blsw_layout_aggregate", "blsw_aggregate_workspace_bytes", "blsw_aggregate_verify_batch", "blsw_layout_multi",
                     "blsw_verify_multi_workspace_bytes", "blsw_verify_multi_batch", "blsw_matrices_info", "blsw_matrices_fill", "blsw_sign_batch", "blsw_microbench"]
@@ -273,6 +274,21 @@ class WitnessEngine:
         if rc:
             raise (BlswBusy if rc == ERR_BUSY else BlswError)("blsw_engine_submit_multi failed: %d" % rc)
         self._keep.append((pks_xy, msgs, sig_xy, witness, result))
+        self._keep = self._keep[-(self.n_buffers + 1) * self.max_steps:]
+        return seq
+
+    def submit_multi_compact(self, pks_xy, msgs, sig_xy, compact, result=None, stream=None):
+        """submit_multi with the step's compact wire form in `compact` (uint8 tensor of compact_bytes()) as its output -> step number"""
+        K = self.n_pairs
+        assert K > 1 and pks_xy.shape == (self.n, K, 12) and msgs.shape == (self.n, K, self.msg_len) and sig_xy.shape == (self.n, 24)
+        assert pks_xy.is_contiguous() and msgs.is_contiguous() and sig_xy.is_contiguous()
+        assert compact.is_cuda and compact.is_contiguous() and compact.dtype.itemsize == 1 and compact.numel() >= self.compact_bytes()
+        seq = self.submitted()
+        rc = lib().blsw_engine_submit_multi_compact(self._e, pks_xy.data_ptr(), msgs.data_ptr() if self.msg_len else None, sig_xy.data_ptr(), compact.data_ptr(),
+                                                    result.data_ptr() if result is not None else None, self._stream(stream))
+        if rc:
+            raise (BlswBusy if rc == ERR_BUSY else BlswError)("blsw_engine_submit_multi_compact failed: %d" % rc)
+        self._keep.append((pks_xy, msgs, sig_xy, compact, result))
         self._keep = self._keep[-(self.n_buffers + 1) * self.max_steps:]
         return seq
 

@@ -157,8 +157,10 @@ static void launch_place(blsw_engine* e, hipStream_t st, const Fp* staging, cons
     hipLaunchKernelGGL(k_place_field, grid2, dim3(256), 0, st, staging, pair, first, e->L.off_expand, e->L.sha_bits, rows, split_row, out, out_stride, (uint32_t)e->n,
                        e->L.off_sig_alloc, e->modes.g2_team ? e->L.off_pk_not_zero - e->L.off_sig_alloc : 0u, e->LS.off_sig_alloc);
 }
-// N+1-pair product: a step's pair tiles, instance tiles and instance-major rows -> their places in the n instance vectors
-static void launch_place_multi(blsw_engine* e, hipStream_t st, const Workspace& ws, uint32_t s, uint64_t* out, uint64_t out_stride) {
+// N+1-pair product: a step's pair tiles, instance tiles and instance-major rows -> their places in the n instance vectors. Sources: the
+// group workspace (first lanes of the step given) or a compact buffer (first lanes 0, instance tiles tile_w wide)
+static void launch_place_multi(blsw_engine* e, hipStream_t st, const Workspace& ws, const Fp* pair_tiles, uint64_t first_pair, const Fp* inst_tiles, uint64_t first_inst,
+                               uint32_t inst_tile_w, const Fp* rows, uint64_t* out, uint64_t out_stride) {
     const blsw_layout_t& L = e->L;
     const blsw_layout_t& S = e->LS;
     const uint32_t K = L.n_pairs, n = (uint32_t)e->n;
@@ -169,11 +171,11 @@ static void launch_place_multi(blsw_engine* e, hipStream_t st, const Workspace& 
     const uint32_t str[6] = {L.stride_msg, L.stride_pk_alloc, L.stride_pk_not_zero, L.stride_hash, L.stride_prep_h, L.stride_prep_pk};
     for (int r = 0; r < 7; r++) pr.src_row[r] = src[r];
     for (int r = 0; r < 6; r++) pr.dst_off[r] = dst[r], pr.dst_stride[r] = str[r];
-    auto blocks = [](uint32_t rows, uint32_t n_y) {
-        const unsigned chunks = (rows * 3 + 256 * BLSW_PLACE_ITERS - 1) / (256 * BLSW_PLACE_ITERS);
+    auto blocks = [](uint32_t rows_, uint32_t n_y) {
+        const unsigned chunks = (rows_ * 3 + 256 * BLSW_PLACE_ITERS - 1) / (256 * BLSW_PLACE_ITERS);
         return dim3(8 * ((chunks + 7) / 8) * n_y);
     };
-    hipLaunchKernelGGL(k_place_runs, blocks(ws.rows_p, n * K), dim3(256), 0, st, (const Fp*)ws.staging, (uint64_t)s * n * K, ws.rows_p, pr, out, out_stride, n * K, K);
+    hipLaunchKernelGGL(k_place_runs, blocks(ws.rows_p, n * K), dim3(256), 0, st, pair_tiles, first_pair, ws.rows_p, pr, out, out_stride, n * K, K, 64u);
     PlaceRuns pi = {};
     pi.n_runs = 2;
     pi.src_row[0] = S.off_sig_alloc;
@@ -181,9 +183,9 @@ static void launch_place_multi(blsw_engine* e, hipStream_t st, const Workspace& 
     pi.src_row[2] = ws.rows_i;
     pi.dst_off[0] = L.off_sig_alloc;
     pi.dst_off[1] = L.off_prep_sig;
-    hipLaunchKernelGGL(k_place_runs, blocks(ws.rows_i, n), dim3(256), 0, st, (const Fp*)ws.staging_inst, (uint64_t)s * n, ws.rows_i, pi, out, out_stride, n, 1u);
+    hipLaunchKernelGGL(k_place_runs, blocks(ws.rows_i, n), dim3(256), 0, st, inst_tiles, first_inst, ws.rows_i, pi, out, out_stride, n, 1u, inst_tile_w);
     const unsigned chunks = (ws.pair_rows * 3 + 256 * BLSW_PLACE_ITERS - 1) / (256 * BLSW_PLACE_ITERS);
-    hipLaunchKernelGGL(k_place_rows, dim3(chunks, n), dim3(256), 0, st, (const Fp*)(ws.pair + (uint64_t)s * n * ws.pair_rows), ws.pair_rows, L.off_miller, out, out_stride);
+    hipLaunchKernelGGL(k_place_rows, dim3(chunks, n), dim3(256), 0, st, rows, ws.pair_rows, L.off_miller, out, out_stride);
 }
 static void launch_canonical(blsw_engine* e, hipStream_t st, uint64_t* out, uint64_t out_stride) {
     const uint32_t rows = e->L.n_witness - e->L.sha_bits;
@@ -226,11 +228,12 @@ static void materialise(blsw_engine* e, int k, uint32_t s) {
     GroupBuf& b = e->buf[k];
     const StepDesc& d = b.h_desc[s];
     const Workspace& ws = b.ws;
-    const CompactForm cf = compact_form(e->n, ws);
+    const uint32_t Kc = e->L.n_pairs;
+    const CompactForm cf = compact_form(e->n, ws, Kc);
     hipStreamWaitEvent(e->expand, b.ev_sha, 0);
     if (d.compact) {  // the step's bit words leave as they are
         wait_released(e, e->expand, d.compact);
-        hipMemcpyAsync(d.compact, ws.bits + (uint64_t)s * (e->n / 64) * bits_tile_words(ws.sha_words), cf.bits_bytes, hipMemcpyDeviceToDevice, e->expand);
+        hipMemcpyAsync(d.compact, ws.bits + (uint64_t)s * (e->n * Kc / 64) * bits_tile_words(ws.sha_words), cf.bits_bytes, hipMemcpyDeviceToDevice, e->expand);
     }
     if (d.out) {
         wait_released(e, e->expand, d.out);
@@ -249,12 +252,21 @@ static void materialise(blsw_engine* e, int k, uint32_t s) {
     hipStreamWaitEvent(e->place, b.ev_x[s], 0);
     if (d.compact) {  // and so do its staged field witnesses
         char* dst = reinterpret_cast<char*>(d.compact);
-        hipMemcpyAsync(dst + cf.off_staging, ws.staging + (uint64_t)s * (e->n / 64) * ws.split_row * 64, cf.staging_bytes, hipMemcpyDeviceToDevice, e->place);
+        hipMemcpyAsync(dst + cf.off_staging, ws.staging + (uint64_t)s * (e->n * Kc / 64) * ws.rows_p * 64, cf.staging_bytes, hipMemcpyDeviceToDevice, e->place);
+        if (cf.inst_bytes) {  // N+1-pair product: the step's n lanes of the instance tiles (whole tiles, or n lanes of one tile packed [rows_i][n])
+            const uint64_t lane0 = (uint64_t)s * e->n;
+            const Fp* src = ws.staging_inst + (lane0 >> 6) * (uint64_t)ws.rows_i * 64 + (lane0 & 63);
+            if (cf.inst_tile_w == 64)
+                hipMemcpyAsync(dst + cf.off_inst, src, cf.inst_bytes, hipMemcpyDeviceToDevice, e->place);
+            else
+                hipMemcpy2DAsync(dst + cf.off_inst, e->n * sizeof(Fp), src, 64 * sizeof(Fp), e->n * sizeof(Fp), ws.rows_i, hipMemcpyDeviceToDevice, e->place);
+        }
         if (cf.pair_bytes) hipMemcpyAsync(dst + cf.off_pair, ws.pair + (uint64_t)s * e->n * ws.pair_rows, cf.pair_bytes, hipMemcpyDeviceToDevice, e->place);
     }
     if (d.out && e->staged && !(dbg_skip & 2)) {
         if (e->L.n_pairs > 1)
-            launch_place_multi(e, e->place, ws, s, d.out, d.out_stride);
+            launch_place_multi(e, e->place, ws, ws.staging, (uint64_t)s * e->n * e->L.n_pairs, ws.staging_inst, (uint64_t)s * e->n, 64u,
+                               ws.pair + (uint64_t)s * e->n * ws.pair_rows, d.out, d.out_stride);
         else
             launch_place(e, e->place, ws.staging, ws.pair, ws.split_row, (uint64_t)s * e->n, d.out, d.out_stride);
     }
@@ -664,8 +676,8 @@ int blsw_engine_submit_aggregate(blsw_engine_t* e, const uint64_t* d_pks_xy, con
 // Compact wire form (the all-gather of full witness vectors is capped by xGMI at a fraction of the generation
 // rate; 2.6 MB per instance travel instead of 34 MB and the receiver expands them).
 int blsw_engine_compact_bytes(blsw_engine_t* e, uint64_t* bytes) {
-    if (!e || !bytes || !e->staged || e->n % 64 || e->L.n_pairs > 1) return BLSW_ERR_ARG;
-    *bytes = compact_form(e->n, carve(nullptr, e->n, e->L, true, e->modes)).total;
+    if (!e || !bytes || !e->staged || !compact_shape_ok(e->n, e->L.n_pairs)) return BLSW_ERR_ARG;
+    *bytes = compact_form(e->n, carve(nullptr, e->n * e->L.n_pairs, e->L, true, e->modes, e->n), e->L.n_pairs).total;
     return BLSW_OK;
 }
 int blsw_engine_submit_compact(blsw_engine_t* e, const uint64_t* d_pk_xy, const uint64_t* d_sig_xy, const uint8_t* d_msg, void* d_compact, int32_t* d_result,
@@ -680,15 +692,30 @@ int blsw_engine_submit_aggregate_compact(blsw_engine_t* e, const uint64_t* d_pks
     StepDesc d = {nullptr, d_sig_xy, d_msg, nullptr, 0, d_result, d_pks_xy, d_bitmap, d_count, d_compact};
     return engine_submit(e, d, stream_);
 }
+// the N+1-pair product's step in compact form (engine created with options.n_pairs = K; n K a multiple of 64, n a divisor or multiple of 64)
+int blsw_engine_submit_multi_compact(blsw_engine_t* e, const uint64_t* d_pks_xy, const uint8_t* d_msgs, const uint64_t* d_sig_xy, void* d_compact, int32_t* d_result,
+                                     void* stream_) {
+    if (!e || e->L.n_pairs < 2 || !compact_shape_ok(e->n, e->L.n_pairs) || !d_compact || !d_pks_xy || !d_sig_xy || (!d_msgs && e->msg_len)) return BLSW_ERR_ARG;
+    StepDesc d = {d_pks_xy, d_sig_xy, d_msgs, nullptr, 0, d_result, nullptr, nullptr, nullptr, d_compact, nullptr};
+    return engine_submit(e, d, stream_);
+}
 // receiver side: one batch in compact form -> its n witness vectors, on `stream` (the expansion and placement kernels of the
 // engine's own steps, pointed at the compact buffer)
 int blsw_engine_expand_compact(blsw_engine_t* e, const void* d_compact, uint64_t* d_witness, uint64_t witness_stride, void* stream_) {
-    if (!e || !e->staged || e->n % 64 || e->L.n_pairs > 1 || !d_compact || !d_witness || witness_stride < e->L.n_witness) return BLSW_ERR_ARG;
+    if (!e || !e->staged || !compact_shape_ok(e->n, e->L.n_pairs) || !d_compact || !d_witness || witness_stride < e->L.n_witness) return BLSW_ERR_ARG;
     DeviceGuard guard(e->device);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream_);
-    const Workspace w = carve(nullptr, e->n, e->L, true, e->modes);
-    const CompactForm cf = compact_form(e->n, w);
+    const uint32_t K = e->L.n_pairs;
+    const Workspace w = carve(nullptr, e->n * K, e->L, true, e->modes, e->n);
+    const CompactForm cf = compact_form(e->n, w, K);
     const char* src = reinterpret_cast<const char*>(d_compact);
+    if (K > 1) {
+        ExpandArgs xm = {reinterpret_cast<const uint32_t*>(src), w.sha_words, 0, e->L.sha_bits, e->L.off_expand, d_witness, witness_stride, K, e->L.stride_hash, 0, 0};
+        launch_expand(e->opt.expand_variant, e->opt.expand_store, e->opt.place_lds, st, xm, (unsigned)(e->n * K));
+        launch_place_multi(e, st, w, reinterpret_cast<const Fp*>(src + cf.off_staging), 0, reinterpret_cast<const Fp*>(src + cf.off_inst), 0, cf.inst_tile_w,
+                           reinterpret_cast<const Fp*>(src + cf.off_pair), d_witness, witness_stride);
+        return hip_ok(hipGetLastError(), "expand compact");
+    }
     ExpandArgs xa = {reinterpret_cast<const uint32_t*>(src), w.sha_words, 0, e->L.sha_bits, e->L.off_expand, d_witness, witness_stride, 1u, 0u, 0, (int)e->opt.output_form};
     launch_expand(e->opt.expand_variant, e->opt.expand_store, e->opt.place_lds, st, xa, (unsigned)e->n);
     launch_place(e, st, reinterpret_cast<const Fp*>(src + cf.off_staging), reinterpret_cast<const Fp*>(src + cf.off_pair), w.split_row, 0, d_witness, witness_stride);

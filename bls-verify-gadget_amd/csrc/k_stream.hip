@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void k_place_field(const Fp* __restrict__ stag
 // k_place_runs: lanes first .. first + n_y of tile-major staging (pair tiles with K pairs per instance, or instance tiles with K = 1);
 // a lane's rows are up to six runs of consecutive rows (PlaceRuns). Same gather shape and XCD-aware block order as k_place_field.
 __global__ __launch_bounds__(256) void k_place_runs(const Fp* __restrict__ tiles, uint64_t first, uint32_t rows, PlaceRuns runs, uint64_t* __restrict__ d_witness,
-                                                    uint64_t stride, uint32_t n_y, uint32_t K) {
+                                                    uint64_t stride, uint32_t n_y, uint32_t K, uint32_t tile_w) {
     const uint32_t L = blockIdx.x, s_in_xcd = L >> 3;
     const uint32_t chunk = (L & 7) + 8 * (s_in_xcd / n_y);
     const uint32_t y = s_in_xcd % n_y;
@@ -187,7 +187,8 @@ __global__ __launch_bounds__(256) void k_place_runs(const Fp* __restrict__ tiles
     if (chunk * (256u * BLSW_PLACE_ITERS) >= npieces) return;
     const uint64_t lane = first + y;
     const uint32_t inst = y / K, j = y - inst * K;
-    const uint4* src = reinterpret_cast<const uint4*>(tiles + (lane >> 6) * (uint64_t)rows * 64 + (lane & 63));
+    // tile_w lanes per tile: 64 in the workspace; a compact buffer packs the instance rows of a step that is a part of one tile
+    const uint4* src = reinterpret_cast<const uint4*>(tiles + (lane / tile_w) * (uint64_t)rows * tile_w + (lane % tile_w));
     uint4* out = reinterpret_cast<uint4*>(d_witness + (uint64_t)inst * stride * 6);
     const uint32_t q0 = chunk * (256 * BLSW_PLACE_ITERS) + threadIdx.x;
 #pragma unroll
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(256) void k_place_runs(const Fp* __restrict__ tiles
 #pragma unroll
             for (int t = 1; t < 6; t++) r += (t < (int)runs.n_runs && e >= runs.src_row[t]) ? 1u : 0u;
             const uint32_t dst_e = runs.dst_off[r] + j * runs.dst_stride[r] + (e - runs.src_row[r]);
-            out[(uint64_t)dst_e * 3 + c] = src[(uint64_t)e * 64 * 3 + c];
+            out[(uint64_t)dst_e * 3 + c] = src[(uint64_t)e * tile_w * 3 + c];
         }
     }
 }

@@ -166,19 +166,27 @@ __device__ __forceinline__ int32_t step_result(const StepDesc& d, uint32_t i, bo
 }
 // Compact wire form of a step of n instances (n a multiple of 64): the step's slices of the group workspace, back to back —
 // [n/64][sha_words/16][64][16] u32 bit words | [n/64][split_row][64] Fp tile-major rows | [n][pair_rows] Fp instance-major rows
+// N+1-pair product (K pairs per instance, n K a multiple of 64 and n a divisor or a multiple of 64): bit words and pair tiles of the step's
+// n K pair lanes | the instance tiles' rows of the step's n lanes, packed [rows_i][tile_w] with tile_w = min(n, 64) per tile | instance-major rows
 struct CompactForm {
-    uint64_t bits_bytes, staging_bytes, pair_bytes, off_staging, off_pair, total;
+    uint64_t bits_bytes, staging_bytes, inst_bytes, pair_bytes, off_staging, off_inst, off_pair, total;
+    uint32_t inst_tile_w;  // lanes per instance tile in the compact buffer (64, or n when a step is a part of one tile)
 };
-inline CompactForm compact_form(uint64_t n, const Workspace& w) {
+inline CompactForm compact_form(uint64_t n, const Workspace& w, uint32_t K = 1) {
     CompactForm c;
-    c.bits_bytes = bits_tile_words(w.sha_words) * (n / 64) * 4;
-    c.staging_bytes = (uint64_t)w.split_row * n * sizeof(Fp);
+    c.bits_bytes = bits_tile_words(w.sha_words) * (n * K / 64) * 4;
+    c.staging_bytes = (uint64_t)w.rows_p * n * K * sizeof(Fp);
+    c.inst_bytes = K > 1 ? (uint64_t)w.rows_i * n * sizeof(Fp) : 0;
+    c.inst_tile_w = n % 64 == 0 ? 64u : (uint32_t)n;
     c.pair_bytes = (uint64_t)w.pair_rows * n * sizeof(Fp);
     c.off_staging = align_up(c.bits_bytes, 256);
-    c.off_pair = align_up(c.off_staging + c.staging_bytes, 256);
+    c.off_inst = align_up(c.off_staging + c.staging_bytes, 256);
+    c.off_pair = align_up(c.off_inst + c.inst_bytes, 256);
     c.total = align_up(c.off_pair + c.pair_bytes, 256);
     return c;
 }
+// can steps of n instances of K pairs leave in compact form (whole pair tiles; instance lanes = whole tiles or an aligned part of one)?
+inline bool compact_shape_ok(uint64_t n, uint32_t K) { return K <= 1 ? n % 64 == 0 : ((n * K) % 64 == 0 && (n % 64 == 0 || 64 % n == 0)); }
 // a group of `steps` batches of n instances each, processed by one set of launches (N = steps * n * K lanes per chain;
 // K = (pk, msg) pairs per instance: 1 except for the N+1-pair product)
 struct Group {
@@ -373,7 +381,7 @@ struct PlaceRuns {
     uint32_t dst_off[6], dst_stride[6];
 };
 __global__ void k_place_runs(const Fp* __restrict__ tiles, uint64_t first, uint32_t rows, PlaceRuns runs, uint64_t* __restrict__ d_witness, uint64_t stride, uint32_t n_y,
-                             uint32_t K);
+                             uint32_t K, uint32_t tile_w);
 __global__ void k_place_rows(const Fp* __restrict__ rows, uint32_t n_rows, uint32_t dst_off, uint64_t* __restrict__ d_witness, uint64_t stride);
 // the two compilations of the chain units as one table
 struct ChainKernels {

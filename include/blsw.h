@@ -128,7 +128,8 @@ typedef struct {
                               2 = inlined. Same witnesses either way. */
     uint32_t n_pairs;      /* 0 / 1 = the single-key circuit; K > 1 = the N+1-pair product (blsw_layout_multi): one signature over K (pk, msg)
                               pairs per instance, batches through blsw_engine_submit_multi. Staged engines only (max_steps > 1 or
-                              n_buffers > 1), default kernel modes, Montgomery output form, n * K <= 65535; no compact wire form yet */
+                              n_buffers > 1), default kernel modes, Montgomery output form, n * K <= 65535. Compact wire form (blsw_engine_submit_multi_compact,
+                              ~180 MB instead of 4.19 GB per instance at K = 128): n * K a multiple of 64 and n a divisor or a multiple of 64 */
     uint32_t cofactor_mode; /* clear_cofactor2 (the longest chain) with the three 255-bit chunks of its scalar on three lanes and a join: half the
                               chain's latency for 38 % more products in it. 0 (default) = for launch groups of at most 8 192 lanes (latency-bound),
                               one chain per lane above; 1 = never; 2 = always. Same witnesses either way. */
@@ -225,6 +226,10 @@ int blsw_engine_submit_compact(blsw_engine_t* e, const uint64_t* d_pk_xy, const 
 /* the same for an aggregate_verify engine (options.n_keys = K): arguments of blsw_engine_submit_aggregate, output d_compact */
 int blsw_engine_submit_aggregate_compact(blsw_engine_t* e, const uint64_t* d_pks_xy, const uint8_t* d_bitmap, const uint64_t* d_sig_xy, const uint8_t* d_msg,
                                          void* d_compact, int32_t* d_result, uint32_t* d_count, void* stream);
+/* the same for an N+1-pair engine (options.n_pairs = K): arguments of blsw_engine_submit_multi, output d_compact (blsw_engine_compact_bytes bytes);
+ * blsw_engine_expand_compact turns it into the n vectors of 4.19 GB (K = 128) on the receiver */
+int blsw_engine_submit_multi_compact(blsw_engine_t* e, const uint64_t* d_pks_xy, const uint8_t* d_msgs, const uint64_t* d_sig_xy, void* d_compact, int32_t* d_result,
+                                     void* stream);
 int blsw_engine_expand_compact(blsw_engine_t* e, const void* d_compact, uint64_t* d_witness, uint64_t witness_stride, void* stream);
 /* average duration (ms) of the bit->Fp expansion kernel launches issued since the previous call (HIP events on the stream they
  * ran on, at most 1024 launches); blocks until they have finished and resets the statistics */

@@ -887,6 +887,48 @@ def test_engine_multi_grouped(pkg, oracle, K, n, consumer):
     eng.close()
 
 
+def test_engine_multi_compact_round_trip(pkg, oracle):
+    """Compact wire form of the N+1-pair engine (blsw_engine_submit_multi_compact; 4 instances of 16 pairs per step: one whole pair tile,
+    a quarter of an instance tile, packed): three steps leave in compact form, a SECOND engine expands them
+    (blsw_engine_expand_compact) and every witness element of every instance equals the oracle's."""
+    import torch
+
+    K, n, steps = 16, 4, 3
+    dev = torch.device("cuda:0")
+    cases = [synth.make_multi(oracle, K, tamper=(3 if a == 5 else None), start=3 * a) for a in range(steps * n)]
+    eng = pkg.WitnessEngine(n, 32, max_steps=2, device=dev, n_buffers=2, n_pairs=K)
+    rx = pkg.WitnessEngine(n, 32, max_steps=2, device=dev, n_buffers=2, n_pairs=K)
+    cb = eng.compact_bytes()
+    lay = pkg.layout_multi(32, K)
+    assert cb < n * lay["n_witness"] * 48 / 10  # an order of magnitude below the vectors
+    cbufs = eng.new_compact_buffer(steps)
+    ress = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(steps)]
+    keep = []
+    for k in range(steps):
+        sl = cases[k * n:(k + 1) * n]
+        d = (torch.from_numpy(np.stack([c[0] for c in sl]).view(np.int64)).to(dev), torch.from_numpy(np.stack([c[1] for c in sl])).to(dev),
+             torch.from_numpy(np.stack([c[2] for c in sl]).view(np.int64)).to(dev))
+        keep.append(d)
+        eng.submit_multi_compact(d[0], d[1], d[2], cbufs[k], result=ress[k])
+    eng.flush()
+    torch.cuda.synchronize()
+    wit = rx.new_witness_tensor()
+    for k in range(steps):
+        wit.zero_()
+        rx.expand_compact(cbufs[k], wit)
+        torch.cuda.synchronize()
+        w = wit.cpu().numpy().view(np.uint64)
+        got = ress[k].cpu().numpy().astype(bool)
+        for i in range(n):
+            c = cases[k * n + i]
+            nw, res, _, ow = oracle.witness_multi(c[0], c[1], c[2])
+            assert nw == w.shape[1] and res == c[3] == bool(got[i]), (k, i)
+            bad = np.nonzero((ow != w[i]).any(axis=1))[0]
+            assert len(bad) == 0, "step %d instance %d: first mismatching witness index %d" % (k, i, bad[0])
+    eng.close()
+    rx.close()
+
+
 def test_verify_multi_128_pairs(pkg, oracle):
     """BASELINE configs[3]: ONE signature over 128 (pk, msg) pairs, a 129-pair Miller product — all 87 295 138 witness
     elements (4.2 GB) against the oracle, plus the tampered variant's result."""
