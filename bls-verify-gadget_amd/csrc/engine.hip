@@ -188,8 +188,8 @@ static void launch_place_multi(blsw_engine* e, hipStream_t st, const Workspace& 
     hipLaunchKernelGGL(k_place_rows, dim3(chunks, n), dim3(256), 0, st, rows, ws.pair_rows, L.off_miller, out, out_stride);
 }
 static void launch_canonical(blsw_engine* e, hipStream_t st, uint64_t* out, uint64_t out_stride) {
-    const uint32_t rows = e->L.n_witness - e->L.sha_bits;
-    hipLaunchKernelGGL(k_canonical_rows, dim3((rows + 255) / 256, (unsigned)e->n), dim3(256), 0, st, out, out_stride, e->L.off_expand, e->L.sha_bits, rows);
+    const uint32_t K = e->L.n_pairs, rows = e->L.n_witness - K * e->L.sha_bits;
+    hipLaunchKernelGGL(k_canonical_rows, dim3((rows + 255) / 256, (unsigned)e->n), dim3(256), 0, st, out, out_stride, e->L.off_expand, e->L.sha_bits, rows, K, e->L.stride_hash);
 }
 
 #ifdef BLSW_DEBUG_KNOBS  // timing experiments only (wrong witnesses): BLSW_DEBUG_SKIP bit 0 chains, bit 1 placement, bit 2 expansion
@@ -488,7 +488,7 @@ int blsw_engine_create_ex(blsw_engine_t** out, uint64_t n, uint32_t msg_len, uin
         return BLSW_ERR_ARG;
     // N+1-pair product (options.n_pairs = K > 1): a staged engine with the default kernel modes; its expansion launch has one row of
     // workgroups per (instance, pair)
-    if (options->n_pairs > 1 && (options->n_keys || options->pairing_mode || options->g2_mode || options->output_form || !(max_steps > 1 || n_buffers > 1) || n * options->n_pairs > 65535))
+    if (options->n_pairs > 1 && (options->n_keys || options->pairing_mode || options->g2_mode || !(max_steps > 1 || n_buffers > 1) || n * options->n_pairs > 65535))
         return BLSW_ERR_ARG;
     *out = nullptr;
     int ndev = 0;
@@ -710,10 +710,11 @@ int blsw_engine_expand_compact(blsw_engine_t* e, const void* d_compact, uint64_t
     const CompactForm cf = compact_form(e->n, w, K);
     const char* src = reinterpret_cast<const char*>(d_compact);
     if (K > 1) {
-        ExpandArgs xm = {reinterpret_cast<const uint32_t*>(src), w.sha_words, 0, e->L.sha_bits, e->L.off_expand, d_witness, witness_stride, K, e->L.stride_hash, 0, 0};
+        ExpandArgs xm = {reinterpret_cast<const uint32_t*>(src), w.sha_words, 0, e->L.sha_bits, e->L.off_expand, d_witness, witness_stride, K, e->L.stride_hash, 0, (int)e->opt.output_form};
         launch_expand(e->opt.expand_variant, e->opt.expand_store, e->opt.place_lds, st, xm, (unsigned)(e->n * K));
         launch_place_multi(e, st, w, reinterpret_cast<const Fp*>(src + cf.off_staging), 0, reinterpret_cast<const Fp*>(src + cf.off_inst), 0, cf.inst_tile_w,
                            reinterpret_cast<const Fp*>(src + cf.off_pair), d_witness, witness_stride);
+        if (e->opt.output_form) launch_canonical(e, st, d_witness, witness_stride);
         return hip_ok(hipGetLastError(), "expand compact");
     }
     ExpandArgs xa = {reinterpret_cast<const uint32_t*>(src), w.sha_words, 0, e->L.sha_bits, e->L.off_expand, d_witness, witness_stride, 1u, 0u, 0, (int)e->opt.output_form};

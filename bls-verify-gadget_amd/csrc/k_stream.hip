@@ -254,10 +254,23 @@ __global__ __launch_bounds__(256) void k_digest(const uint64_t* __restrict__ w, 
 
 // options.output_form = 1: the field witnesses of a step, in place, from Montgomery form to canonical integers (what
 // CanonicalSerialize writes for an Fq: 48 bytes little-endian); the SHA segment is written in that form by the expansion itself
-__global__ __launch_bounds__(256) void k_canonical_rows(uint64_t* __restrict__ d_witness, uint64_t stride, uint32_t off_expand, uint32_t sha_bits, uint32_t rows) {
+// K SHA segments (one per pair, stride_hash apart; K = 1: the single-key and aggregate circuits) are skipped: row idx of the field rows
+// lies in front of the first segment, in the tail of pair j's hash block (hash_tail rows behind each segment), or behind the last block
+__global__ __launch_bounds__(256) void k_canonical_rows(uint64_t* __restrict__ d_witness, uint64_t stride, uint32_t off_expand, uint32_t sha_bits, uint32_t rows, uint32_t K,
+                                                        uint32_t stride_hash) {
     const uint32_t idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= rows) return;
-    Fp* p = reinterpret_cast<Fp*>(d_witness + ((uint64_t)blockIdx.y * stride + (idx < off_expand ? idx : idx + sha_bits)) * 6);
+    uint32_t el;
+    if (idx < off_expand)
+        el = idx;
+    else if (K <= 1)
+        el = idx + sha_bits;
+    else {
+        const uint32_t hash_tail = stride_hash - sha_bits, r = idx - off_expand;
+        const uint32_t j = r / hash_tail;
+        el = j < K ? off_expand + j * stride_hash + sha_bits + (r - j * hash_tail) : idx + K * sha_bits;
+    }
+    Fp* p = reinterpret_cast<Fp*>(d_witness + ((uint64_t)blockIdx.y * stride + el) * 6);
     st_fp(p, fp_to_canonical(ld_fp(p)));
 }
 

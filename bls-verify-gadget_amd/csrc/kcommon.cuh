@@ -323,7 +323,7 @@ __global__ void k_sha_values(Group g);
 __global__ void k_place_field(const Fp* __restrict__ staging, const Fp* __restrict__ pair, uint64_t first, uint32_t off_expand, uint32_t sha_bits,
                               uint32_t staging_rows, uint32_t split_row, uint64_t* __restrict__ d_witness, uint64_t stride, uint32_t n_inst, uint32_t moved_lo,
                               uint32_t moved_len, uint32_t moved_at);
-__global__ void k_canonical_rows(uint64_t* __restrict__ d_witness, uint64_t stride, uint32_t off_expand, uint32_t sha_bits, uint32_t rows);
+__global__ void k_canonical_rows(uint64_t* __restrict__ d_witness, uint64_t stride, uint32_t off_expand, uint32_t sha_bits, uint32_t rows, uint32_t K, uint32_t stride_hash);
 __global__ void k_digest(const uint64_t* __restrict__ w, uint64_t stride, uint64_t n_words, uint64_t* __restrict__ digest);
 __global__ void k_g1(Group g);
 __global__ void k_g1_inl(Group g);

@@ -128,7 +128,7 @@ typedef struct {
                               2 = inlined. Same witnesses either way. */
     uint32_t n_pairs;      /* 0 / 1 = the single-key circuit; K > 1 = the N+1-pair product (blsw_layout_multi): one signature over K (pk, msg)
                               pairs per instance, batches through blsw_engine_submit_multi. Staged engines only (max_steps > 1 or
-                              n_buffers > 1), default kernel modes, Montgomery output form, n * K <= 65535. Compact wire form (blsw_engine_submit_multi_compact,
+                              n_buffers > 1), default kernel modes, n * K <= 65535. Compact wire form (blsw_engine_submit_multi_compact,
                               ~180 MB instead of 4.19 GB per instance at K = 128): n * K a multiple of 64 and n a divisor or a multiple of 64 */
     uint32_t cofactor_mode; /* clear_cofactor2 (the longest chain) with the three 255-bit chunks of its scalar on three lanes and a join: half the
                               chain's latency for 38 % more products in it. 0 (default) = for launch groups of at most 8 192 lanes (latency-bound),
