@@ -19,7 +19,8 @@ FP_BYTES = 48
 _LAYOUT_FIELDS = (
     "msg_len n_instance_vars n_witness sha_bits off_msg off_pk_alloc off_sig_alloc off_pk_not_zero off_expand off_map0 off_map1 "
     "off_add off_cofactor off_prep_h off_prep_pk off_prep_sig off_miller off_final_exp off_is_one n_keys off_keys off_bitmap off_count off_agg "
-    "n_pairs stride_msg stride_pk_alloc stride_pk_not_zero stride_hash stride_prep_h stride_prep_pk"
+    "n_pairs stride_msg stride_pk_alloc stride_pk_not_zero stride_hash stride_prep_h stride_prep_pk "
+    "params_mode off_params_alloc off_prep_g1"
 ).split()
 
 
@@ -28,7 +29,7 @@ class blsw_layout_t(ctypes.Structure):
 
 
 class blsw_engine_options_t(ctypes.Structure):
-    _fields_ = [("device", ctypes.c_int32)] + [(n, ctypes.c_uint32) for n in "n_keys pairing_mode g2_mode expand_variant expand_store prio_mode place_lds consumer_mode output_form chain_variant n_pairs cofactor_mode".split()]
+    _fields_ = [("device", ctypes.c_int32)] + [(n, ctypes.c_uint32) for n in "n_keys pairing_mode g2_mode expand_variant expand_store prio_mode place_lds consumer_mode output_form chain_variant n_pairs cofactor_mode params_mode".split()]
 
 
 class blsw_matrices_info_t(ctypes.Structure):
@@ -92,6 +93,9 @@ def lib():
         L.blsw_witness_digest.argtypes = [vp, u64, u64, u32, vp, vp]
         L.blsw_matrices_info.argtypes = [u32, u32, u32, ctypes.POINTER(blsw_matrices_info_t)]
         L.blsw_matrices_fill.argtypes = [u32, u32, u32, ctypes.POINTER(blsw_matrices_info_t), ctypes.POINTER(blsw_matrices_t)]
+        L.blsw_matrices_info_params.argtypes = [u32, u32, ctypes.POINTER(blsw_matrices_info_t)]
+        L.blsw_matrices_fill_params.argtypes = [u32, u32, ctypes.POINTER(blsw_matrices_info_t), ctypes.POINTER(blsw_matrices_t)]
+        L.blsw_layout_params.argtypes = [u32, u32, ctypes.POINTER(blsw_layout_t)]
         L.blsw_layout_multi.argtypes = [u32, u32, ctypes.POINTER(blsw_layout_t)]
         L.blsw_verify_multi_workspace_bytes.argtypes = [u64, u32, u32, ctypes.POINTER(u64)]
         L.blsw_verify_multi_batch.argtypes = [vp, vp, u32, u32, vp, u64, vp, u64, vp, vp, u64, vp]
@@ -118,13 +122,19 @@ EXPORTED_SYMBOLS = ["blsw_version", "blsw_layout", "blsw_engine_options_default"
                     "blsw_engine_create_ex", "blsw_engine_destroy", "blsw_engine_submit", "blsw_engine_submit_bytes", "blsw_engine_submit_multi", "blsw_engine_submit_multi_compact", "blsw_engine_submit_aggregate", "blsw_engine_flush", "blsw_engine_submitted", "blsw_engine_launched", "blsw_engine_materialised", "blsw_engine_wait_step",
                     "blsw_engine_output_consumed", "blsw_engine_compact_bytes", "blsw_engine_submit_compact", "blsw_engine_submit_aggregate_compact", "blsw_engine_expand_compact", "blsw_engine_expand_stats", "blsw_witness_digest", "blsw_hash_to_g2_workspace_bytes", "blsw_hash_to_g2_batch",
                     "blsw_decode_batch", "blsw_layout_aggregate", "blsw_aggregate_workspace_bytes", "blsw_aggregate_verify_batch", "blsw_layout_multi",
-                    "blsw_verify_multi_workspace_bytes", "blsw_verify_multi_batch", "blsw_matrices_info", "blsw_matrices_fill", "blsw_sign_batch", "blsw_microbench"]
+                    "blsw_verify_multi_workspace_bytes", "blsw_verify_multi_batch", "blsw_matrices_info", "blsw_matrices_fill", "blsw_sign_batch", "blsw_microbench",
+                    "blsw_layout_params", "blsw_matrices_info_params", "blsw_matrices_fill_params"]
 
 
-def layout(msg_len=32):
-    """Segment table of the witness vector (host logic; replaces cs.num_witness_variables(), constraints.rs:369-373)."""
+PARAMS_MODES = {"constant": 0, "witness": 1}
+
+
+def layout(msg_len=32, params_mode=0):
+    """Segment table of the witness vector (host logic; replaces cs.num_witness_variables(), constraints.rs:369-373).
+    params_mode 1 / "witness": ParametersVar::new_variable with AllocationMode::Witness (constraints.rs:198-211)."""
     L = blsw_layout_t()
-    rc = lib().blsw_layout(msg_len, ctypes.byref(L))
+    params_mode = PARAMS_MODES.get(params_mode, params_mode)
+    rc = lib().blsw_layout_params(msg_len, params_mode, ctypes.byref(L)) if params_mode else lib().blsw_layout(msg_len, ctypes.byref(L))
     if rc:
         raise BlswError("blsw_layout failed: %d" % rc)
     return {n: getattr(L, n) for n in _LAYOUT_FIELDS}
@@ -163,7 +173,7 @@ def engine_options(**overrides):
     for var, field in (("BLSW_CHAIN_VARIANT", "chain_variant"), ("BLSW_COFACTOR_MODE", "cofactor_mode"), ("BLSW_EXPAND_VARIANT", "expand_variant"), ("BLSW_EXPAND_NT", "expand_store"), ("BLSW_PRIO_MODE", "prio_mode"), ("BLSW_PLACE_LDS", "place_lds")):
         if env.get(var):
             setattr(o, field, int(env[var]))
-    names = {"pairing_mode": {"team": 0, "lane": 1}, "g2_mode": {"lane": 0, "team": 1}}
+    names = {"pairing_mode": {"team": 0, "lane": 1}, "g2_mode": {"lane": 0, "team": 1}, "params_mode": PARAMS_MODES}
     for k, v in overrides.items():
         if v is None:
             continue
@@ -188,7 +198,7 @@ class WitnessEngine:
         opt.device = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.n_keys = int(opt.n_keys)
         self.n_pairs = int(opt.n_pairs) if opt.n_pairs > 1 else 1
-        self.layout = layout_aggregate(msg_len, self.n_keys) if self.n_keys else (layout_multi(msg_len, self.n_pairs) if self.n_pairs > 1 else layout(msg_len))
+        self.layout = layout_aggregate(msg_len, self.n_keys) if self.n_keys else (layout_multi(msg_len, self.n_pairs) if self.n_pairs > 1 else layout(msg_len, int(opt.params_mode)))
         self.n_witness = self.layout["n_witness"]
         wb = ctypes.c_uint64(0)
         rc = lib().blsw_engine_workspace_bytes_ex(self.n, self.msg_len, self.max_steps, self.n_buffers, ctypes.byref(opt), ctypes.byref(wb))
@@ -401,10 +411,22 @@ class WitnessEngine:
 
 
 class ParametersVar:
-    """constraints.rs:23-28: g1_generator; only AllocationMode::Constant (the default generator) is on the GPU path."""
+    """constraints.rs:23-28, AllocVar at :194-212: the default generator, allocated as a Constant (every circuit of the reference) or
+    as a Witness (new_witness: the generator goes through G1Var::new_variable like a public key). AllocationMode::Input would put it
+    into instance_assignment, which the engine does not produce."""
 
-    def __init__(self):
-        self.mode = "Constant"
+    def __init__(self, mode="Constant"):
+        if mode not in ("Constant", "Witness"):
+            raise BlswError("ParametersVar: AllocationMode %r is not on the GPU path (Constant or Witness)" % (mode,))
+        self.mode = mode
+
+    @classmethod
+    def new_constant(cls):
+        return cls("Constant")
+
+    @classmethod
+    def new_witness(cls):
+        return cls("Witness")
 
 
 class PublicKeyVar:
@@ -433,6 +455,7 @@ class BlsSignatureVerifyGadget:
     """Batched counterpart of constraints.rs:79-128. One call = n independent circuits (direct mode engine, one batch)."""
 
     def __init__(self, n, msg_len=32, device=None, want_witness=True, max_steps=1, **options):
+        """options: blsw_engine_options_t fields; params_mode="witness" builds the circuit for ParametersVar.new_witness()."""
         self.engine = WitnessEngine(n, msg_len, max_steps=max_steps, device=device, **options)
         torch = self.engine.torch
         self.torch = torch
@@ -446,6 +469,8 @@ class BlsSignatureVerifyGadget:
         """message: [n, msg_len] uint8 tensor. Returns the int32 result tensor (gadget Boolean per instance); the witness
         vectors are in self.witness (or the tensor passed as `witness`)."""
         assert isinstance(parameters, ParametersVar)
+        if (parameters.mode == "Witness") != bool(self.layout["params_mode"]):
+            raise BlswError("ParametersVar mode %s does not match the circuit this gadget was built for (params_mode=%d)" % (parameters.mode, self.layout["params_mode"]))
         w = witness if witness is not None else self.witness
         self.engine.submit(public_key.xy, signature.xy, message, witness=w, result=self.result, stream=stream)
         self.engine.flush(stream=stream)
@@ -519,14 +544,21 @@ def aggregate_verify(parameters, public_keys, bitmap, message, signature, want_w
     return res, cnt, wit
 
 
-def matrices(msg_len=32, n_keys=0, n_pairs=1):
+def matrices(msg_len=32, n_keys=0, n_pairs=1, params_mode=0):
     """Constraint matrices of a circuit shape (host only; blsw_matrices_info + blsw_matrices_fill): the R1CS an arkworks prover
     takes next to the witness vectors, in ConstraintMatrices shape. Returns dict(n_constraints, n_instance_vars, n_witness,
-    A / B / C = (row_ptr uint64 [n_constraints + 1], col uint32 [nnz], val uint64 [nnz, 6] Montgomery limbs))."""
+    A / B / C = (row_ptr uint64 [n_constraints + 1], col uint32 [nnz], val uint64 [nnz, 6] Montgomery limbs)).
+    params_mode 1 / "witness" (single-key circuit): the system of layout(msg_len, params_mode=1)."""
     import numpy as np
 
+    params_mode = PARAMS_MODES.get(params_mode, params_mode)
     info = blsw_matrices_info_t()
-    rc = lib().blsw_matrices_info(msg_len, n_keys, n_pairs, ctypes.byref(info))
+    if params_mode:
+        if n_keys or n_pairs != 1:
+            raise BlswError("params_mode applies to the single-key circuit")
+        rc = lib().blsw_matrices_info_params(msg_len, params_mode, ctypes.byref(info))
+    else:
+        rc = lib().blsw_matrices_info(msg_len, n_keys, n_pairs, ctypes.byref(info))
     if rc:
         raise BlswError("blsw_matrices_info failed: %d" % rc)
     u64p, u32p = ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)
@@ -538,7 +570,10 @@ def matrices(msg_len=32, n_keys=0, n_pairs=1):
         out.row_ptr[m] = rp[m].ctypes.data_as(u64p)
         out.col[m] = col[m].ctypes.data_as(u32p)
         out.val[m] = val[m].ctypes.data_as(u64p)
-    rc = lib().blsw_matrices_fill(msg_len, n_keys, n_pairs, ctypes.byref(info), ctypes.byref(out))
+    if params_mode:
+        rc = lib().blsw_matrices_fill_params(msg_len, params_mode, ctypes.byref(info), ctypes.byref(out))
+    else:
+        rc = lib().blsw_matrices_fill(msg_len, n_keys, n_pairs, ctypes.byref(info), ctypes.byref(out))
     if rc:
         raise BlswError("blsw_matrices_fill failed: %d" % rc)
     return {"n_constraints": info.n_constraints, "n_instance_vars": info.n_instance_vars, "n_witness": info.n_witness,

@@ -388,8 +388,8 @@ static int launch_group(blsw_engine* e) {
     if (e->L.n_keys) {  // aggregate_verify: one lane per (instance, key) allocates, then mapped_aggregate + pk != 0 + prepare_g1 per instance
         hipLaunchKernelGGL(ck.agg_keys, dim3((unsigned)((g.N * e->L.n_keys + 63) / 64)), dim3(64), 0, sb, g, g.ws.keyproj);
         hipLaunchKernelGGL(ck.agg_sum, dim3(g1), dim3(64), 0, sb, g, (const Fp*)g.ws.keyproj);
-    } else
-        hipLaunchKernelGGL(ck.g1, dim3(g1), dim3(64), 0, sb, g);
+    } else  // params_mode: lanes [N, 2 N) allocate and prepare the generator (k_g1)
+        hipLaunchKernelGGL(ck.g1, dim3(e->L.params_mode ? (unsigned)((2 * g.N + 63) / 64) : g1), dim3(64), 0, sb, g);
     if (e->modes.g2_team)
         hipLaunchKernelGGL(k_g2_alloc_team, dim3(gt), dim3(64), 0, b.st[1], g);
     else
@@ -431,6 +431,12 @@ int blsw_layout(uint32_t msg_len, blsw_layout_t* out) {
     return BLSW_OK;
 }
 
+int blsw_layout_params(uint32_t msg_len, uint32_t params_mode, blsw_layout_t* out) {
+    if (!out || msg_len > 65535 || params_mode > 1) return BLSW_ERR_ARG;
+    make_layout(msg_len, out, 0, 1, params_mode == 1);
+    return BLSW_OK;
+}
+
 int blsw_engine_options_default(blsw_engine_options_t* o) {
     if (!o) return BLSW_ERR_ARG;
     o->device = -1;
@@ -446,16 +452,18 @@ int blsw_engine_options_default(blsw_engine_options_t* o) {
     o->chain_variant = 0;
     o->n_pairs = 0;
     o->cofactor_mode = 0;
+    o->params_mode = 0;
     return BLSW_OK;
 }
 
 int blsw_engine_workspace_bytes_ex(uint64_t n, uint32_t msg_len, uint32_t max_steps, uint32_t n_buffers, const blsw_engine_options_t* options, uint64_t* bytes) {
     if (!bytes || n == 0 || max_steps == 0 || n_buffers == 0 || n_buffers > BLSW_MAX_BUFFERS || msg_len > 65535 || !options || options->n_keys > 65535 ||
-        options->n_pairs > 4096 || (options->n_pairs > 1 && options->n_keys))
+        options->n_pairs > 4096 || (options->n_pairs > 1 && options->n_keys) || options->params_mode > 1 ||
+        (options->params_mode && (options->n_keys || options->n_pairs > 1 || options->pairing_mode)))
         return BLSW_ERR_ARG;
     blsw_layout_t L;
     const uint32_t K = options->n_pairs > 1 ? options->n_pairs : 1;
-    make_layout(msg_len, &L, options->n_keys, K);
+    make_layout(msg_len, &L, options->n_keys, K, options->params_mode == 1);
     const bool staged = max_steps > 1 || n_buffers > 1;
     // the same workspace serves every kernel variant: the largest carve of the three mode combinations
     uint64_t need = 0;
@@ -490,6 +498,8 @@ int blsw_engine_create_ex(blsw_engine_t** out, uint64_t n, uint32_t msg_len, uin
     // workgroups per (instance, pair)
     if (options->n_pairs > 1 && (options->n_keys || options->pairing_mode || options->g2_mode || !(max_steps > 1 || n_buffers > 1) || n * options->n_pairs > 65535))
         return BLSW_ERR_ARG;
+    // ParametersVar allocated as witnesses: the single-key circuit with the six-lane pairing kernel (k_pairing_team_pv)
+    if (options->params_mode > 1 || (options->params_mode && (options->n_keys || options->n_pairs > 1 || options->pairing_mode))) return BLSW_ERR_ARG;
     *out = nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return BLSW_ERR_NO_DEVICE;
@@ -527,7 +537,7 @@ int blsw_engine_create_ex(blsw_engine_t** out, uint64_t n, uint32_t msg_len, uin
     e->staged = max_steps > 1 || n_buffers > 1;
     e->cofactor_mode = options->cofactor_mode;
     e->chains_inlined = options->chain_variant == 2 || (options->chain_variant == 0 && !e->staged);
-    make_layout(msg_len, &e->L, options->n_keys, options->n_pairs > 1 ? options->n_pairs : 1);
+    make_layout(msg_len, &e->L, options->n_keys, options->n_pairs > 1 ? options->n_pairs : 1, options->params_mode == 1);
     e->LS = e->L.n_pairs > 1 ? staging_layout_multi(e->L).LS : staging_layout(e->L, e->modes);
     for (int i = 0; i < BLSW_MAX_CONSUMED; i++) {
         e->consumed_ptr[i] = nullptr;

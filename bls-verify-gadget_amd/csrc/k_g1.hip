@@ -14,14 +14,31 @@
 
 namespace blsw {
 
+// Lanes [0, N): the public key of a (pk, msg) pair. ParametersVar allocated as witnesses (L.params_mode, single-key circuit: constraints.rs:198-211
+// with AllocationMode::Witness): lanes [N, 2 N) run the same chain on the generator of instance I - N — G1Var::new_variable, then g1.negate()
+// (linear) and prepare_g1(&g1_neg) = to_affine; no enforce_not_equal on it (constraints.rs:97-99 is about the public key only).
 __global__ __launch_bounds__(64) BLSW_CHAIN_ATTR void BLSW_K(k_g1)(Group g) {
     if (g.chain_prio) __builtin_amdgcn_s_setprio(3);  // latency-critical chain: win VALU issue arbitration against the streaming placement waves
     uint64_t I = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool params = g.L.params_mode && I >= g.N;
+    if (params) I -= g.N;
     if (I >= g.N) return;
     LaneId id = lane_id(g, I);
     const Fp* p = reinterpret_cast<const Fp*>(g.desc[id.s].pk + (uint64_t)id.f * 12);
-    G1ChainOut o = chain_g1_alloc(EMITJ(g, id, off_pk_alloc, stride_pk_alloc), EMITJ(g, id, off_pk_not_zero, stride_pk_not_zero),
-                                  EMITJ(g, id, off_prep_pk, stride_prep_pk), ld_fp(p), ld_fp(p + 1));
+    Emitter e_alloc = EMITJ(g, id, off_pk_alloc, stride_pk_alloc), e_nz = EMITJ(g, id, off_pk_not_zero, stride_pk_not_zero),
+            e_prep = EMITJ(g, id, off_prep_pk, stride_prep_pk);
+    Fp x = ld_fp(p), y = ld_fp(p + 1);
+    if (params) {
+        e_alloc = EMIT(g, id, off_params_alloc);
+        e_prep = EMIT(g, id, off_prep_g1);
+        e_nz.base = nullptr;
+        x = K_G1_GEN_X();
+        y = fp_neg(K_G1_GEN_NEG_Y());
+    }
+    Proj<OpsFp> pk = chain_g1_alloc_only(e_alloc, x, y);
+    if (params) pk.y = fp_neg(pk.y);
+    G1ChainOut o = chain_g1_post(e_nz, e_prep, pk);
+    if (params) return;  // its affine form is the constant the pairing kernel uses
     st_fp(g.ws.pkaff + I, o.ax);
     st_fp(g.ws.pkaff + g.N + I, o.ay);
 }

@@ -31,6 +31,33 @@ __global__ __launch_bounds__(64) void k_pairing_team(Group g) {
     int32_t* r = g.desc[id.s].result;
     if (active && j == 0 && r) r[id.i] = step_result(g.desc[id.s], id.i, res);
 }
+// the same for ParametersVar allocated as witnesses (L.params_mode: constraints.rs:198-211 with AllocationMode::Witness): team_miller_pv
+__global__ __launch_bounds__(64) void k_pairing_team_pv(Group g) {
+    __shared__ Fp2 lds[BLSW_TEAMS_PER_WAVE * TS_NSLOTS];
+    if ((uint64_t)blockIdx.x * BLSW_TEAMS_PER_WAVE >= g.N) return;
+    if (g.chain_prio) __builtin_amdgcn_s_setprio(3);
+    const uint32_t team = threadIdx.x / 6, j = threadIdx.x % 6;
+    const uint64_t I0 = (uint64_t)blockIdx.x * BLSW_TEAMS_PER_WAVE + team;
+    const bool active = team < BLSW_TEAMS_PER_WAVE && I0 < g.N;
+    const uint64_t I = active ? I0 : 0, N = g.N;
+    LaneId id = lane_id(g, I);
+    TeamLanesPv t;
+    t.slots = lds + (active ? team : 0) * TS_NSLOTS;
+    t.j = j;
+    t.active = active;
+    t.coeff_h = {g.ws.coeff_h + I, N};
+    t.coeff_sig = {g.ws.coeff_sig + I, g.ws.n_sig};
+    t.pkx = ld_fp(g.ws.pkaff + I);
+    t.pky = ld_fp(g.ws.pkaff + N + I);
+    t.e = EMIT(g, id, off_miller);
+    if (!active) t.e.base = nullptr;
+    Fp2 f = team_miller_pv(t);
+    Emitter e_one = EMIT(g, id, off_is_one);
+    if (!active) e_one.base = nullptr;
+    bool res = team_final_exp_is_one(t, f, e_one);
+    int32_t* r = g.desc[id.s].result;
+    if (active && j == 0 && r) r[id.i] = step_result(g.desc[id.s], id.i, res);
+}
 // G2 allocation, six lanes per instance: the (r - 1) * sig chain of the subgroup check runs on the team machinery (points on
 // lanes 0..2), the allocation witnesses and the enforce_equal tail are single-lane work of lane 0
 __global__ __launch_bounds__(64) void k_g2_alloc_team(Group g) {
@@ -99,7 +126,9 @@ __global__ __launch_bounds__(64) void k_pairing_team_multi(Group gs, uint32_t K,
     if (active && j == 0 && r) r[id.i] = step_result(gs.desc[id.s], id.i, res);
 }
 void launch_pairing(const Group& g, const Modes& m, hipStream_t st) {
-    if (!m.pairing_team)
+    if (g.L.params_mode)
+        hipLaunchKernelGGL(k_pairing_team_pv, dim3((unsigned)((g.N + BLSW_TEAMS_PER_WAVE - 1) / BLSW_TEAMS_PER_WAVE)), dim3(64), 0, st, g);
+    else if (!m.pairing_team)
         hipLaunchKernelGGL(k_pairing, dim3((unsigned)((g.N + 63) / 64)), dim3(64), 0, st, g);
     else
         hipLaunchKernelGGL(k_pairing_team, dim3((unsigned)((g.N + BLSW_TEAMS_PER_WAVE - 1) / BLSW_TEAMS_PER_WAVE)), dim3(64), 0, st, g);

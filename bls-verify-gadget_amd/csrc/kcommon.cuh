@@ -50,10 +50,12 @@ inline blsw_layout_t staging_layout(const blsw_layout_t& L, const Modes& m) {
     uint32_t* f = &S.off_msg;
     const uint32_t* g = &L.off_msg;
     for (int k = 0; k < 15; k++) f[k] = g[k] > L.off_expand ? g[k] - L.sha_bits : g[k];
+    if (L.off_prep_g1 > L.off_expand) S.off_prep_g1 = L.off_prep_g1 - L.sha_bits;  // off_params_alloc lies in front of the expansion
     if (m.g2_team) {
         const uint32_t lo = L.off_sig_alloc, len = L.off_pk_not_zero - L.off_sig_alloc;
         for (int k = 0; k < 15; k++)
             if (f[k] > lo) f[k] -= len;
+        if (S.off_prep_g1 > lo) S.off_prep_g1 -= len;
         S.off_sig_alloc = L.n_witness - L.sha_bits - len;  // last rows of the staging coordinates
     }
     return S;
@@ -347,6 +349,7 @@ __global__ void k_prepare(Group g, int which);
 __global__ void k_prepare_inl(Group g, int which);
 __global__ void k_pairing(Group g);
 __global__ void k_pairing_team(Group g);
+__global__ void k_pairing_team_pv(Group g);
 __global__ void k_g2_alloc_team(Group g);
 __global__ void k_pairing_team_multi(Group gs, uint32_t K, uint64_t n_h);
 __global__ void k_decode(const uint8_t* __restrict__ pk48, const uint8_t* __restrict__ sig96, uint64_t n, uint64_t* pk_xy, uint64_t* sig_xy, int32_t* status);

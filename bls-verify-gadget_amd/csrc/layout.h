@@ -27,7 +27,10 @@ enum : uint32_t {
 // n_pairs (pk, msg) pairs; every statement of constraints.rs:97-125 becomes a loop over the pairs, allocation order
 // msgs, params, pks, sig as in constraints.rs:335-366). n_pairs == 1 is exactly the single-key circuit.
 inline uint32_t seg_miller(uint32_t n_pairs) { return 62 * 36 + 68 * 30 - 30 + 68 * 38 * n_pairs; }
-inline void make_layout(uint32_t msg_len, blsw_layout_t* L, uint32_t n_keys = 0, uint32_t n_pairs = 1) {
+// params_witness: ParametersVar::new_variable(Witness) (constraints.rs:198-211), single-key circuit only: the generator's allocation
+// segment follows the message (argument order of constraints.rs:346-364), prepare_g1(-g1) emits its to_affine in front of prepare(H),
+// and every ell of the (-g1, sig) pair has a variable point: 38 witnesses instead of 30, 2 instead of 0 in the first one (f = 1).
+inline void make_layout(uint32_t msg_len, blsw_layout_t* L, uint32_t n_keys = 0, uint32_t n_pairs = 1, bool params_witness = false) {
     std::vector<uint8_t> msg(msg_len ? msg_len : 1, 0);
     BitSink s;
     s.init(nullptr, 0);
@@ -55,6 +58,12 @@ inline void make_layout(uint32_t msg_len, blsw_layout_t* L, uint32_t n_keys = 0,
     L->stride_prep_pk = SEG_PREP_PK;
     L->off_msg = o;
     o += 8 * msg_len * K;
+    L->params_mode = params_witness ? 1 : 0;
+    L->off_params_alloc = L->off_prep_g1 = 0;
+    if (params_witness) {
+        L->off_params_alloc = o;
+        o += SEG_PK_ALLOC;
+    }
     L->off_pk_alloc = o;
     if (!n_keys) o += SEG_PK_ALLOC * K;
     L->off_sig_alloc = o;
@@ -74,6 +83,10 @@ inline void make_layout(uint32_t msg_len, blsw_layout_t* L, uint32_t n_keys = 0,
     L->off_add = L->off_map1 + SEG_MAP;
     L->off_cofactor = L->off_add + SEG_ADD;
     o += L->stride_hash * K;
+    if (params_witness) {
+        L->off_prep_g1 = o;
+        o += SEG_PREP_PK;
+    }
     L->off_prep_h = o;
     o += SEG_PREP_G2 * K;
     L->off_prep_pk = o;
@@ -81,7 +94,7 @@ inline void make_layout(uint32_t msg_len, blsw_layout_t* L, uint32_t n_keys = 0,
     L->off_prep_sig = o;
     o += SEG_PREP_G2;
     L->off_miller = o;
-    o += seg_miller(K);
+    o += seg_miller(K) + (params_witness ? 67 * 8 + 2 : 0);
     L->off_final_exp = o;
     o += SEG_FINAL_EXP;
     L->off_is_one = o;

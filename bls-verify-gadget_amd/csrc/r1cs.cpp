@@ -1200,11 +1200,13 @@ static std::vector<U8> msg_alloc(uint32_t msg_len) {
     return m;
 }
 // verify over K (pk, msg) pairs and one signature (K = 1: constraints.rs:90-128 statement by statement)
-static B verify_gadget(const std::vector<Pt<T1>>& pks, const std::vector<std::vector<U8>>& msgs, const Pt<T2>& sig) {
+// g1: the generator variable of a ParametersVar allocated as witnesses (constraints.rs:198-211), or nullptr for Constant parameters
+static B verify_gadget(const std::vector<Pt<T1>>& pks, const std::vector<std::vector<U8>>& msgs, const Pt<T2>& sig, const Pt<T1>* g1 = nullptr) {
     for (auto& pk : pks) b_enforce_equal_const(pt_is_eq<T1>(pk, pt_zero<T1>()), false);  // pk.enforce_not_equal(zero)
     G1Prep g1n = {v_const(K_G1_GEN_X()), v_const(K_G1_GEN_NEG_Y())};  // prepare_g1(-g1): a constant
     std::vector<Pt<T2>> hs;
     for (auto& m : msgs) hs.push_back(hash_to_g2(m));
+    if (g1) g1n = g1_prepare(pt_neg<T1>(*g1));  // g1.negate() is linear, prepare_g1 = to_affine (constraints.rs:107-108, 117)
     std::vector<G1Prep> ps = {g1n};
     std::vector<Coeffs> qs(1);
     for (auto& h : hs) qs.push_back(g2_prepare(h));
@@ -1213,7 +1215,7 @@ static B verify_gadget(const std::vector<Pt<T1>>& pks, const std::vector<std::ve
     V12 fe = final_exponentiation(miller_loop(ps, qs));
     return v12_is_eq(fe, v12_one());
 }
-static void circuit(uint32_t msg_len, uint32_t n_keys, uint32_t n_pairs) {
+static void circuit(uint32_t msg_len, uint32_t n_keys, uint32_t n_pairs, bool params_witness) {
     if (n_keys) {  // constraints.rs:378-441: keys, bitmap booleans, msg, params, sig, aggregate_verify
         std::vector<Pt<T1>> keys;
         for (uint32_t k = 0; k < n_keys; k++) keys.push_back(g1_new_witness());
@@ -1237,16 +1239,19 @@ static void circuit(uint32_t msg_len, uint32_t n_keys, uint32_t n_pairs) {
     }
     std::vector<std::vector<U8>> msgs;
     for (uint32_t j = 0; j < n_pairs; j++) msgs.push_back(msg_alloc(msg_len));
+    Pt<T1> g1 = pt_zero<T1>();
+    if (params_witness) g1 = g1_new_witness();  // ParametersVar::new_variable(Witness): argument order of constraints.rs:346-364
     std::vector<Pt<T1>> pks;
     for (uint32_t j = 0; j < n_pairs; j++) pks.push_back(g1_new_witness());
     Pt<T2> sig = g2_new_witness();
-    (void)verify_gadget(pks, msgs, sig);
+    (void)verify_gadget(pks, msgs, sig, params_witness ? &g1 : nullptr);
 }
 
-static int run(uint32_t msg_len, uint32_t n_keys, uint32_t n_pairs, Sys& sys) {
+static int run(uint32_t msg_len, uint32_t n_keys, uint32_t n_pairs, Sys& sys, uint32_t params_mode = 0) {
     if (msg_len > 65535 || n_keys > 65535 || (n_keys && n_pairs > 1) || n_pairs == 0 || n_pairs > 4096) return BLSW_ERR_ARG;
+    if (params_mode > 1 || (params_mode && (n_keys || n_pairs != 1))) return BLSW_ERR_ARG;
     S = &sys;
-    circuit(msg_len, n_keys, n_pairs);
+    circuit(msg_len, n_keys, n_pairs, params_mode == 1);
     sys.finish();
     S = nullptr;
     return BLSW_OK;
@@ -1256,7 +1261,7 @@ static int run(uint32_t msg_len, uint32_t n_keys, uint32_t n_pairs, Sys& sys) {
 struct Cache {
     std::mutex mu;
     bool valid = false;
-    uint32_t msg_len = 0, n_keys = 0, n_pairs = 0;
+    uint32_t msg_len = 0, n_keys = 0, n_pairs = 0, params_mode = 0;
     Sys sys;
 };
 static Cache& cache() {
@@ -1267,9 +1272,7 @@ static Cache& cache() {
 }  // namespace r1cs
 }  // namespace blsw
 
-extern "C" {
-
-int blsw_matrices_info(uint32_t msg_len, uint32_t n_keys, uint32_t n_pairs, blsw_matrices_info_t* out) {
+static int matrices_info(uint32_t msg_len, uint32_t n_keys, uint32_t n_pairs, uint32_t params_mode, blsw_matrices_info_t* out) {
     if (!out) return BLSW_ERR_ARG;
     blsw::r1cs::Cache& c = blsw::r1cs::cache();
     std::lock_guard<std::mutex> lock(c.mu);
@@ -1277,7 +1280,7 @@ int blsw_matrices_info(uint32_t msg_len, uint32_t n_keys, uint32_t n_pairs, blsw
     int rc;
     try {  // no exception crosses the ABI: a system that does not fit in memory is BLSW_ERR_WORKSPACE
         c.sys = blsw::r1cs::Sys();
-        rc = blsw::r1cs::run(msg_len, n_keys, n_pairs, c.sys);
+        rc = blsw::r1cs::run(msg_len, n_keys, n_pairs, c.sys, params_mode);
     } catch (...) {
         c.sys = blsw::r1cs::Sys();
         return BLSW_ERR_WORKSPACE;
@@ -1287,6 +1290,7 @@ int blsw_matrices_info(uint32_t msg_len, uint32_t n_keys, uint32_t n_pairs, blsw
     c.msg_len = msg_len;
     c.n_keys = n_keys;
     c.n_pairs = n_pairs;
+    c.params_mode = params_mode;
     out->n_constraints = c.sys.n_cons;
     out->n_instance_vars = 1;
     out->n_witness = c.sys.n_wit;
@@ -1294,18 +1298,18 @@ int blsw_matrices_info(uint32_t msg_len, uint32_t n_keys, uint32_t n_pairs, blsw
     return BLSW_OK;
 }
 
-int blsw_matrices_fill(uint32_t msg_len, uint32_t n_keys, uint32_t n_pairs, const blsw_matrices_info_t* info, blsw_matrices_t* out) {
+static int matrices_fill(uint32_t msg_len, uint32_t n_keys, uint32_t n_pairs, uint32_t params_mode, const blsw_matrices_info_t* info, blsw_matrices_t* out) {
     if (!info || !out) return BLSW_ERR_ARG;
     for (int m = 0; m < 3; m++)
         if (!out->row_ptr[m] || (info->nnz[m] && (!out->col[m] || !out->val[m]))) return BLSW_ERR_ARG;
     blsw::r1cs::Cache& c = blsw::r1cs::cache();
     std::lock_guard<std::mutex> lock(c.mu);
-    if (!(c.valid && c.msg_len == msg_len && c.n_keys == n_keys && c.n_pairs == n_pairs)) {
+    if (!(c.valid && c.msg_len == msg_len && c.n_keys == n_keys && c.n_pairs == n_pairs && c.params_mode == params_mode)) {
         c.valid = false;
         int rc;
         try {
             c.sys = blsw::r1cs::Sys();
-            rc = blsw::r1cs::run(msg_len, n_keys, n_pairs, c.sys);
+            rc = blsw::r1cs::run(msg_len, n_keys, n_pairs, c.sys, params_mode);
         } catch (...) {
             c.sys = blsw::r1cs::Sys();
             return BLSW_ERR_WORKSPACE;
@@ -1326,5 +1330,15 @@ int blsw_matrices_fill(uint32_t msg_len, uint32_t n_keys, uint32_t n_pairs, cons
     c.valid = false;
     c.sys = blsw::r1cs::Sys();  // release
     return ok ? BLSW_OK : BLSW_ERR_ARG;  // BLSW_ERR_ARG: `info` belongs to another circuit shape
+}
+
+extern "C" {
+int blsw_matrices_info(uint32_t msg_len, uint32_t n_keys, uint32_t n_pairs, blsw_matrices_info_t* out) { return matrices_info(msg_len, n_keys, n_pairs, 0, out); }
+int blsw_matrices_fill(uint32_t msg_len, uint32_t n_keys, uint32_t n_pairs, const blsw_matrices_info_t* info, blsw_matrices_t* out) {
+    return matrices_fill(msg_len, n_keys, n_pairs, 0, info, out);
+}
+int blsw_matrices_info_params(uint32_t msg_len, uint32_t params_mode, blsw_matrices_info_t* out) { return matrices_info(msg_len, 0, 1, params_mode, out); }
+int blsw_matrices_fill_params(uint32_t msg_len, uint32_t params_mode, const blsw_matrices_info_t* info, blsw_matrices_t* out) {
+    return matrices_fill(msg_len, 0, 1, params_mode, info, out);
 }
 }

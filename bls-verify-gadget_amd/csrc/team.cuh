@@ -192,6 +192,22 @@ BLSW_HD Fp2 team_first_f(uint32_t j, const Fp2* slots) {
     if (j == 4) return team_ld(slots, TS_XYC);
     return fp2_zero();
 }
+// the same with a VARIABLE point (ParametersVar allocated as witnesses): ell computes c1.c0 * p.x and c1.c1 * p.x — two product witnesses —
+// before mul_by_014 on the constant f = 1, which is linear. Pair slots as for TEAM_OP_ELLV: XH0 = c0, XH1 = c1, XPX = (p.x, 0), XYV = (p.y, 0).
+BLSW_HD Fp2 team_first_f_var(uint32_t j, const Fp2* slots, const Emitter& e) {
+    if (j == 0) return team_ld(slots, TS_XH0);
+    if (j == 1) {
+        const Fp2 c1 = team_ld(slots, TS_XH1);
+        const Fp px = team_ld(slots, TS_XPX).c0;
+        Fp2 r = {fp_mul(c1.c0, px), fp_mul(c1.c1, px)};
+        Emitter w = e;
+        w.put(r.c0);
+        w.put(r.c1);
+        return r;
+    }
+    if (j == 4) return team_ld(slots, TS_XYV);
+    return fp2_zero();
+}
 // line coefficients of step k into the slot file: lane j < 4 moves the sig pair, lane j - ... see TeamLanes / host
 // C: coefficient storage with ld(idx), as chain_prepare_g2 wrote it (4 Fp per step: c0.c0, c0.c1, c1.c0, c1.c1)
 template <class C>
@@ -244,6 +260,29 @@ BLSW_HD typename TEAM::Reg team_miller(TEAM& t) {
             }
             const TeamOp& T = ph == 0 ? TEAM_OP_SQR : ((ph & 1) ? TEAM_OP_ELLC : TEAM_OP_ELLV);
             f = t.exec_hot(T, f, f);
+            if (ph == 2 || ph == 4) k++;
+        }
+    }
+    return t.conj(f);
+}
+// miller_loop of the single-key circuit with ParametersVar allocated as witnesses: both pairs have a variable point, every ell is TEAM_OP_ELLV.
+// TEAM provides load_pair_sig(k) / load_pair_h(k) (pair slots XH0, XH1, XYV, XPX) and first_f_var() (2 witnesses, cursor advanced).
+template <class TEAM>
+BLSW_HD typename TEAM::Reg team_miller_pv(TEAM& t) {
+    typename TEAM::Reg f = t.zero();
+    uint32_t k = 0;
+#pragma unroll 1
+    for (int i = 62; i >= 0; i--) {
+        const int n_phases = ((BLSW_X_ABS >> i) & 1) ? 5 : 3;
+#pragma unroll 1
+        for (int ph = (i == 62 ? 1 : 0); ph < n_phases; ph++) {
+            if (ph == 1 || ph == 3) t.load_pair_sig(k);
+            if (ph == 2 || ph == 4) t.load_pair_h(k);
+            if (i == 62 && ph == 1) {
+                f = t.first_f_var();
+                continue;
+            }
+            f = t.exec_hot(ph == 0 ? TEAM_OP_SQR : TEAM_OP_ELLV, f, f);
             if (ph == 2 || ph == 4) k++;
         }
     }

@@ -25,4 +25,23 @@ struct TeamLanesMulti : TeamLanes<CoeffStrided> {
     }
 };
 
+// single-key circuit with ParametersVar allocated as witnesses (team_miller_pv): both pairs go through the pair slots
+struct TeamLanesPv : TeamLanes<CoeffStrided> {
+    Fp pkx, pky;  // lane 5 / lane 4 hold prepare_g1(pk)
+    BLSW_TEAM_DEV void load_pair_sig(uint32_t k) {
+        // prepare_g1(-g1) of the allocated generator: the to_affine of k_g1's params lanes yields these canonical values
+        if (active) team_load_pair_lane(j, slots, coeff_sig, k, K_G1_GEN_X(), K_G1_GEN_NEG_Y());
+        team_sync();
+    }
+    BLSW_TEAM_DEV void load_pair_h(uint32_t k) {
+        if (active) team_load_pair_lane(j, slots, coeff_h, k, pkx, pky);
+        team_sync();
+    }
+    BLSW_TEAM_DEV Reg first_f_var() {
+        Reg r = active ? team_first_f_var(j, slots, e) : fp2_zero();
+        e.pos += 2;
+        return r;
+    }
+};
+
 }  // namespace blsw

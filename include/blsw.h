@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define BLSW_ABI_VERSION 7
+#define BLSW_ABI_VERSION 8
 
 #define BLSW_OK 0
 #define BLSW_ERR_ARG 1
@@ -42,7 +42,7 @@ extern "C" {
 
 /* Segment table of one instance's witness vector for the circuit of src/constraints.rs:335-366
  * (msg witness bytes, params Constant, pk Witness, sig Witness, then verify). Offsets are in field elements.
- * 31 uint32_t fields; the Rust mirror in INTEGRATION.md must have the same fields in the same order. */
+ * 34 uint32_t fields; the Rust mirror in INTEGRATION.md must have the same fields in the same order. */
 typedef struct {
     uint32_t msg_len;
     uint32_t n_instance_vars; /* 1: the constant one (this gadget allocates no public input) */
@@ -56,6 +56,11 @@ typedef struct {
      * prep_h and prep_pk exist once per (pk, msg) pair; pair j's copy starts at off_* + j * stride_*. n_pairs = 1 and
      * strides = segment lengths for the single-key and aggregate circuits. */
     uint32_t n_pairs, stride_msg, stride_pk_alloc, stride_pk_not_zero, stride_hash, stride_prep_h, stride_prep_pk;
+    /* ParametersVar allocated with AllocationMode::Witness (blsw_layout_params; src/constraints.rs:198-211 takes any mode): the
+     * generator's G1Var::new_variable segment between msg and pk_alloc, and prepare_g1(-g1) (to_affine, 7 witnesses) in front of
+     * prep_h; the ell of the (-g1, sig) pair then has a variable point (68 x 8 witnesses more, 2 in the first one). All zero for
+     * the reference's own circuits (params Constant: no witnesses). */
+    uint32_t params_mode, off_params_alloc, off_prep_g1;
 } blsw_layout_t;
 
 /* layout(circuit shape) — replaces reading cs.num_witness_variables() after synthesis (constraints.rs:369-373). Host only. */
@@ -84,6 +89,10 @@ int blsw_aggregate_verify_batch(const uint64_t* d_pks_xy, const uint8_t* d_bitma
  * Direct mode on the device that owns `stream`. The call copies its descriptor to the device and SYNCHRONISES `stream` once
  * before issuing the kernels (asynchronous from there on); side streams are kept per host thread and device. */
 int blsw_layout_multi(uint32_t msg_len, uint32_t n_pairs, blsw_layout_t* out);
+/* single-key circuit with ParametersVar::new_variable(.., mode) (src/constraints.rs:198-211): params_mode 0 = Constant (blsw_layout),
+ * 1 = Witness. AllocationMode::Input would put the generator into instance_assignment, which this engine does not produce:
+ * BLSW_ERR_ARG. Host only. */
+int blsw_layout_params(uint32_t msg_len, uint32_t params_mode, blsw_layout_t* out);
 int blsw_verify_multi_workspace_bytes(uint64_t n, uint32_t msg_len, uint32_t n_pairs, uint64_t* bytes);
 int blsw_verify_multi_batch(const uint64_t* d_pks_xy, const uint8_t* d_msgs, uint32_t msg_len, uint32_t n_pairs, const uint64_t* d_sig_xy, uint64_t n,
                             uint64_t* d_witness, uint64_t witness_stride, int32_t* d_result, void* d_workspace, uint64_t workspace_bytes, void* stream);
@@ -133,6 +142,10 @@ typedef struct {
     uint32_t cofactor_mode; /* clear_cofactor2 (the longest chain) with the three 255-bit chunks of its scalar on three lanes and a join: half the
                               chain's latency for 38 % more products in it. 0 (default) = for launch groups of at most 8 192 lanes (latency-bound),
                               one chain per lane above; 1 = never; 2 = always. Same witnesses either way. */
+    uint32_t params_mode;  /* ParametersVar allocation (src/constraints.rs:198-211): 0 (default) Constant, as in every circuit of the reference;
+                              1 Witness (blsw_layout_params): the generator is allocated like a public key, prepare_g1(-g1) and the ell of
+                              the (-g1, sig) pair emit witnesses. Single-key circuit with the default kernel modes only (n_keys 0, n_pairs <= 1,
+                              pairing_mode 0). */
 } blsw_engine_options_t;
 /* the defaults (pure: the library reads no environment variable; measurement scripts set the fields they want to vary) */
 int blsw_engine_options_default(blsw_engine_options_t* out);
@@ -263,6 +276,9 @@ typedef struct {
 } blsw_matrices_t;
 int blsw_matrices_info(uint32_t msg_len, uint32_t n_keys, uint32_t n_pairs, blsw_matrices_info_t* out);
 int blsw_matrices_fill(uint32_t msg_len, uint32_t n_keys, uint32_t n_pairs, const blsw_matrices_info_t* info, blsw_matrices_t* out);
+/* the same for the single-key circuit of blsw_layout_params (params_mode 0 = the two calls above with n_keys 0, n_pairs 1) */
+int blsw_matrices_info_params(uint32_t msg_len, uint32_t params_mode, blsw_matrices_info_t* out);
+int blsw_matrices_fill_params(uint32_t msg_len, uint32_t params_mode, const blsw_matrices_info_t* info, blsw_matrices_t* out);
 
 /* Input decode (PublicKey::try_from / Signature::try_from -> deserialize_compressed, src/bls.rs:219-242, 316-339):
  *   d_pk48 [n][48], d_sig96 [n][96]  ZCash-format compressed points

@@ -572,11 +572,15 @@ inline Bool bls_verify_gadget(const G1Var& g1_generator, const G1Var& pk, const 
     }
     return res;
 }
-// the circuit of constraints.rs:335-366: msg witness bytes, params Constant, pk Witness, sig Witness, verify
-inline Bool bls_verify_circuit(const G1Aff& pk, const uint8_t* msg, size_t msg_len, const G2Aff& sig, VerifyTrace* tr = nullptr) {
+// the circuit of constraints.rs:335-366: msg witness bytes, params Constant, pk Witness, sig Witness, verify.
+// params_witness: ParametersVar::new_variable with AllocationMode::Witness instead (constraints.rs:198-211 takes any mode): the
+// generator goes through G1Var::new_variable like a public key, between the message and the key (argument order of :346-364).
+inline Bool bls_verify_circuit(const G1Aff& pk, const uint8_t* msg, size_t msg_len, const G2Aff& sig, VerifyTrace* tr = nullptr,
+                               bool params_witness = false) {
     CSREF.mark("msg");
     std::vector<U8> msg_var = u8witness_vec(msg, msg_len);
-    G1Var g1 = pv_constant<FpT>(g1_generator());
+    if (params_witness) CSREF.mark("params_alloc");
+    G1Var g1 = params_witness ? g1_new_witness(g1_generator()) : pv_constant<FpT>(g1_generator());
     CSREF.mark("pk_alloc");
     G1Var pk_var = g1_new_witness(pk);
     CSREF.mark("sig_alloc");

@@ -285,6 +285,40 @@ uint64_t orc_witness(const uint64_t* pk_xy, const uint8_t* msg, size_t msg_len, 
     }
     return n;
 }
+// the same circuit with the parameters allocated as witnesses (constraints.rs:198-211 with AllocationMode::Witness)
+uint64_t orc_witness_params(const uint64_t* pk_xy, const uint8_t* msg, size_t msg_len, const uint64_t* sig_xy, int params_witness,
+                            uint64_t* out_witness, uint64_t out_capacity_elems, uint64_t* n_constraints, int* result) {
+    ValueScope s;
+    Bool r = bls_verify_circuit(limbs_to_aff1(pk_xy), msg, msg_len, limbs_to_aff2(sig_xy), nullptr, params_witness != 0);
+    if (result) *result = r.val;
+    if (n_constraints) *n_constraints = s.cs.ncons;
+    uint64_t n = s.cs.wit.size();
+    if (out_witness) memcpy(out_witness, s.cs.wit.data(), std::min(n, out_capacity_elems) * 48);
+    return n;
+}
+uint64_t orc_layout_params(size_t msg_len, int params_witness, uint64_t* starts, uint64_t cap, char* names_buf, size_t names_cap, uint64_t* n_wit,
+                           uint64_t* n_cons) {
+    std::vector<uint8_t> msg(msg_len, 0);
+    G2Aff h = hash_to_g2_native(msg.data(), msg_len);
+    ValueScope s;
+    bls_verify_circuit(g1_generator(), msg.data(), msg_len, h, nullptr, params_witness != 0);
+    std::string names;
+    uint64_t k = 0;
+    for (auto& m : s.cs.marks) {
+        if (k < cap) starts[k] = m.second;
+        names += m.first;
+        names += '\n';
+        k++;
+    }
+    if (names_buf && names_cap) {
+        size_t c = std::min(names.size(), names_cap - 1);
+        memcpy(names_buf, names.data(), c);
+        names_buf[c] = 0;
+    }
+    if (n_wit) *n_wit = s.cs.wit.size();
+    if (n_cons) *n_cons = s.cs.ncons;
+    return k;
+}
 // batch, multi-threaded (CPU baseline): only results and the per-instance 64-bit FNV digest of the witness bytes
 static uint64_t fnv1a(const void* p, size_t n) {
     const uint8_t* b = (const uint8_t*)p;
@@ -421,7 +455,10 @@ int64_t orc_check_satisfied(const uint64_t* pk_xy, const uint8_t* msg, size_t ms
 // CSR export of the recorded R1CS (A, B, C) for a circuit SHAPE: (msg_len, n_keys, n_pairs) as the product's blsw_matrices_*.
 // The instance is a dummy (generator keys, sig = H(0...0)): the matrices do not depend on values. Two-phase: with null
 // arrays only the counts are returned in nnz[3]; returns the number of constraints.
+static uint64_t export_csr(ValueScope& s, uint64_t* nnz, uint64_t* n_witness, uint64_t** row_ptr, uint32_t** col, uint64_t** val);
+uint64_t orc_matrices_params(size_t msg_len, int params_witness, uint64_t* nnz, uint64_t* n_witness, uint64_t** row_ptr, uint32_t** col, uint64_t** val);
 uint64_t orc_matrices(size_t msg_len, uint64_t n_keys, uint64_t n_pairs, uint64_t* nnz, uint64_t* n_witness, uint64_t** row_ptr, uint32_t** col, uint64_t** val) {
+    if (!n_keys && n_pairs <= 1) return orc_matrices_params(msg_len, 0, nnz, n_witness, row_ptr, col, val);
     std::vector<uint8_t> msg(msg_len * (n_pairs ? n_pairs : 1) + 1, 0);
     G2Aff h = hash_to_g2_native(msg.data(), msg_len);
     ValueScope s(true);
@@ -432,8 +469,18 @@ uint64_t orc_matrices(size_t msg_len, uint64_t n_keys, uint64_t n_pairs, uint64_
     } else if (n_pairs > 1) {
         std::vector<G1Aff> pks(n_pairs, g1_generator());
         bls_verify_multi_circuit(pks, msg.data(), msg_len, h);
-    } else
-        bls_verify_circuit(g1_generator(), msg.data(), msg_len, h);
+    }
+    return export_csr(s, nnz, n_witness, row_ptr, col, val);
+}
+// the single-key circuit, parameters Constant or allocated as witnesses (constraints.rs:198-211)
+uint64_t orc_matrices_params(size_t msg_len, int params_witness, uint64_t* nnz, uint64_t* n_witness, uint64_t** row_ptr, uint32_t** col, uint64_t** val) {
+    std::vector<uint8_t> msg(msg_len + 1, 0);
+    G2Aff h = hash_to_g2_native(msg.data(), msg_len);
+    ValueScope s(true);
+    bls_verify_circuit(g1_generator(), msg.data(), msg_len, h, nullptr, params_witness != 0);
+    return export_csr(s, nnz, n_witness, row_ptr, col, val);
+}
+static uint64_t export_csr(ValueScope& s, uint64_t* nnz, uint64_t* n_witness, uint64_t** row_ptr, uint32_t** col, uint64_t** val) {
     const std::vector<LC>* M[3] = {&s.cs.A, &s.cs.B, &s.cs.C};
     for (int m = 0; m < 3; m++) {
         uint64_t k = 0;

@@ -68,6 +68,20 @@ struct TeamHost {
         for (uint32_t j = 0; j < 6; j++) r[j] = team_first_f(j, slots);
         return r;
     }
+    // ParametersVar allocated as witnesses (team_miller_pv)
+    Fp pkx, pky;
+    void load_pair_sig(uint32_t k) {
+        for (uint32_t j = 0; j < 6; j++) team_load_pair_lane(j, slots, coeff_sig, k, K_G1_GEN_X(), K_G1_GEN_NEG_Y());
+    }
+    void load_pair_h(uint32_t k) {
+        for (uint32_t j = 0; j < 6; j++) team_load_pair_lane(j, slots, coeff_h, k, pkx, pky);
+    }
+    Reg first_f_var() {
+        Reg r;
+        for (uint32_t j = 0; j < 6; j++) r[j] = team_first_f_var(j, slots, e);
+        e.pos += 2;
+        return r;
+    }
     // N+1-pair product: per-pair inputs
     const std::vector<std::vector<Fp>>* pair_coeff = nullptr;
     const std::vector<G1ChainOut>* pair_pk = nullptr;
@@ -127,6 +141,19 @@ static void g2_alloc_segment(uint32_t* base, const blsw_layout_t& L, const Fp2& 
 }
 
 static bool pairing_segment(uint32_t* base, const blsw_layout_t& L, const Fp& ax, const Fp& ay, Fp* cs, Fp* ch) {
+    if (L.params_mode) {  // six-lane program only (k_pairing_team_pv)
+        TeamHost t;
+        t.coeff_sig = CoeffLinear{cs};
+        t.coeff_h = CoeffLinear{ch};
+        t.e = {base, L.off_miller};
+        t.pkx = ax;
+        t.pky = ay;
+        TeamHost::Reg f = team_miller_pv(t);
+        if (t.e.pos != L.off_final_exp) return false;
+        bool r = team_final_exp_is_one(t, f, Emitter{base, L.off_is_one});
+        if (t.e.pos != L.off_is_one) return false;
+        return r;
+    }
     if (!g_use_team) {
         Fp12 fm = chain_miller({base, L.off_miller}, ax, ay, CoeffLinear{cs}, CoeffLinear{ch});
         return chain_final_exp_is_one({base, L.off_final_exp}, {base, L.off_is_one}, fm);
@@ -164,10 +191,27 @@ int hostsim_layout(uint32_t msg_len, blsw_layout_t* L) {
     return 0;
 }
 // out: n_witness * 6 u64. returns gadget result (0/1); seg_ends (optional, 16 u32): cursor after each chain
+int hostsim_witness_params(const uint64_t* pk_xy, const uint8_t* msg, uint32_t msg_len, const uint64_t* sig_xy, uint32_t params_mode, uint64_t* out);
 int hostsim_witness(const uint64_t* pk_xy, const uint8_t* msg, uint32_t msg_len, const uint64_t* sig_xy, uint64_t* out, uint32_t* seg_ends) {
+    (void)seg_ends;
+    return hostsim_witness_params(pk_xy, msg, msg_len, sig_xy, 0, out);
+}
+int hostsim_layout_params(uint32_t msg_len, uint32_t params_mode, blsw_layout_t* L) {
+    make_layout(msg_len, L, 0, 1, params_mode == 1);
+    return 0;
+}
+// params_mode 1: ParametersVar::new_variable(Witness) — the statements of k_g1's params lanes and k_pairing_team_pv
+int hostsim_witness_params(const uint64_t* pk_xy, const uint8_t* msg, uint32_t msg_len, const uint64_t* sig_xy, uint32_t params_mode, uint64_t* out) {
     blsw_layout_t L;
-    make_layout(msg_len, &L);
+    make_layout(msg_len, &L, 0, 1, params_mode == 1);
     uint32_t* base = reinterpret_cast<uint32_t*>(out);
+    if (L.params_mode) {
+        Emitter none = {nullptr, 0};
+        Proj<OpsFp> g = chain_g1_alloc_only({base, L.off_params_alloc}, K_G1_GEN_X(), fp_neg(K_G1_GEN_NEG_Y()));
+        g.y = fp_neg(g.y);
+        G1ChainOut gn = chain_g1_post(none, {base, L.off_prep_g1}, g);
+        if (memcmp(gn.ax.l, K_G1_GEN_X().l, 48) || memcmp(gn.ay.l, K_G1_GEN_NEG_Y().l, 48)) return -2;
+    }
     // msg bits (UInt8::new_witness_vec)
     Emitter em = {base, L.off_msg};
     for (uint32_t i = 0; i < msg_len; i++)
@@ -197,7 +241,6 @@ int hostsim_witness(const uint64_t* pk_xy, const uint8_t* msg, uint32_t msg_len,
     Proj<OpsFp2> sp = {sinf ? fp2_zero() : sx, sinf ? fp2_one() : sy, sinf ? fp2_zero() : fp2_one()};
     chain_prepare_g2({base, L.off_prep_sig}, sp, CoeffLinear{cs.data()});
     bool res = pairing_segment(base, L, g1.ax, g1.ay, cs.data(), ch.data());
-    (void)seg_ends;
     return res ? 1 : 0;
 }
 // N+1-pair product circuit for one instance (blsw_verify_multi_batch): pks_xy [K][12], msgs [K][msg_len]

@@ -11,7 +11,8 @@ u64p = ctypes.POINTER(ctypes.c_uint64)
 _FIELDS = (
     "msg_len n_instance_vars n_witness sha_bits off_msg off_pk_alloc off_sig_alloc off_pk_not_zero off_expand off_map0 off_map1 "
     "off_add off_cofactor off_prep_h off_prep_pk off_prep_sig off_miller off_final_exp off_is_one n_keys off_keys off_bitmap off_count off_agg "
-    "n_pairs stride_msg stride_pk_alloc stride_pk_not_zero stride_hash stride_prep_h stride_prep_pk"
+    "n_pairs stride_msg stride_pk_alloc stride_pk_not_zero stride_hash stride_prep_h stride_prep_pk "
+    "params_mode off_params_alloc off_prep_g1"
 ).split()
 
 
@@ -30,19 +31,20 @@ def load():
     return _lib
 
 
-def layout(msg_len):
+def layout(msg_len, params_mode=0):
     L = Lay()
-    load().hostsim_layout(msg_len, ctypes.byref(L))
+    load().hostsim_layout_params(msg_len, params_mode, ctypes.byref(L))
     return {n: getattr(L, n) for n in _FIELDS}
 
 
-def witness(pk_xy, msg, sig_xy):
+def witness(pk_xy, msg, sig_xy, params_mode=0):
+    """params_mode 1: ParametersVar allocated as witnesses (constraints.rs:198-211 with AllocationMode::Witness)"""
     pk_xy = np.ascontiguousarray(pk_xy, dtype=np.uint64)
     sig_xy = np.ascontiguousarray(sig_xy, dtype=np.uint64)
-    lay = layout(len(msg))
+    lay = layout(len(msg), params_mode)
     out = np.zeros((lay["n_witness"], 6), dtype=np.uint64)
     buf = (ctypes.c_uint8 * max(1, len(msg))).from_buffer_copy(bytes(msg) if len(msg) else b"\0")
-    r = load().hostsim_witness(pk_xy.ctypes.data_as(u64p), buf, len(msg), sig_xy.ctypes.data_as(u64p), out.ctypes.data_as(u64p), None)
+    r = load().hostsim_witness_params(pk_xy.ctypes.data_as(u64p), buf, len(msg), sig_xy.ctypes.data_as(u64p), params_mode, out.ctypes.data_as(u64p))
     return r, out
 
 

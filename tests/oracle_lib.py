@@ -107,11 +107,21 @@ class Oracle:
         rc = self.lib.orc_aggregate_g2(self._buf(b"".join(sigs)), ctypes.c_size_t(len(sigs)), out)
         return None if rc else bytes(out)
 
-    def witness(self, pk_xy, msg, sig_xy, want_vector=True):
+    def witness(self, pk_xy, msg, sig_xy, want_vector=True, params_mode=0):
         pk_xy = np.ascontiguousarray(pk_xy, dtype=np.uint64)
         sig_xy = np.ascontiguousarray(sig_xy, dtype=np.uint64)
         ncons = ctypes.c_uint64(0)
         res = ctypes.c_int(0)
+        if params_mode:  # ParametersVar allocated as witnesses (constraints.rs:198-211 with AllocationMode::Witness)
+            self.lib.orc_witness_params.restype = ctypes.c_uint64
+            call = lambda w, cap: self.lib.orc_witness_params(pk_xy.ctypes.data_as(u64p), self._buf(msg), ctypes.c_size_t(len(msg)), sig_xy.ctypes.data_as(u64p),
+                                                              ctypes.c_int(params_mode), w, ctypes.c_uint64(cap), ctypes.byref(ncons), ctypes.byref(res))
+            n = call(None, 0)
+            if not want_vector:
+                return n, ncons.value, bool(res.value), None
+            w = np.zeros((n, 6), dtype=np.uint64)
+            call(w.ctypes.data_as(u64p), n)
+            return n, ncons.value, bool(res.value), w
         n = self.lib.orc_witness(pk_xy.ctypes.data_as(u64p), self._buf(msg), ctypes.c_size_t(len(msg)), sig_xy.ctypes.data_as(u64p), None, ctypes.c_uint64(0), ctypes.byref(ncons), ctypes.byref(res))
         if not want_vector:
             return n, ncons.value, bool(res.value), None
@@ -159,12 +169,18 @@ class Oracle:
             self.lib.orc_witness_multi(*args(w.ctypes.data_as(u64p), n))
         return n, bool(res.value), marks, w
 
-    def matrices(self, msg_len=32, n_keys=0, n_pairs=1):
+    def matrices(self, msg_len=32, n_keys=0, n_pairs=1, params_mode=0):
         """(n_constraints, n_witness, [(row_ptr, col, val) for A, B, C]) of the oracle's recorded R1CS for a circuit shape"""
         nnz = (ctypes.c_uint64 * 3)()
         nw = ctypes.c_uint64(0)
         self.lib.orc_matrices.restype = ctypes.c_uint64
-        nc = self.lib.orc_matrices(ctypes.c_size_t(msg_len), ctypes.c_uint64(n_keys), ctypes.c_uint64(n_pairs), nnz, ctypes.byref(nw), None, None, None)
+        self.lib.orc_matrices_params.restype = ctypes.c_uint64
+        if params_mode:
+            assert n_keys == 0 and n_pairs == 1
+            run = lambda a, b, c: self.lib.orc_matrices_params(ctypes.c_size_t(msg_len), ctypes.c_int(params_mode), nnz, ctypes.byref(nw), a, b, c)
+        else:
+            run = lambda a, b, c: self.lib.orc_matrices(ctypes.c_size_t(msg_len), ctypes.c_uint64(n_keys), ctypes.c_uint64(n_pairs), nnz, ctypes.byref(nw), a, b, c)
+        nc = run(None, None, None)
         rp = [np.zeros(nc + 1, dtype=np.uint64) for _ in range(3)]
         col = [np.zeros(nnz[m], dtype=np.uint32) for m in range(3)]
         val = [np.zeros((nnz[m], 6), dtype=np.uint64) for m in range(3)]
@@ -172,7 +188,7 @@ class Oracle:
         a_rp = (u64p * 3)(*[x.ctypes.data_as(u64p) for x in rp])
         a_col = (u32p * 3)(*[x.ctypes.data_as(u32p) for x in col])
         a_val = (u64p * 3)(*[x.ctypes.data_as(u64p) for x in val])
-        self.lib.orc_matrices(ctypes.c_size_t(msg_len), ctypes.c_uint64(n_keys), ctypes.c_uint64(n_pairs), nnz, ctypes.byref(nw), a_rp, a_col, a_val)
+        run(a_rp, a_col, a_val)
         return nc, nw.value, list(zip(rp, col, val))
 
     def witness_batch(self, pk_xy, msgs, sig_xy, threads=1, want_digests=True):
@@ -187,12 +203,13 @@ class Oracle:
             results.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), digests.ctypes.data_as(u64p) if want_digests else None)
         return results.astype(bool), digests
 
-    def layout(self, msg_len=32):
+    def layout(self, msg_len=32, params_mode=0):
         starts = (ctypes.c_uint64 * 64)()
         names = ctypes.create_string_buffer(4096)
         nw = ctypes.c_uint64(0)
         nc = ctypes.c_uint64(0)
-        k = self.lib.orc_layout(ctypes.c_size_t(msg_len), starts, ctypes.c_uint64(64), names, ctypes.c_size_t(4096), ctypes.byref(nw), ctypes.byref(nc))
+        self.lib.orc_layout_params.restype = ctypes.c_uint64
+        k = self.lib.orc_layout_params(ctypes.c_size_t(msg_len), ctypes.c_int(params_mode), starts, ctypes.c_uint64(64), names, ctypes.c_size_t(4096), ctypes.byref(nw), ctypes.byref(nc))
         nm = names.value.decode().split("\n")[:k]
         return [(nm[i], starts[i]) for i in range(k)], nw.value, nc.value
 

@@ -29,6 +29,27 @@ def test_layout_matches_oracle_trace(oracle, msg_len):
             assert lay[ORACLE_TO_ABI[name]] == start, name
 
 
+def test_params_witness_layout_and_witness(oracle):
+    """ParametersVar allocated with AllocationMode::Witness (constraints.rs:198-211): segment table against the oracle's trace, then the
+    device chain code (k_g1's params lanes, team_miller_pv) on the host against the oracle's vector — a valid and a tampered instance."""
+    marks, n_wit, n_cons = oracle.layout(32, params_mode=1)
+    lay = hostsim_lib.layout(32, params_mode=1)
+    names = dict(ORACLE_TO_ABI, **{"params_alloc": "off_params_alloc", "prepare.g1_neg": "off_prep_g1"})
+    assert lay["n_witness"] == n_wit and lay["params_mode"] == 1
+    for name, start in marks:
+        if name in names:
+            assert lay[names[name]] == start, name
+    pk, msg, sig, expect = synth.make_batch(oracle, 16)
+    for i in (3, 15):
+        n, _, res, w = oracle.witness(pk[i], msg[i].tobytes(), sig[i], params_mode=1)
+        r, out = hostsim_lib.witness(pk[i], msg[i].tobytes(), sig[i], params_mode=1)
+        assert n == out.shape[0] and bool(r) == res == bool(expect[i])
+        bad = np.nonzero((w != out).any(axis=1))[0]
+        assert len(bad) == 0, "first mismatching witness index %d" % bad[0]
+    # Constant parameters: all three fields are zero and the table is the reference circuit's
+    assert hostsim_lib.layout(32)["params_mode"] == 0 and hostsim_lib.layout(32)["off_prep_g1"] == 0
+
+
 def test_library_exports_and_layout():
     pkg = importlib.import_module("bls-verify-gadget_amd")
     L = pkg.lib()

@@ -212,6 +212,78 @@ def test_engine_grouped_batches(pkg, oracle):
     eng.close()
 
 
+def test_params_allocated_as_witnesses(pkg, oracle):
+    """ParametersVar::new_variable with AllocationMode::Witness (constraints.rs:198-211 takes any mode; the reference's tests use
+    Constant): the generator's G1Var::new_variable segment, prepare_g1(-g1) and the variable-point ell of the (-g1, sig) pair.
+    Direct mode (70 instances: a full wave and a ragged one, every vector against the oracle), then the grouped engine (staging,
+    streamed placement, compact wire form expanded by a second engine), with g2_mode team as well (its staging coordinates move
+    the new segments); a gadget built for Constant parameters refuses a Witness ParametersVar."""
+    import torch
+
+    dev = torch.device("cuda:0")
+    n = 70
+    pk, msg, sig, expect = synth.make_batch(oracle, n)
+    t = lambda a: torch.from_numpy(a.view(np.int64) if a.dtype == np.uint64 else a).to(dev)
+
+    def compare(got, w, idx, lo=0):
+        for i in idx:
+            nw, _, r, ow = oracle.witness(pk[lo + i], msg[lo + i].tobytes(), sig[lo + i], params_mode=1)
+            assert r == bool(got[i]) and w.shape[1] == nw
+            bad = np.nonzero((ow != w[i]).any(axis=1))[0]
+            assert len(bad) == 0, "instance %d: first mismatching witness index %d" % (lo + i, bad[0])
+
+    g = pkg.BlsSignatureVerifyGadget(n, 32, device=dev, params_mode="witness")
+    assert g.layout["params_mode"] == 1 and g.n_witness == pkg.layout(32)["n_witness"] + 1942 + 7 + 67 * 8 + 2
+    res = g.verify(pkg.ParametersVar.new_witness(), pkg.PublicKeyVar.new_witness(t(pk)), t(msg), pkg.SignatureVar.new_witness(t(sig)))
+    torch.cuda.synchronize()
+    got = res.cpu().numpy().astype(bool)
+    assert np.array_equal(got, expect)
+    compare(got, g.witness.cpu().numpy().view(np.uint64), range(n))
+    with pytest.raises(pkg.BlswError):
+        g.verify(pkg.ParametersVar.new_constant(), pkg.PublicKeyVar.new_witness(t(pk)), t(msg), pkg.SignatureVar.new_witness(t(sig)))
+    g.engine.close()
+    # grouped engine: 3 steps of 20 instances, groups of 2; the last step leaves in compact form and is expanded by a direct-mode engine
+    ns, steps = 20, 3
+    for opts in (dict(), dict(g2_mode="team")):
+        eng = pkg.WitnessEngine(ns, 32, max_steps=2, device=dev, n_buffers=2, params_mode=1, **opts)
+        outs, ress, keep = [], [], []
+        for k in range(steps):
+            sl = slice(k * ns, (k + 1) * ns)
+            d = (t(pk[sl]), t(sig[sl]), t(msg[sl]))
+            w, r = eng.new_witness_tensor(), torch.empty(ns, dtype=torch.int32, device=dev)
+            eng.submit(d[0], d[1], d[2], witness=w, result=r)
+            outs.append(w)
+            ress.append(r)
+            keep.append(d)
+        eng.flush()
+        torch.cuda.synchronize()
+        for k in range(steps):
+            got = ress[k].cpu().numpy().astype(bool)
+            assert np.array_equal(got, expect[k * ns:(k + 1) * ns])
+            compare(got, outs[k].cpu().numpy().view(np.uint64), (0, 7, ns - 1), lo=k * ns)
+        eng.close()
+    # compact wire form: one step of 64 instances leaves as bit words + staged rows and is expanded by a receiving engine of the same circuit
+    eng = pkg.WitnessEngine(64, 32, max_steps=2, device=dev, n_buffers=2, params_mode=1)
+    recv = pkg.WitnessEngine(64, 32, max_steps=2, device=dev, n_buffers=1, params_mode=1)
+    d = (t(pk[:64]), t(sig[:64]), t(msg[:64]))
+    comp, plain = eng.new_compact_buffer(1), eng.new_witness_tensor()
+    r1, r2 = torch.empty(64, dtype=torch.int32, device=dev), torch.empty(64, dtype=torch.int32, device=dev)
+    eng.submit_compact(d[0], d[1], d[2], comp[0], result=r1)
+    eng.submit(d[0], d[1], d[2], witness=plain, result=r2)
+    eng.flush()
+    torch.cuda.synchronize()
+    out = recv.new_witness_tensor()
+    out.fill_(-1)
+    recv.expand_compact(comp[0], out)
+    torch.cuda.synchronize()
+    assert torch.equal(out, plain) and torch.equal(r1, r2)
+    compare(r2.cpu().numpy().astype(bool), plain.cpu().numpy().view(np.uint64), (5, 63))
+    eng.close()
+    recv.close()
+    with pytest.raises(pkg.BlswError):  # the aggregate and N+1-pair circuits take Constant parameters only
+        pkg.WitnessEngine(8, 32, device=dev, n_keys=4, params_mode=1)
+
+
 def test_hash_to_g2_batch(pkg, oracle):
     import torch
 

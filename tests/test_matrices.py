@@ -37,6 +37,22 @@ def test_product_matrices_equal_the_oracles(pkg, oracle, shape):
     assert val.any(axis=1).all()
 
 
+def test_params_witness_matrices_equal_the_oracles(pkg, oracle):
+    """ParametersVar::new_variable(Witness) (constraints.rs:198-211): the generator's allocation, prepare_g1(-g1) and the variable-point
+    ell of the (-g1, sig) pair, row by row against the oracle; a witness vector of that circuit satisfies the system."""
+    nc, nw, M = oracle.matrices(32, params_mode=1)
+    P = pkg.matrices(32, params_mode="witness")
+    assert (P["n_constraints"], P["n_witness"], P["n_instance_vars"]) == (nc, nw, 1)
+    assert pkg.layout(32, params_mode=1)["n_witness"] == nw == pkg.layout(32)["n_witness"] + 1942 + 7 + 67 * 8 + 2
+    for m, name in enumerate("ABC"):
+        assert _same(M[m], P[name]), "matrix %s differs" % name
+    pk, msg, sig, expect = synth.make_batch(oracle, 16)
+    r, w = hostsim_lib.witness(pk[5], msg[5].tobytes(), sig[5], params_mode=1)
+    assert r == 1 and hostsim_lib.r1cs_check(P, w) == -1
+    # the Constant-parameters system is a different one
+    assert pkg.matrices(32)["n_constraints"] != nc
+
+
 def test_witness_vectors_satisfy_the_product_matrices(pkg, oracle):
     P = pkg.matrices(32, 0, 1)
     pk, msg, sig, expect = synth.make_batch(oracle, 16)
@@ -58,5 +74,6 @@ def test_argument_checks(pkg):
 
     info = pkg.blsw_matrices_info_t()
     assert pkg.lib().blsw_matrices_info(32, 2, 2, ctypes.byref(info)) == 1  # aggregate and multi together
+    assert pkg.lib().blsw_matrices_info_params(32, 2, ctypes.byref(info)) == 1  # AllocationMode::Input is not produced
     assert pkg.lib().blsw_matrices_info(32, 0, 0, ctypes.byref(info)) == 1
     assert pkg.lib().blsw_matrices_info(32, 0, 1, None) == 1
