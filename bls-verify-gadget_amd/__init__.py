@@ -112,6 +112,8 @@ def lib():
         L.blsw_aggregate_workspace_bytes.argtypes = [u64, u32, u32, ctypes.POINTER(u64)]
         L.blsw_aggregate_verify_batch.argtypes = [vp, vp, u32, vp, vp, u32, u64, vp, u64, vp, vp, vp, u64, vp]
         L.blsw_decode_batch.argtypes = [vp, vp, u64, vp, vp, vp, vp]
+        L.blsw_aggregate_points_workspace_bytes.argtypes = [u32, u64, u32, ctypes.POINTER(u64)]
+        L.blsw_aggregate_points_batch.argtypes = [u32, vp, u32, u64, vp, vp, vp, u64, vp]
         L.blsw_sign_batch.argtypes = [vp, vp, u32, u64, vp, vp, vp, vp, vp, vp, u64, vp]
         L.blsw_microbench.argtypes = [ctypes.c_int, u32, u32, ctypes.POINTER(ctypes.c_double)]
         _lib = L
@@ -123,7 +125,7 @@ EXPORTED_SYMBOLS = ["blsw_version", "blsw_layout", "blsw_engine_options_default"
                     "blsw_engine_output_consumed", "blsw_engine_compact_bytes", "blsw_engine_submit_compact", "blsw_engine_submit_aggregate_compact", "blsw_engine_expand_compact", "blsw_engine_expand_stats", "blsw_witness_digest", "blsw_hash_to_g2_workspace_bytes", "blsw_hash_to_g2_batch",
                     "blsw_decode_batch", "blsw_layout_aggregate", "blsw_aggregate_workspace_bytes", "blsw_aggregate_verify_batch", "blsw_layout_multi",
                     "blsw_verify_multi_workspace_bytes", "blsw_verify_multi_batch", "blsw_matrices_info", "blsw_matrices_fill", "blsw_sign_batch", "blsw_microbench",
-                    "blsw_layout_params", "blsw_matrices_info_params", "blsw_matrices_fill_params"]
+                    "blsw_layout_params", "blsw_matrices_info_params", "blsw_matrices_fill_params", "blsw_aggregate_points_workspace_bytes", "blsw_aggregate_points_batch"]
 
 
 PARAMS_MODES = {"constant": 0, "witness": 1}
@@ -494,6 +496,39 @@ def decode_batch(pk48, sig96):
     if rc:
         raise BlswError("blsw_decode_batch failed: %d" % rc)
     return pk_xy, sig_xy, status
+
+
+def aggregate_points(group, points):
+    """Signature::aggregate (group 2: [n, k, 96] uint8) / PublicKey::aggregate (group 1: [n, k, 48]) for n lists of k compressed points
+    (bls.rs:288-300, 183-195; tests/tests.rs:270-294): returns (sum [n, 96 or 48] uint8, status [n] int32 — ST_OK or the status of the first
+    point of the list that does not decode). An empty list (k == 0) is None, as in the reference."""
+    torch = _require_cuda()
+    nbytes = {1: 48, 2: 96}[group]
+    n, k = points.shape[0], points.shape[1]
+    assert points.shape == (n, k, nbytes) and points.dtype == torch.uint8 and points.is_contiguous()
+    if k == 0:
+        return None
+    wb = ctypes.c_uint64(0)
+    rc = lib().blsw_aggregate_points_workspace_bytes(group, n, k, ctypes.byref(wb))
+    if rc:
+        raise BlswError("blsw_aggregate_points_workspace_bytes failed: %d" % rc)
+    ws = torch.empty(wb.value, dtype=torch.uint8, device=points.device)
+    out = torch.empty((n, nbytes), dtype=torch.uint8, device=points.device)
+    status = torch.empty(n, dtype=torch.int32, device=points.device)
+    rc = lib().blsw_aggregate_points_batch(group, points.data_ptr(), k, n, out.data_ptr(), status.data_ptr(), ws.data_ptr(), ws.numel(),
+                                           torch.cuda.current_stream(points.device).cuda_stream)
+    if rc:
+        raise BlswError("blsw_aggregate_points_batch failed: %d" % rc)
+    torch.cuda.synchronize(points.device)
+    return out, status
+
+
+def aggregate_signatures(sig96):
+    return aggregate_points(2, sig96)
+
+
+def aggregate_public_keys(pk48):
+    return aggregate_points(1, pk48)
 
 
 def verify_bytes_batch(pk48, msg, sig96):

@@ -1061,6 +1061,27 @@ int blsw_decode_batch(const uint8_t* d_pk48, const uint8_t* d_sig96, uint64_t n,
     hipLaunchKernelGGL(k_decode, dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, st, d_pk48, d_sig96, n, d_pk_xy, d_sig_xy, d_status);
     return hip_ok(hipGetLastError(), "launch");
 }
+// Signature::aggregate / PublicKey::aggregate for n lists of k compressed points (bls.rs:288-300, 183-195)
+int blsw_aggregate_points_workspace_bytes(uint32_t group, uint64_t n, uint32_t k, uint64_t* bytes) {
+    if (!bytes || (group != 1 && group != 2) || n == 0 || k == 0 || n > 0x3fffffffu / k) return BLSW_ERR_ARG;
+    const uint64_t m = n * k;
+    *bytes = align_up(m * (group == 1 ? 2 : 4) * sizeof(Fp), 256) + align_up(m * sizeof(int32_t), 256);
+    return BLSW_OK;
+}
+int blsw_aggregate_points_batch(uint32_t group, const uint8_t* d_in, uint32_t k, uint64_t n, uint8_t* d_out, int32_t* d_status, void* d_workspace,
+                                uint64_t workspace_bytes, void* stream_) {
+    uint64_t need = 0;
+    if (!d_in || !d_out || !d_status || !d_workspace || blsw_aggregate_points_workspace_bytes(group, n, k, &need)) return BLSW_ERR_ARG;
+    if (workspace_bytes < need) return BLSW_ERR_WORKSPACE;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream_);
+    DeviceGuard guard(stream_device(st));
+    const uint64_t m = n * k;
+    Fp* xy = reinterpret_cast<Fp*>(d_workspace);
+    int32_t* pst = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(d_workspace) + align_up(m * (group == 1 ? 2 : 4) * sizeof(Fp), 256));
+    hipLaunchKernelGGL(k_decode_points, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, st, group, d_in, m, xy, pst);
+    hipLaunchKernelGGL(k_sum_points, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, group, (const Fp*)xy, (const int32_t*)pst, k, n, d_out, d_status);
+    return hip_ok(hipGetLastError(), "launch");
+}
 int blsw_hash_to_g2_workspace_bytes(uint64_t n, uint32_t msg_len, uint64_t* bytes) {
     if (!bytes || n == 0 || msg_len > 65535) return BLSW_ERR_ARG;
     blsw_layout_t L;

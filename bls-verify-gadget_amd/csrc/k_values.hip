@@ -77,6 +77,66 @@ __global__ __launch_bounds__(64) void k_decode(const uint8_t* __restrict__ pk48,
     }
 }
 
+// Signature::aggregate / PublicKey::aggregate (bls.rs:288-300, 183-195). Phase 1: one lane per compressed point (try_from: flags, x < p, on
+// curve, subgroup), affine coordinates and status into the workspace. Phase 2: one lane per list adds its k points and serialises the sum.
+__global__ __launch_bounds__(64) void k_decode_points(uint32_t group, const uint8_t* __restrict__ in, uint64_t m, Fp* xy, int32_t* st) {
+    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m) return;
+    if (group == 1) {
+        Fp x, y;
+        st[t] = g1_decode(in + t * 48, x, y);
+        st_fp(xy + 2 * t, x);
+        st_fp(xy + 2 * t + 1, y);
+    } else {
+        Fp2 x, y;
+        st[t] = g2_decode(in + t * 96, x, y);
+        st_fp(xy + 4 * t, x.c0);
+        st_fp(xy + 4 * t + 1, x.c1);
+        st_fp(xy + 4 * t + 2, y.c0);
+        st_fp(xy + 4 * t + 3, y.c1);
+    }
+}
+__global__ __launch_bounds__(64) void k_sum_points(uint32_t group, const Fp* __restrict__ xy, const int32_t* __restrict__ pst, uint32_t k, uint64_t n, uint8_t* out,
+                                                   int32_t* status) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int bad = DEC_OK;
+    for (uint32_t j = 0; j < k && bad == DEC_OK; j++) {
+        const int s = pst[i * k + j];
+        if (s != DEC_OK && s != DEC_IDENTITY) bad = s;
+    }
+    status[i] = bad;
+    const uint32_t bytes = group == 1 ? 48u : 96u;
+    uint8_t* o = out + i * bytes;
+    if (bad != DEC_OK) {
+        for (uint32_t b = 0; b < bytes; b++) o[b] = 0;
+        return;
+    }
+    if (group == 1) {
+        Jac1v acc = {fp_one(), fp_one(), fp_zero()};
+#pragma unroll 1
+        for (uint32_t j = 0; j < k; j++) {
+            if (pst[i * k + j] == DEC_IDENTITY) continue;
+            const Fp* p = xy + 2 * (i * k + j);
+            acc = jac1v_add_mixed(acc, ld_fp(p), ld_fp(p + 1));
+        }
+        const bool inf = fp_is_zero(acc.z);
+        const Fp zi = fp_inv(acc.z), zi2 = fp_sqr(zi);
+        g1_encode(fp_mul(acc.x, zi2), fp_mul(acc.y, fp_mul(zi2, zi)), inf, o);
+    } else {
+        Jac2 acc = {fp2_one(), fp2_one(), fp2_zero()};
+#pragma unroll 1
+        for (uint32_t j = 0; j < k; j++) {
+            if (pst[i * k + j] == DEC_IDENTITY) continue;
+            const Fp* p = xy + 4 * (i * k + j);
+            acc = jac2_add_mixed(acc, {ld_fp(p), ld_fp(p + 1)}, {ld_fp(p + 2), ld_fp(p + 3)});
+        }
+        const bool inf = fp2_is_zero(acc.z);
+        const Fp2 zi = fp2_inv(acc.z), zi2 = fp2_sqr(zi);
+        g2_encode(fp2_mul(acc.x, zi2), fp2_mul(acc.y, fp2_mul(zi2, zi)), inf, o);
+    }
+}
+
 // H(m) projective -> affine (hash_to_g2 batch output)
 __global__ __launch_bounds__(64) void k_h_to_affine(uint64_t n, Workspace ws, uint64_t* d_out) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -354,6 +354,8 @@ __global__ void k_g2_alloc_team(Group g);
 __global__ void k_pairing_team_multi(Group gs, uint32_t K, uint64_t n_h);
 __global__ void k_decode(const uint8_t* __restrict__ pk48, const uint8_t* __restrict__ sig96, uint64_t n, uint64_t* pk_xy, uint64_t* sig_xy, int32_t* status);
 __global__ void k_h_to_affine(uint64_t n, Workspace ws, uint64_t* d_out);
+__global__ void k_decode_points(uint32_t group, const uint8_t* __restrict__ in, uint64_t m, Fp* xy, int32_t* st);
+__global__ void k_sum_points(uint32_t group, const Fp* __restrict__ xy, const int32_t* __restrict__ pst, uint32_t k, uint64_t n, uint8_t* out, int32_t* status);
 __global__ void k_sign(uint64_t n, Workspace ws, const uint8_t* __restrict__ sk32, uint8_t* sig96, uint64_t* sig_xy, uint8_t* pk48, uint64_t* pk_xy, int32_t* status);
 __global__ void k_bench_mad(uint32_t iters, uint32_t* out);
 __global__ void k_bench_fpmul(uint32_t iters, uint32_t* out);

@@ -288,6 +288,17 @@ int blsw_matrices_fill_params(uint32_t msg_len, uint32_t params_mode, const blsw
  * tests/tests.rs:244-263 semantics: an instance verifies iff both statuses are BLSW_ST_OK and the gadget result is 1. */
 int blsw_decode_batch(const uint8_t* d_pk48, const uint8_t* d_sig96, uint64_t n, uint64_t* d_pk_xy, uint64_t* d_sig_xy, int32_t* d_status, void* stream);
 
+/* Signature::aggregate / PublicKey::aggregate (src/bls.rs:288-300, 183-195; tests/tests.rs:270-294 and the key sums of :296-334) for n
+ * independent lists of k compressed points each: group 2 = signatures (G2, 96 bytes), group 1 = public keys (G1, 48 bytes).
+ *   d_in [n][k][96 or 48]   d_out [n][96 or 48] the compressed sum (the infinity encoding for a sum that is the identity)
+ *   d_status [n] int32: BLSW_ST_OK, or the status of the first point of the list that does not decode (try_from fails there: the
+ *   reference unwraps); a well-formed point at infinity is a valid summand, as in aggregate_infinity_signature.json
+ * An empty list is None in the reference: k == 0 is BLSW_ERR_ARG. Every point is decoded with its subgroup check by one lane, then one
+ * lane per list adds. Asynchronous on `stream`; the workspace holds the decoded points. */
+int blsw_aggregate_points_workspace_bytes(uint32_t group, uint64_t n, uint32_t k, uint64_t* bytes);
+int blsw_aggregate_points_batch(uint32_t group, const uint8_t* d_in, uint32_t k, uint64_t n, uint8_t* d_out, int32_t* d_status, void* d_workspace,
+                                uint64_t workspace_bytes, void* stream);
+
 /* hash_to_g2 only (src/hasher.rs:727-740 / src/bls.rs:477-493): d_out_affine [n][24] u64 (x.c0, x.c1, y.c0, y.c1) Montgomery */
 int blsw_hash_to_g2_workspace_bytes(uint64_t n, uint32_t msg_len, uint64_t* bytes);
 int blsw_hash_to_g2_batch(const uint8_t* d_msg, uint32_t msg_len, uint64_t n, uint64_t* d_out_affine, void* d_workspace, uint64_t workspace_bytes,

@@ -497,6 +497,69 @@ def test_sign_batch_fixtures_and_synthetic_workload(pkg, oracle):
     assert (gmsg.cpu().numpy() == omsg).all() and (gexp == oexp).all()
 
 
+def test_aggregate_points_fixtures_and_batches(pkg, oracle):
+    """Signature::aggregate / PublicKey::aggregate on the GPU (bls.rs:288-300, 183-195): the reference's test_sign_aggr over
+    tests/test_cases/aggregate/*.json (tests/tests.rs:270-294; the empty list is None), the key sums of fast_aggregate_verify
+    (tests/tests.rs:296-334), and ragged multi-wave batches of lists against the oracle — with repeated points (the addition runs into
+    its doubling case), P + (-P) (the identity) and lists holding the encoding of the point at infinity; a point that does not decode
+    gives its status for the list."""
+    import torch
+
+    dev = torch.device("cuda:0")
+    t = lambda rows, nbytes: torch.from_numpy(np.frombuffer(b"".join(b"".join(r) for r in rows), dtype=np.uint8).reshape(len(rows), -1, nbytes).copy()).to(dev)
+    n_cases = 0
+    for name, c in eth_cases("aggregate"):
+        sigs = [unhex(x) for x in c["input"]]
+        if not sigs:
+            assert c["output"] is None and pkg.aggregate_signatures(torch.empty((1, 0, 96), dtype=torch.uint8, device=dev)) is None
+            continue
+        out, st = pkg.aggregate_signatures(t([sigs], 96))
+        assert int(st[0]) == 0 and out[0].cpu().numpy().tobytes() == unhex(c["output"]), name
+        n_cases += 1
+    assert n_cases == 5
+    for name, c in eth_cases("fast_aggregate_verify"):
+        pks = [unhex(x) for x in c["input"]["pubkeys"]]
+        if not pks:
+            continue
+        out, st = pkg.aggregate_public_keys(t([pks], 48))
+        exp = oracle.aggregate_g1(pks)
+        if exp is None:  # a key that does not decode (the infinity encoding decodes)
+            assert int(st[0]) != 0
+        else:
+            assert int(st[0]) == 0 and out[0].cpu().numpy().tobytes() == exp, name
+    # batches: 150 lists of 5 (three waves of lists, 750 points), built from 12 distinct signatures / keys
+    sks = [int.from_bytes(synth._h(0xA66, b"sk", j), "big") % synth.R_MOD or 1 for j in range(12)]
+    sig = [oracle.sign(sk, b"aggregate me") for sk in sks]
+    pk = [oracle.sk_to_pk(sk) for sk in sks]
+    neg = lambda b: bytes([b[0] ^ 0x20]) + b[1:]  # the other root: -P
+    inf2, inf1 = bytes([0xC0]) + bytes(95), bytes([0xC0]) + bytes(47)
+    for group, pts, inf, agg, nbytes in ((2, sig, inf2, oracle.aggregate_g2, 96), (1, pk, inf1, oracle.aggregate_g1, 48)):
+        rows = []
+        for i in range(150):
+            row = [pts[(i * 7 + 3 * j) % 12] for j in range(5)]
+            if i % 10 == 1:
+                row[2] = row[0]  # P + ... + P: doubling inside the mixed addition
+            if i % 10 == 2:
+                row = [row[0], neg(row[0]), inf, row[0], neg(row[0])]  # the identity
+            if i % 10 == 3:
+                row[4] = inf
+            rows.append(row)
+        out, st = pkg.aggregate_points(group, t(rows, nbytes))
+        assert (st.cpu().numpy() == 0).all()
+        got = out.cpu().numpy()
+        for i in range(150):
+            assert got[i].tobytes() == agg(rows[i]), "group %d list %d" % (group, i)
+        assert got[2].tobytes() == inf
+        # a point that is not on the curve / not in the subgroup: the list's status names it, the others are unaffected
+        bad = bytearray(rows[5][3])
+        bad[-1] ^= 1
+        rows[5][3] = bytes(bad)
+        out2, st2 = pkg.aggregate_points(group, t(rows, nbytes))
+        st2 = st2.cpu().numpy()
+        assert st2[5] in (pkg.ST_NOT_ON_CURVE, pkg.ST_NOT_IN_SUBGROUP, pkg.ST_BAD_ENCODING) and (np.delete(st2, 5) == 0).all()
+        assert agg(rows[5]) is None and (np.delete(out2.cpu().numpy(), 5, axis=0) == np.delete(got, 5, axis=0)).all()
+
+
 def test_gpu_matches_oracle_emitted_digests(pkg, oracle):
     """ORACLE-vs-GPU (T2), not a T3 check: tests/golden/witness_digests.json was emitted by this repository's own oracle
     (tests/golden/gen_oracle_vectors.py), so it pins the GPU to the oracle, not to real arkworks — the witness ORDER of real

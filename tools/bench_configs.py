@@ -74,6 +74,16 @@ def main():
     print(json.dumps({"workload": "decode pk48 + sig96 incl. subgroup checks (bls.rs:219-242, 316-339)", "instances": sk.shape[0], "seconds": dt,
                       "value": sk.shape[0] / dt, "unit": "instances/s"}))
 
+    # Signature::aggregate / PublicKey::aggregate: lists of 8 of the signatures / keys just minted (decode with subgroup check + sum + serialise)
+    k_agg = 8
+    lists = sk.shape[0] // k_agg
+    s96, p48 = r["sig96"][: lists * k_agg].reshape(lists, k_agg, 96).contiguous(), r["pk48"][: lists * k_agg].reshape(lists, k_agg, 48).contiguous()
+    for name, fn, pts in (("Signature::aggregate (bls.rs:288-300)", pkg.aggregate_signatures, s96), ("PublicKey::aggregate (bls.rs:183-195)", pkg.aggregate_public_keys, p48)):
+        fn(pts)
+        dt, (o, stt) = timed(lambda: fn(pts))
+        print(json.dumps({"workload": name + ", lists of %d compressed points, decode incl. subgroup checks + sum + serialise" % k_agg, "lists": lists, "points": lists * k_agg,
+                          "seconds": dt, "value": lists * k_agg / dt, "unit": "points/s", "all_ok": bool((stt == 0).all().item())}))
+
     # the single-key path with the steps leaving in compact wire form (bit-packed SHA witnesses + field witnesses, 2.6 MB per
     # instance; what a sharded job ships): generation without the 34 MB-per-instance expansion
     nb = 1024
