@@ -9,6 +9,10 @@
 
 namespace blsw {
 
+#if defined(__HIPCC__)  // both passes: device functions are parsed for the host as well
+typedef uint32_t blsw_u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) blsw_u32x4 blsw_global_u32x4;
+#endif
 struct Emitter {
     uint32_t* base;        // where element 0 of this instance lives (16-byte aligned); nullptr = value-only mode
     uint32_t pos;          // element index of the next witness
@@ -22,10 +26,12 @@ struct Emitter {
 #if defined(__HIP_DEVICE_COMPILE__) && defined(BLSW_DEBUG_NO_EMIT)  // timing experiment: chains without their staging stores
         if (v.l[0] == 0x12345678u && v.l[7] == 0x9abcdef0u) *reinterpret_cast<uint32_t*>(base + (size_t)pos * stride) = 1;
 #elif defined(__HIP_DEVICE_COMPILE__)
-        uint4* d = reinterpret_cast<uint4*>(base + (size_t)pos * stride);
-        d[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
-        d[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
-        d[2] = make_uint4(v.l[8], v.l[9], v.l[10], v.l[11]);
+        // witnesses live in global memory (staging or an output tensor): say so — a generic pointer makes these FLAT stores, which count on
+        // lgkmcnt as well and hold up every later wait for an LDS operation (the team kernels) until their addresses are resolved
+        blsw_global_u32x4* d = (blsw_global_u32x4*)(base + (size_t)pos * stride);
+        d[0] = blsw_u32x4{v.l[0], v.l[1], v.l[2], v.l[3]};
+        d[1] = blsw_u32x4{v.l[4], v.l[5], v.l[6], v.l[7]};
+        d[2] = blsw_u32x4{v.l[8], v.l[9], v.l[10], v.l[11]};
 #else
         uint32_t* d = base + (size_t)pos * stride;
         for (int i = 0; i < 12; i++) d[i] = v.l[i];

@@ -203,9 +203,10 @@ struct Group {
     int chain_prio;        // chain waves raise s_setprio
 };
 
+// workspace / staging / tensor accesses: global address space stated (see Emitter::put)
 __device__ __forceinline__ Fp ld_fp(const Fp* p) {
-    const uint4* s = reinterpret_cast<const uint4*>(p);
-    uint4 a = s[0], b = s[1], c = s[2];
+    const blsw_global_u32x4* s = (const blsw_global_u32x4*)p;
+    blsw_u32x4 a = s[0], b = s[1], c = s[2];
     Fp r;
     r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
     r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
@@ -213,10 +214,10 @@ __device__ __forceinline__ Fp ld_fp(const Fp* p) {
     return r;
 }
 __device__ __forceinline__ void st_fp(Fp* p, const Fp& v) {
-    uint4* d = reinterpret_cast<uint4*>(p);
-    d[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
-    d[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
-    d[2] = make_uint4(v.l[8], v.l[9], v.l[10], v.l[11]);
+    blsw_global_u32x4* d = (blsw_global_u32x4*)p;
+    d[0] = blsw_u32x4{v.l[0], v.l[1], v.l[2], v.l[3]};
+    d[1] = blsw_u32x4{v.l[4], v.l[5], v.l[6], v.l[7]};
+    d[2] = blsw_u32x4{v.l[8], v.l[9], v.l[10], v.l[11]};
 }
 __device__ __forceinline__ Fp2 ld_fp2(const Fp* p, uint64_t n) { return {ld_fp(p), ld_fp(p + n)}; }
 
