@@ -1,0 +1,75 @@
+// TEST PROGRAM: the reference's gadget test (src/constraints.rs:318-376, `test_verify`) written against include/blsw.hpp — the C++ host side
+// above the C ABI. Same inputs, same statements, same assertion; the three messages of the reference's loop are the three systems of one
+// ConstraintSystem batch here. Prints key=value pairs for tests/test_gpu_parity.py (witness digest of system 0 against the oracle).
+//   gadget_test [constant|witness] [count-constraints]
+#include <cstdio>
+#include <cstring>
+
+#include "blsw.hpp"
+
+using namespace blsw;
+
+// position-weighted sum of the assignment's u64 words, mod 2^64 (vectorisable on the checking side)
+static uint64_t digest(const std::vector<uint64_t>& w) {
+    uint64_t h = 0;
+    for (size_t k = 0; k < w.size(); k++) h += w[k] * (2 * (uint64_t)k + 1);
+    return h;
+}
+
+int main(int argc, char** argv) {
+    const bool params_witness = argc > 1 && !strcmp(argv[1], "witness");
+    const bool count = argc > 2 && !strcmp(argv[2], "count-constraints");
+    try {
+        // use case from tests/test_cases/verify (constraints.rs:320-324)
+        const char* msgs[3] = {
+            "5656565656565656565656565656565656565656565656565656565656565656",  // valid
+            "5656565656565656565656565656565656565656565656565656565656565657",  // invalid
+            "7878787878787878787878787878787878787878787878787878787878787878",  // invalid
+        };
+        const bool expects[3] = {true, false, false};
+
+        ConstraintSystem cs(3, 32);
+
+        const PublicKey public_key = PublicKey::try_from("a491d1b0ecd9bb917989f0e74f0dea0422eac4a873e5e2644f368dffb9a6e20fd6e10c1b77654d067c0618f6e5a7f79a");
+        std::vector<std::vector<uint8_t>> msg_bytes;
+        for (const char* m : msgs) msg_bytes.push_back(detail::unhex(m, 32));
+        const MessageVar msg = UInt8::new_witness_vec(cs, msg_bytes);
+        const Signature sig = Signature::try_from(
+            "882730e5d03f6b42c3abc26d3372625034e1d871b65a8a6b900a56dae22da98abbe1b68f85e49fe7652a55ec3d0591c20767677e33e5cbb1207315c41a9ac03be39c2e7668edc043d6"
+            "cb1d9fd93033caa8a1c5b0e84bedaeb6c64972503a43eb");
+
+        const Boolean result = BlsSignatureVerifyGadget::verify(
+            ParametersVar::new_variable(cs, Parameters{}, params_witness ? AllocationMode::Witness : AllocationMode::Constant),
+            PublicKeyVar::new_variable(cs, std::vector<PublicKey>(3, public_key), AllocationMode::Witness), msg,
+            SignatureVar::new_variable(cs, std::vector<Signature>(3, sig), AllocationMode::Witness));
+
+        for (int i = 0; i < 3; i++) {
+            printf("verification_result_%d=%d ", i, (int)result.value()[i]);
+            if (result.value()[i] != expects[i]) {
+                fprintf(stderr, "system %d: expected %d\n", i, (int)expects[i]);
+                return 2;
+            }
+        }
+        const std::vector<uint64_t> w0 = cs.witness_assignment(0), w2 = cs.witness_assignment(2);
+        printf("num_witness_variables=%llu num_instance_variables=%llu status_pk=%d status_sig=%d digest0=%llu digest2=%llu", (unsigned long long)cs.num_witness_variables(),
+               (unsigned long long)cs.num_instance_variables(), cs.status(0)[0], cs.status(0)[1], (unsigned long long)digest(w0), (unsigned long long)digest(w2));
+        if (count) printf(" constraint_size=%llu", (unsigned long long)cs.num_constraints());  // "constraint size" of constraints.rs:369-373
+        printf("\n");
+        // the argument rules of the mirror
+        try {
+            (void)ParametersVar::new_variable(cs, Parameters{}, AllocationMode::Input);
+            return 3;
+        } catch (const Error& e) {
+            if (e.code != BLSW_ERR_ARG) return 4;
+        }
+        try {
+            (void)PublicKey::try_from("a491");
+            return 5;
+        } catch (const Error&) {
+        }
+    } catch (const Error& e) {
+        fprintf(stderr, "%s\n", e.what());
+        return 10;
+    }
+    return 0;
+}

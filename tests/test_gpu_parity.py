@@ -1158,6 +1158,37 @@ def test_c_caller_on_the_gpu(pkg, oracle):
     assert [int(kv["digest0"]), int(kv["digest1"])] == pkg.witness_digest_reference(w)
 
 
+def test_cpp_host_mirror_reference_gadget_test(pkg, oracle):
+    """tests/cpp_caller/gadget_test.cpp = the reference's `test_verify` (constraints.rs:318-376) written against include/blsw.hpp, the C++ host side
+    with the reference's names: the three messages as three systems of one batch, expected [true, false, false]; witness vectors of the valid and of an
+    invalid system against the oracle (a position-weighted digest of the assignment), for Constant and for Witness parameters; `constraint size` against the oracle's."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "tests", "cpp_caller")])
+    g = LIT["gadget_verify"]
+    _, pk, _ = oracle.g1_decompress(bytes.fromhex(g["pubkey"]))
+    _, sig, _ = oracle.g2_decompress(bytes.fromhex(g["signature"]))
+
+    def digest(a):  # the program's: sum of w_k (2 k + 1) over the u64 words, mod 2^64
+        w = a.reshape(-1).astype(np.uint64)
+        with np.errstate(over="ignore"):
+            return int((w * (2 * np.arange(w.size, dtype=np.uint64) + 1)).sum(dtype=np.uint64))
+
+    for mode, pm in (("constant", 0), ("witness", 1)):
+        args = [os.path.join(root, "tests", "cpp_caller", "gadget_test"), mode] + (["count-constraints"] if pm == 0 else [])
+        out = subprocess.check_output(args, text=True, timeout=600)
+        kv = dict(p.split("=") for p in out.split())
+        assert [kv["verification_result_%d" % i] for i in range(3)] == ["1", "0", "0"] and g["expected"] == [True, False, False]
+        assert kv["status_pk"] == kv["status_sig"] == "0" and kv["num_instance_variables"] == "1"
+        for k, key in ((0, "digest0"), (2, "digest2")):
+            n, ncons, res, w = oracle.witness(pk, bytes.fromhex(g["messages"][k]), sig, params_mode=pm)
+            assert int(kv["num_witness_variables"]) == n and res == g["expected"][k]
+            assert int(kv[key]) == digest(w), "%s parameters, system %d" % (mode, k)
+        if pm == 0:
+            assert int(kv["constraint_size"]) == ncons
+
+
 def test_c_caller_submit_bytes_fixtures(pkg, tmp_path):
     """blsw_engine_submit_bytes from plain C: all 29 verify/*.json cases of the reference (tests/tests.rs:239-268) as ONE batch of
     compressed bytes — decode, status rule (an undecodable / identity point is replaced by the default and the case is false) and
