@@ -9,6 +9,7 @@
 //   UInt8::new_witness_vec                              constraints.rs:341
 //   ParametersVar / PublicKeyVar / SignatureVar::new_variable(cs, value, AllocationMode)   constraints.rs:194-249
 //   BlsSignatureVerifyGadget::verify(&params, &pk, &msg, &sig) -> Boolean                  constraints.rs:90-128
+//   BlsSignatureVerifyGadget::aggregate_verify(&params, &keys, &bitmap, &msg, &sig) -> (Boolean, UInt32)   constraints.rs:153-191
 //   cs.num_constraints(), cs.num_witness_variables(), Boolean::value()                     constraints.rs:369-373
 #pragma once
 #include <hip/hip_runtime_api.h>
@@ -19,6 +20,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "blsw.h"
@@ -134,7 +136,7 @@ class ConstraintSystem {
     // cs.num_constraints(): the library synthesises the system symbolically on the host (a few seconds, once per call)
     uint64_t num_constraints() const {
         blsw_matrices_info_t info;
-        check(layout_.params_mode ? blsw_matrices_info_params(msg_len_, layout_.params_mode, &info) : blsw_matrices_info(msg_len_, 0, 1, &info), "blsw_matrices_info");
+        check(layout_.params_mode ? blsw_matrices_info_params(msg_len_, layout_.params_mode, &info) : blsw_matrices_info(msg_len_, layout_.n_keys, 1, &info), "blsw_matrices_info");
         return info.n_constraints;
     }
     const blsw_layout_t& layout() const { return layout_; }
@@ -228,14 +230,29 @@ class SignatureVar {
     std::vector<Signature> sigs_;
 };
 
-// Boolean<ConstraintF>: the gadget's output of every system
+// Boolean<ConstraintF>: one Boolean of every system — the gadget's output, or a bitmap entry allocated with new_witness (constraints.rs:414-419)
 class Boolean {
    public:
     const std::vector<bool>& value() const { return v_; }
+    static Boolean new_witness(ConstraintSystem& cs, const std::vector<bool>& values) {
+        if (values.size() != cs.num_instances()) throw Error("Boolean::new_witness: one value per system", BLSW_ERR_ARG);
+        Boolean b;
+        b.v_ = values;
+        return b;
+    }
 
    private:
     friend struct BlsSignatureVerifyGadget;
     std::vector<bool> v_;
+};
+// UInt32<ConstraintF>: the effective public key count of aggregate_verify (constraints.rs:177-189)
+class UInt32 {
+   public:
+    const std::vector<uint32_t>& value() const { return v_; }
+
+   private:
+    friend struct BlsSignatureVerifyGadget;
+    std::vector<uint32_t> v_;
 };
 
 struct BlsSignatureVerifyGadget {
@@ -287,6 +304,82 @@ struct BlsSignatureVerifyGadget {
         b.v_.resize(n);
         for (size_t i = 0; i < n; i++) b.v_[i] = r[i] == 1;
         return b;
+    }
+
+    // constraints.rs:153-167 for the n systems of `cs`: public_keys[k] / bitmap[k] hold key k / bit k of every system (the reference passes
+    // slices of K variables of one system). Returns (result, effective public key count). The circuit is the one of blsw_layout_aggregate:
+    // keys, bitmap, msg, sig allocated in the order of constraints.rs:378-441, Constant parameters. A key or signature that does not decode
+    // makes its system false (status()), as in verify. Synchronous; direct-mode batch entry blsw_aggregate_verify_batch.
+    static std::pair<Boolean, UInt32> aggregate_verify(const ParametersVar& parameters, const std::vector<PublicKeyVar>& public_keys, const std::vector<Boolean>& bitmap,
+                                                       const MessageVar& message, const SignatureVar& signature) {
+        if (!parameters.cs_) throw Error("aggregate_verify: parameters were not allocated in a ConstraintSystem", BLSW_ERR_ARG);
+        ConstraintSystem& cs = *parameters.cs_;
+        const size_t n = cs.n_, K = public_keys.size();
+        if (K == 0 || bitmap.size() != K) throw Error("aggregate_verify: public_keys.len() == bitmap.len() > 0", BLSW_ERR_ARG);  // constraints.rs:160
+        if (cs.layout_.params_mode || cs.engine_) throw Error("aggregate_verify: Constant parameters, a ConstraintSystem not used by verify", BLSW_ERR_ARG);
+        if (signature.sigs_.size() != n || message.bytes().size() != n * cs.msg_len_) throw Error("aggregate_verify: variables of another ConstraintSystem", BLSW_ERR_ARG);
+        check(blsw_layout_aggregate(cs.msg_len_, (uint32_t)K, &cs.layout_), "blsw_layout_aggregate");
+        if (cs.device_ >= 0) hip_check(hipSetDevice(cs.device_), "hipSetDevice");
+        // compressed inputs, system-major: keys [n][K][48], bitmap [n][K], signatures [n][96]
+        std::vector<uint8_t> pk(n * K * 48), bm(n * K), sg(n * 96);
+        for (size_t k = 0; k < K; k++) {
+            if (public_keys[k].keys_.size() != n || bitmap[k].v_.size() != n) throw Error("aggregate_verify: one key and one bit per system", BLSW_ERR_ARG);
+            for (size_t i = 0; i < n; i++) {
+                std::memcpy(&pk[(i * K + k) * 48], public_keys[k].keys_[i].bytes.data(), 48);
+                bm[i * K + k] = bitmap[k].v_[i] ? 1 : 0;
+            }
+        }
+        for (size_t i = 0; i < n; i++) std::memcpy(&sg[96 * i], signature.sigs_[i].bytes.data(), 96);
+        // decode (blsw_decode_batch takes as many keys as signatures: the keys with a block of zero bytes beside them, then the signatures likewise)
+        const size_t m = n * K;
+        detail::DeviceBytes d_pk(m * 48), d_sg(m * 96), d_pk_xy(m * 96), d_sg_xy(m * 192), d_st(m * 8), d_bm(m), d_msg(message.bytes().size());
+        hip_check(hipMemset(d_sg.get(), 0, m * 96), "hipMemset");
+        d_pk.upload(pk.data(), pk.size());
+        check(blsw_decode_batch(static_cast<const uint8_t*>(d_pk.get()), static_cast<const uint8_t*>(d_sg.get()), m, static_cast<uint64_t*>(d_pk_xy.get()),
+                                static_cast<uint64_t*>(d_sg_xy.get()), static_cast<int32_t*>(d_st.get()), nullptr),
+              "blsw_decode_batch");
+        std::vector<int32_t> st_keys(2 * m);
+        hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+        d_st.download(st_keys.data(), m * 8);
+        detail::DeviceBytes d_pk0(n * 48), d_sig(n * 96), d_pk0_xy(n * 96), d_st2(n * 8);
+        cs.sig_xy_ = detail::DeviceBytes(n * 192);
+        hip_check(hipMemset(d_pk0.get(), 0, n * 48), "hipMemset");
+        d_sig.upload(sg.data(), sg.size());
+        check(blsw_decode_batch(static_cast<const uint8_t*>(d_pk0.get()), static_cast<const uint8_t*>(d_sig.get()), n, static_cast<uint64_t*>(d_pk0_xy.get()),
+                                static_cast<uint64_t*>(cs.sig_xy_.get()), static_cast<int32_t*>(d_st2.get()), nullptr),
+              "blsw_decode_batch");
+        std::vector<int32_t> st_sig(2 * n);
+        hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+        d_st2.download(st_sig.data(), n * 8);
+        d_bm.upload(bm.data(), bm.size());
+        if (!message.bytes().empty()) d_msg.upload(message.bytes().data(), message.bytes().size());
+        uint64_t bytes = 0;
+        check(blsw_aggregate_workspace_bytes(n, cs.msg_len_, (uint32_t)K, &bytes), "blsw_aggregate_workspace_bytes");
+        cs.workspace_ = detail::DeviceBytes(bytes);
+        cs.witness_ = detail::DeviceBytes(n * (size_t)cs.layout_.n_witness * 48);
+        cs.result_ = detail::DeviceBytes(n * 4);
+        detail::DeviceBytes d_count(n * 4);
+        check(blsw_aggregate_verify_batch(static_cast<const uint64_t*>(d_pk_xy.get()), static_cast<const uint8_t*>(d_bm.get()), (uint32_t)K,
+                                          static_cast<const uint64_t*>(cs.sig_xy_.get()), static_cast<const uint8_t*>(d_msg.get()), cs.msg_len_, n,
+                                          static_cast<uint64_t*>(cs.witness_.get()), cs.layout_.n_witness, static_cast<int32_t*>(cs.result_.get()),
+                                          static_cast<uint32_t*>(d_count.get()), cs.workspace_.get(), bytes, nullptr),
+              "blsw_aggregate_verify_batch");
+        hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+        std::vector<int32_t> r(n);
+        cs.result_.download(r.data(), n * 4);
+        UInt32 count;
+        count.v_.resize(n);
+        d_count.download(count.v_.data(), n * 4);
+        // status(i): the first key of system i that did not decode (or OK), and the signature's
+        cs.status_.assign(2 * n, BLSW_ST_OK);
+        Boolean b;
+        b.v_.resize(n);
+        for (size_t i = 0; i < n; i++) {
+            for (size_t k = 0; k < K && cs.status_[2 * i] == BLSW_ST_OK; k++) cs.status_[2 * i] = st_keys[2 * (i * K + k)];
+            cs.status_[2 * i + 1] = st_sig[2 * i + 1];
+            b.v_[i] = r[i] == 1 && cs.status_[2 * i] == BLSW_ST_OK && cs.status_[2 * i + 1] == BLSW_ST_OK;
+        }
+        return {b, count};
     }
 };
 

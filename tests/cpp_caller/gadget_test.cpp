@@ -2,6 +2,7 @@
 // above the C ABI. Same inputs, same statements, same assertion; the three messages of the reference's loop are the three systems of one
 // ConstraintSystem batch here. Prints key=value pairs for tests/test_gpu_parity.py (witness digest of system 0 against the oracle).
 //   gadget_test [constant|witness] [count-constraints]
+//   gadget_test aggregate      the reference's test_aggregate_verify and test_aggregate_verify_neg (constraints.rs:378-521) as the two systems of one batch
 #include <cstdio>
 #include <cstring>
 
@@ -16,7 +17,41 @@ static uint64_t digest(const std::vector<uint64_t>& w) {
     return h;
 }
 
+// constraints.rs:378-441 (bitmap: the first two of 512 keys) and :452-521 (all 512): expected true / false, effective key counts 2 / 512
+static int aggregate_tests() {
+    ConstraintSystem cs(2, 32);
+    const PublicKey pub_key1 = PublicKey::try_from("a491d1b0ecd9bb917989f0e74f0dea0422eac4a873e5e2644f368dffb9a6e20fd6e10c1b77654d067c0618f6e5a7f79a");
+    const PublicKey pub_key2 = PublicKey::try_from("b301803f8b5ac4a1133581fc676dfedc60d891dd5fa99028805e5ea5b08d3491af75d0707adab3b70c6a6a580217bf81");
+    std::vector<PublicKeyVar> pub_keys;
+    pub_keys.push_back(PublicKeyVar::new_variable(cs, {pub_key1, pub_key1}, AllocationMode::Witness));
+    for (int i = 1; i < 512; i++) pub_keys.push_back(PublicKeyVar::new_variable(cs, {pub_key2, pub_key2}, AllocationMode::Witness));
+    std::vector<Boolean> bitmap;
+    bitmap.push_back(Boolean::new_witness(cs, {true, true}));
+    bitmap.push_back(Boolean::new_witness(cs, {true, true}));
+    for (int i = 2; i < 512; i++) bitmap.push_back(Boolean::new_witness(cs, {false, true}));
+    const std::vector<uint8_t> m = detail::unhex("5656565656565656565656565656565656565656565656565656565656565656", 32);
+    const MessageVar msg = UInt8::new_witness_vec(cs, {m, m});
+    const Signature sig = Signature::try_from(
+        "912c3615f69575407db9392eb21fee18fff797eeb2fbe1816366ca2a08ae574d8824dbfafb4c9eaa1cf61b63c6f9b69911f269b664c42947dd1b53ef1081926c1e82bb2a465f927124b08391a5249"
+        "036146d6f3f1e17ff5f162f779746d830d1");
+    const auto [result, count] = BlsSignatureVerifyGadget::aggregate_verify(ParametersVar::new_variable(cs, Parameters{}, AllocationMode::Constant), pub_keys, bitmap, msg,
+                                                                            SignatureVar::new_variable(cs, {sig, sig}, AllocationMode::Witness));
+    printf("verification_result_0=%d verification_result_1=%d effective_public_key_count_0=%u effective_public_key_count_1=%u num_witness_variables=%llu", (int)result.value()[0],
+           (int)result.value()[1], count.value()[0], count.value()[1], (unsigned long long)cs.num_witness_variables());
+    if (result.value()[0] != true || result.value()[1] != false) return 2;
+    printf(" digest0=%llu digest1=%llu\n", (unsigned long long)digest(cs.witness_assignment(0)), (unsigned long long)digest(cs.witness_assignment(1)));
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && !strcmp(argv[1], "aggregate")) {
+        try {
+            return aggregate_tests();
+        } catch (const Error& e) {
+            fprintf(stderr, "%s\n", e.what());
+            return 10;
+        }
+    }
     const bool params_witness = argc > 1 && !strcmp(argv[1], "witness");
     const bool count = argc > 2 && !strcmp(argv[2], "count-constraints");
     try {

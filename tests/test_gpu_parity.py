@@ -1161,7 +1161,8 @@ def test_c_caller_on_the_gpu(pkg, oracle):
 def test_cpp_host_mirror_reference_gadget_test(pkg, oracle):
     """tests/cpp_caller/gadget_test.cpp = the reference's `test_verify` (constraints.rs:318-376) written against include/blsw.hpp, the C++ host side
     with the reference's names: the three messages as three systems of one batch, expected [true, false, false]; witness vectors of the valid and of an
-    invalid system against the oracle (a position-weighted digest of the assignment), for Constant and for Witness parameters; `constraint size` against the oracle's."""
+    invalid system against the oracle (a position-weighted digest of the assignment), for Constant and for Witness parameters; `constraint size` against the oracle's. Then `test_aggregate_verify` and `test_aggregate_verify_neg`
+    (constraints.rs:378-521) through BlsSignatureVerifyGadget::aggregate_verify of the same header: results, effective key counts, both witness vectors."""
     import subprocess
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -1187,6 +1188,19 @@ def test_cpp_host_mirror_reference_gadget_test(pkg, oracle):
             assert int(kv[key]) == digest(w), "%s parameters, system %d" % (mode, k)
         if pm == 0:
             assert int(kv["constraint_size"]) == ncons
+    # the reference's two aggregate_verify tests (constraints.rs:378-521) as the two systems of one batch: 512 keys, bitmaps {first two} / {all}
+    out = subprocess.check_output([os.path.join(root, "tests", "cpp_caller", "gadget_test"), "aggregate"], text=True, timeout=600)
+    kv = dict(p.split("=") for p in out.split())
+    assert (kv["verification_result_0"], kv["verification_result_1"], kv["effective_public_key_count_0"], kv["effective_public_key_count_1"]) == ("1", "0", "2", "512")
+    _, p1, _ = oracle.g1_decompress(bytes.fromhex("a491d1b0ecd9bb917989f0e74f0dea0422eac4a873e5e2644f368dffb9a6e20fd6e10c1b77654d067c0618f6e5a7f79a"))
+    _, p2, _ = oracle.g1_decompress(bytes.fromhex("b301803f8b5ac4a1133581fc676dfedc60d891dd5fa99028805e5ea5b08d3491af75d0707adab3b70c6a6a580217bf81"))
+    _, s, _ = oracle.g2_decompress(bytes.fromhex(
+        "912c3615f69575407db9392eb21fee18fff797eeb2fbe1816366ca2a08ae574d8824dbfafb4c9eaa1cf61b63c6f9b69911f269b664c42947dd1b53ef1081926c1e82bb2a465f927124b08391a5249036146d6f3f1e17ff5f162f779746d830d1"))
+    keys = np.stack([p1] + [p2] * 511)
+    for i, bits in enumerate((np.array([1, 1] + [0] * 510, dtype=np.uint8), np.ones(512, dtype=np.uint8))):
+        n, res, c, _, ow = oracle.witness_aggregate(keys, bits, bytes([0x56]) * 32, s)
+        assert int(kv["num_witness_variables"]) == n and res == (i == 0) and c == (2, 512)[i]
+        assert int(kv["digest%d" % i]) == digest(ow), "aggregate system %d" % i
 
 
 def test_c_caller_submit_bytes_fixtures(pkg, tmp_path):
