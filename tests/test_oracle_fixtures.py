@@ -164,3 +164,15 @@ def test_witness_digest_goldens(oracle):
         assert hashlib.sha256(b.tobytes()).hexdigest() == c["sha256_all"], name
         lo, hi = gold["segments"][-3][1], gold["segments"][-3][2]  # the Miller-loop segment
         assert hashlib.sha256(b[lo:hi].tobytes()).hexdigest() == c["sha256_segments"]["miller"], name
+    # the section for ParametersVar allocated as witnesses (tools/t3_dumper --params-witness)
+    pw = gold["params_witness"]
+    assert [s[0] for s in pw["segments"]][1] == "params_alloc" and len(pw["cases"]) == 2
+    for name, c in pw["cases"].items():
+        _, pk, _ = oracle.g1_decompress(bytes.fromhex(c["pubkey"]))
+        _, sig, _ = oracle.g2_decompress(bytes.fromhex(c["signature"]))
+        n, nc, res, w = oracle.witness(pk, bytes.fromhex(c["message"]), sig, params_mode=1)
+        assert (n, nc, bool(res)) == (c["n_witness"], c["n_constraints"], c["result"]), name
+        b = np.ascontiguousarray(w).view(np.uint8).reshape(n, 48)
+        assert hashlib.sha256(b.tobytes()).hexdigest() == c["sha256_all"], name
+        for sname, lo, hi in pw["segments"]:
+            assert hashlib.sha256(b[lo:hi].tobytes()).hexdigest() == c["sha256_segments"][sname], (name, sname)

@@ -6,7 +6,8 @@
 //!   * cs.num_instance_variables(), cs.num_witness_variables(), cs.num_constraints(), the result value,
 //!   * SHA-256 over the witness assignment, each element as its 6 little-endian u64 MONTGOMERY limbs (48 bytes),
 //!   * the same digest per segment of the layout table stored in the golden file,
-//! and prints the first segment that differs. Written for this repository; not derived from the reference's sources
+//! and prints the first segment that differs. With `--params-witness` it does the same for the golden file's "params_witness" section:
+//! the circuit with `ParametersVar::new_variable(.., AllocationMode::Witness)` (src/constraints.rs:198-211 takes any mode). Written for this repository; not derived from the reference's sources
 //! beyond calling its public API.
 use ark_bls12_381::{Config, Fq};
 use ark_crypto_primitives::signature::SigVerifyGadget;
@@ -31,8 +32,12 @@ fn digest(elems: &[Fq]) -> String {
 }
 
 fn main() {
-    let path = std::env::args().nth(1).expect("usage: t3-dumper <witness_digests.json>");
-    let golden: serde_json::Value = serde_json::from_str(&std::fs::read_to_string(path).unwrap()).unwrap();
+    let args: Vec<String> = std::env::args().skip(1).collect();
+    let params_witness = args.iter().any(|a| a == "--params-witness");
+    let path = args.iter().find(|a| !a.starts_with("--")).expect("usage: t3-dumper [--params-witness] <witness_digests.json>");
+    let file: serde_json::Value = serde_json::from_str(&std::fs::read_to_string(path).unwrap()).unwrap();
+    let golden = if params_witness { file["params_witness"].clone() } else { file };
+    let params_mode = if params_witness { AllocationMode::Witness } else { AllocationMode::Constant };
     let mut all_ok = true;
     for (name, case) in golden["cases"].as_object().unwrap() {
         let cs = ConstraintSystem::<Fq>::new_ref();
@@ -40,7 +45,7 @@ fn main() {
         let sig = Signature::<Config>::try_from(case["signature"].as_str().unwrap()).unwrap();
         let msg = hex::decode(case["message"].as_str().unwrap()).unwrap();
         let msg_var = UInt8::<Fq>::new_witness_vec(cs.clone(), &msg).unwrap();
-        let params = ParametersVar::<Config>::new_variable(cs.clone(), || Ok(Parameters::default()), AllocationMode::Constant).unwrap();
+        let params = ParametersVar::<Config>::new_variable(cs.clone(), || Ok(Parameters::default()), params_mode).unwrap();
         let pk_var = PublicKeyVar::<Config>::new_variable(cs.clone(), || Ok(pk), AllocationMode::Witness).unwrap();
         let sig_var = SignatureVar::<Config>::new_variable(cs.clone(), || Ok(sig), AllocationMode::Witness).unwrap();
         let result: Boolean<Fq> = BlsSignatureVerifyGadget::<Config>::verify(&params, &pk_var, &msg_var, &sig_var).unwrap();
