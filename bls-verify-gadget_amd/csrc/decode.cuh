@@ -3,7 +3,7 @@
 // 316-339) -> affine Montgomery coordinates + a status code. Checks: flags, x < p, on curve, prime-order subgroup.
 // Pinned by tests/test_cases/deserialization_G1/*.json (10) and deserialization_G2/*.json (12).
 #pragma once
-#include "fp.cuh"
+#include "constants.cuh"
 
 namespace blsw {
 
@@ -183,9 +183,72 @@ BLSW_FN Jac1v jac1v_add_mixed(const Jac1v& p, const Fp& qx, const Fp& qy) {
     return {x3, y3, z3};
 }
 
+// ---- prime-order subgroup membership of a point ON the curve (not the identity), as ark-bls12-381 0.4 decides it in
+// is_in_correct_subgroup_assuming_on_curve (what PublicKey::try_from / Signature::try_from reach through deserialize_compressed): the
+// endomorphism tests of Scott, eprint 2021/1130 — two / one 64-bit ladders by |x| instead of one 255-bit ladder by r. The [r]P == O ladders
+// stay as the definition they are checked against (tests/hostsim: random curve points outside the subgroup, cofactor multiples inside).
+BLSW_FN bool g1_in_subgroup_ladder(const Fp& px, const Fp& py) {
+    constexpr uint32_t RW[8] = BLSW_R_WORDS;
+    Jac1v acc = {px, py, fp_one()};
+#pragma unroll 1
+    for (int i = 253; i >= 0; i--) {
+        acc = jac1v_dbl(acc);
+        if ((RW[i >> 5] >> (i & 31)) & 1) acc = jac1v_add_mixed(acc, px, py);
+    }
+    return fp_is_zero(acc.z);
+}
+BLSW_FN bool g2_in_subgroup_ladder(const Fp2& px, const Fp2& py) {
+    constexpr uint32_t RW[8] = BLSW_R_WORDS;
+    Jac2 acc = {px, py, fp2_one()};
+#pragma unroll 1
+    for (int i = 253; i >= 0; i--) {
+        acc = jac2_dbl(acc);
+        if ((RW[i >> 5] >> (i & 31)) & 1) acc = jac2_add_mixed(acc, px, py);
+    }
+    return fp2_is_zero(acc.z);
+}
+// G1: phi(P) = (beta x, y) acts on G1 as multiplication by -x^2 (x^4 - x^2 + 1 = r), so P in G1 <=> phi(P) = -[x^2] P; arkworks' early exit
+// [|x|]P == +-P -> not in the subgroup keeps the second ladder off degenerate inputs.
+BLSW_FN bool g1_in_subgroup(const Fp& px, const Fp& py) {
+    Jac1v t = {px, py, fp_one()};
+#pragma unroll 1
+    for (int i = 62; i >= 0; i--) {
+        t = jac1v_dbl(t);
+        if ((BLSW_X_ABS >> i) & 1) t = jac1v_add_mixed(t, px, py);
+    }
+    if (fp_is_zero(t.z)) return false;  // [|x|]P = O: the order of P divides |x| < r
+    // u = [|x|]P as an affine point, then [|x|]u = [x^2]P
+    const Fp zi = fp_inv(t.z), zi2 = fp_sqr(zi);
+    const Fp ux = fp_mul(t.x, zi2), uy = fp_mul(t.y, fp_mul(zi2, zi));
+    if (fp_eq(ux, px)) return false;  // [|x|]P = +-P
+    Jac1v w = {ux, uy, fp_one()};
+#pragma unroll 1
+    for (int i = 62; i >= 0; i--) {
+        w = jac1v_dbl(w);
+        if ((BLSW_X_ABS >> i) & 1) w = jac1v_add_mixed(w, ux, uy);
+    }
+    if (fp_is_zero(w.z)) return false;
+    // (beta px, py) == -(w.x / z^2, w.y / z^3)
+    const Fp z2 = fp_sqr(w.z), z3 = fp_mul(z2, w.z);
+    return fp_eq(fp_mul(fp_mul(px, K_G1_BETA()), z2), w.x) && fp_eq(fp_mul(py, z3), fp_neg(w.y));
+}
+// G2: psi = untwist-Frobenius-twist acts on G2 as multiplication by x (negative): P in G2 <=> psi(P) = [x] P = -[|x|] P
+BLSW_FN bool g2_in_subgroup(const Fp2& px, const Fp2& py) {
+    Jac2 t = {px, py, fp2_one()};
+#pragma unroll 1
+    for (int i = 62; i >= 0; i--) {
+        t = jac2_dbl(t);
+        if ((BLSW_X_ABS >> i) & 1) t = jac2_add_mixed(t, px, py);
+    }
+    if (fp2_is_zero(t.z)) return false;
+    const Fp2 qx = fp2_mul(fp2_conj(px), K_PSI_C1()), qy = fp2_mul(fp2_conj(py), K_PSI_C2());  // psi(P), affine
+    const Fp2 z2 = fp2_sqr(t.z), z3 = fp2_mul(z2, t.z);
+    const Fp2 lx = fp2_mul(qx, z2), ly = fp2_mul(qy, z3), ny = fp2_neg(t.y);
+    return fp_eq(lx.c0, t.x.c0) && fp_eq(lx.c1, t.x.c1) && fp_eq(ly.c0, ny.c0) && fp_eq(ly.c1, ny.c1);
+}
+
 // G1: 48 bytes -> (x, y) Montgomery ((0,0) for the identity) + status
 BLSW_FN int g1_decode(const uint8_t* in, Fp& x, Fp& y) {
-    constexpr uint32_t RW[8] = BLSW_R_WORDS;
     x = fp_zero();
     y = fp_zero();
     const bool c = in[0] >> 7, inf = (in[0] >> 6) & 1, sort = (in[0] >> 5) & 1;
@@ -198,21 +261,13 @@ BLSW_FN int g1_decode(const uint8_t* in, Fp& x, Fp& y) {
     Fp py;
     if (!fp_sqrt(rhs, py)) return DEC_NOT_ON_CURVE;
     if (fp_lex_largest(py) != sort) py = fp_neg(py);
-    // [r]P == O ?
-    Jac1v acc = {px, py, fp_one()};
-#pragma unroll 1
-    for (int i = 253; i >= 0; i--) {
-        acc = jac1v_dbl(acc);
-        if ((RW[i >> 5] >> (i & 31)) & 1) acc = jac1v_add_mixed(acc, px, py);
-    }
-    if (!fp_is_zero(acc.z)) return DEC_NOT_IN_SUBGROUP;
+    if (!g1_in_subgroup(px, py)) return DEC_NOT_IN_SUBGROUP;
     x = px;
     y = py;
     return DEC_OK;
 }
 // G2: 96 bytes = x.c1 || x.c0 -> (x.c0, x.c1, y.c0, y.c1) + status
 BLSW_FN int g2_decode(const uint8_t* in, Fp2& x, Fp2& y) {
-    constexpr uint32_t RW[8] = BLSW_R_WORDS;
     x = fp2_zero();
     y = fp2_zero();
     const bool c = in[0] >> 7, inf = (in[0] >> 6) & 1, sort = (in[0] >> 5) & 1;
@@ -228,13 +283,7 @@ BLSW_FN int g2_decode(const uint8_t* in, Fp2& x, Fp2& y) {
     Fp2 py;
     if (!fp2_sqrt(rhs, py)) return DEC_NOT_ON_CURVE;
     if (fp2_lex_largest(py) != sort) py = fp2_neg(py);
-    Jac2 acc = {px, py, fp2_one()};
-#pragma unroll 1
-    for (int i = 253; i >= 0; i--) {
-        acc = jac2_dbl(acc);
-        if ((RW[i >> 5] >> (i & 31)) & 1) acc = jac2_add_mixed(acc, px, py);
-    }
-    if (!fp2_is_zero(acc.z)) return DEC_NOT_IN_SUBGROUP;
+    if (!g2_in_subgroup(px, py)) return DEC_NOT_IN_SUBGROUP;
     x = px;
     y = py;
     return DEC_OK;

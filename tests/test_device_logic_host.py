@@ -151,6 +151,123 @@ def test_decode_all_verify_fixture_points(oracle):
                 assert np.array_equal(xy, oxy), name
 
 
+def test_endomorphism_subgroup_tests_against_the_order_r_definition(oracle):
+    """g1_in_subgroup / g2_in_subgroup (decode.cuh: phi(P) = -[x^2]P and psi(P) = [x]P, the tests ark-bls12-381 0.4 itself uses, eprint 2021/1130)
+    against the oracle's [r]P == O: random encodings (about half decode to curve points, all of large order outside the subgroup), points of the
+    COFACTOR torsion ([r]Q for random curve points Q: the false positives an endomorphism test could have), and their sums with subgroup points."""
+    import random
+
+    P = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
+    R = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+    rnd = random.Random(0xE2D0)
+
+    ops1 = dict(add=lambda a, b: (a + b) % P, sub=lambda a, b: (a - b) % P, mul=lambda a, b: a * b % P, inv=lambda a: pow(a, -1, P), zero=0)
+    ops2 = dict(add=lambda a, b: ((a[0] + b[0]) % P, (a[1] + b[1]) % P), sub=lambda a, b: ((a[0] - b[0]) % P, (a[1] - b[1]) % P),
+                mul=lambda a, b: ((a[0] * b[0] - a[1] * b[1]) % P, (a[0] * b[1] + a[1] * b[0]) % P),
+                inv=lambda a: (lambda n: (a[0] * n % P, -a[1] * n % P))(pow(a[0] * a[0] + a[1] * a[1], -1, P)), zero=(0, 0))
+
+    def ec_add(o, A, B):
+        if A is None:
+            return B
+        if B is None:
+            return A
+        (x1, y1), (x2, y2) = A, B
+        if x1 == x2:
+            if o["add"](y1, y2) == o["zero"]:
+                return None
+            lam = o["mul"](o["mul"](o["add"](o["add"](x1, x1), x1), x1), o["inv"](o["add"](y1, y1)))
+        else:
+            lam = o["mul"](o["sub"](y2, y1), o["inv"](o["sub"](x2, x1)))
+        x3 = o["sub"](o["sub"](o["mul"](lam, lam), x1), x2)
+        return (x3, o["sub"](o["mul"](lam, o["sub"](x1, x3)), y1))
+
+    def ec_mul(o, k, A):
+        acc = None
+        for bit in bin(k)[2:]:
+            acc = ec_add(o, acc, acc)
+            if bit == "1":
+                acc = ec_add(o, acc, A)
+        return acc
+
+    def lex_largest_fp(y):
+        return y > (P - 1) // 2
+
+    def enc1(pt):
+        x, y = pt
+        b = bytearray(x.to_bytes(48, "big"))
+        b[0] |= 0x80 | (0x20 if lex_largest_fp(y) else 0)
+        return bytes(b)
+
+    def enc2(pt):
+        (x0, x1), (y0, y1) = pt
+        b = bytearray(x1.to_bytes(48, "big") + x0.to_bytes(48, "big"))
+        big = lex_largest_fp(y1) if y1 else lex_largest_fp(y0)
+        b[0] |= 0x80 | (0x20 if big else 0)
+        return bytes(b)
+
+    def agree(kind, data):
+        st, xy = _hs_decode(kind, data)
+        ost, oxy, oinf = (oracle.g1_decompress if kind == "g1" else oracle.g2_decompress)(data)
+        assert (st if st != 4 else 0) == ost, (kind, data.hex(), st, ost)
+        return ost
+
+    # random encodings
+    seen = {0: 0, 1: 0, 2: 0, 3: 0}
+    curve1, curve2 = [], []
+    for kind, nbytes in (("g1", 48), ("g2", 96)):
+        for _ in range(60):
+            b = bytearray(rnd.randbytes(nbytes))
+            b[0] = 0x80 | (b[0] & 0x20) | (b[0] & 0x0F)  # compressed, not infinity, x below 2^380 (< p)
+            if kind == "g2":
+                b[48] &= 0x0F
+            ost = agree(kind, bytes(b))
+            seen[ost] += 1
+            if ost == 3:
+                (curve1 if kind == "g1" else curve2).append(bytes(b))
+    assert seen[3] >= 30 and seen[2] >= 30 and seen[0] == 0  # curve points outside the subgroup, and x values without a point
+    # cofactor torsion: [r]Q, and a subgroup point plus a torsion point
+    g1gen = (0x17F1D3A73197D7942695638C4FA9AC0FC3688C4F9774B905A14E3A3F171BAC586C55E83FF97A1AEFFB3AF00ADB22C6BB,
+             0x08B3F481E3AAA0F1A09E30ED741D8AE4FCF5E095D5D00AF600DB18CB2C04B3EDD03CC744A2888AE40CAA232946C5E7E1)
+    assert agree("g1", enc1(g1gen)) == 0 and agree("g1", enc1(ec_mul(ops1, 0xD201000000010000, g1gen))) == 0
+    n_t = 0
+    for data in curve1[:6]:
+        x = int.from_bytes(bytes([data[0] & 0x1F]) + data[1:], "big")
+        y = pow((x * x * x + 4) % P, (P + 1) // 4, P)
+        t = ec_mul(ops1, R, (x, y))
+        if t is None:
+            continue
+        assert agree("g1", enc1(t)) == 3  # order divides the cofactor
+        assert agree("g1", enc1(ec_add(ops1, t, g1gen))) == 3
+        n_t += 1
+    assert n_t >= 4
+    n_t = 0
+    for data in curve2[:4]:
+        x1 = int.from_bytes(bytes([data[0] & 0x1F]) + data[1:48], "big")
+        x0 = int.from_bytes(data[48:], "big")
+        # y^2 = x^3 + 4 (1 + i): square root in Fp2 by the norm method
+        xx = ops2["mul"]((x0, x1), (x0, x1))
+        rhs = ops2["add"](ops2["mul"](xx, (x0, x1)), (4, 4))
+        nrm = (rhs[0] * rhs[0] + rhs[1] * rhs[1]) % P
+        s_ = pow(nrm, (P + 1) // 4, P)
+        if s_ * s_ % P != nrm:
+            continue
+        for sg in (s_, P - s_):
+            half = (rhs[0] + sg) * pow(2, -1, P) % P
+            a = pow(half, (P + 1) // 4, P)
+            if a * a % P == half and a:
+                y = (a, rhs[1] * pow(2 * a, -1, P) % P)
+                break
+        else:
+            continue
+        assert ops2["mul"](y, y) == rhs
+        t = ec_mul(ops2, R, ((x0, x1), y))
+        if t is None:
+            continue
+        assert agree("g2", enc2(t)) == 3
+        n_t += 1
+    assert n_t >= 2
+
+
 def test_aggregate_verify_device_logic(oracle):
     # constraints.rs:378-521 shape with 6 keys: key1 + 5 x key2, bitmap first two (true) / all (false); bit-exact vs oracle
     pk1 = "a491d1b0ecd9bb917989f0e74f0dea0422eac4a873e5e2644f368dffb9a6e20fd6e10c1b77654d067c0618f6e5a7f79a"
