@@ -11,6 +11,7 @@
 //   BlsSignatureVerifyGadget::verify(&params, &pk, &msg, &sig) -> Boolean                  constraints.rs:90-128
 //   BlsSignatureVerifyGadget::aggregate_verify(&params, &keys, &bitmap, &msg, &sig) -> (Boolean, UInt32)   constraints.rs:153-191
 //   cs.num_constraints(), cs.num_witness_variables(), Boolean::value()                     constraints.rs:369-373
+//   BLS::sign / BLS::verify (the native scheme, batched)                                   bls.rs:411-458
 #pragma once
 #include <hip/hip_runtime_api.h>
 
@@ -380,6 +381,100 @@ struct BlsSignatureVerifyGadget {
             b.v_[i] = r[i] == 1 && cs.status_[2 * i] == BLSW_ST_OK && cs.status_[2 * i + 1] == BLSW_ST_OK;
         }
         return {b, count};
+    }
+};
+
+// The native scheme (src/bls.rs:395-458, `impl SignatureScheme for BLS`) for batches: one secret key / message / signature per element.
+struct SecretKey {
+    std::array<uint8_t, 32> le;  // PrivateKey::try_from(&[u8]) (bls.rs:97-103): little-endian Fr
+    static SecretKey try_from(const std::string& hex_be) {  // the fixtures' big-endian hex ("0x..." allowed)
+        SecretKey k;
+        auto b = detail::unhex(hex_be, 32);
+        for (int i = 0; i < 32; i++) k.le[i] = b[31 - i];
+        return k;
+    }
+};
+struct BLS {
+    struct Signed {
+        std::vector<Signature> signatures;    // Signature (compressed), the infinity encoding where status != BLSW_ST_OK
+        std::vector<PublicKey> public_keys;   // PublicKey::from(&sk)
+        std::vector<int32_t> status;          // BLSW_ST_OK, BLSW_ST_INVALID_SECRET_KEY (sk = 0: Err(InvalidSecretKey), bls.rs:417-419), BLSW_ST_BAD_ENCODING (sk >= r)
+    };
+    // BLS::sign (bls.rs:411-425) and PublicKey::from(&sk) (bls.rs:183-195): messages [n][msg_len]
+    static Signed sign(const Parameters&, const std::vector<SecretKey>& sks, const std::vector<std::vector<uint8_t>>& messages) {
+        const size_t n = sks.size();
+        if (n == 0 || messages.size() != n) throw Error("BLS::sign: one message per key", BLSW_ERR_ARG);
+        const uint32_t msg_len = (uint32_t)messages[0].size();
+        std::vector<uint8_t> sk(n * 32), msg(n * (size_t)msg_len);
+        for (size_t i = 0; i < n; i++) {
+            if (messages[i].size() != msg_len) throw Error("BLS::sign: messages of one length per batch", BLSW_ERR_ARG);
+            std::memcpy(&sk[32 * i], sks[i].le.data(), 32);
+            if (msg_len) std::memcpy(&msg[(size_t)msg_len * i], messages[i].data(), msg_len);
+        }
+        uint64_t bytes = 0;
+        check(blsw_hash_to_g2_workspace_bytes(n, msg_len, &bytes), "blsw_hash_to_g2_workspace_bytes");
+        detail::DeviceBytes d_sk(sk.size()), d_msg(msg.size()), d_sig(n * 96), d_pk(n * 48), d_st(n * 4), ws(bytes);
+        d_sk.upload(sk.data(), sk.size());
+        if (!msg.empty()) d_msg.upload(msg.data(), msg.size());
+        check(blsw_sign_batch(static_cast<const uint8_t*>(d_sk.get()), static_cast<const uint8_t*>(d_msg.get()), msg_len, n, static_cast<uint8_t*>(d_sig.get()), nullptr,
+                              static_cast<uint8_t*>(d_pk.get()), nullptr, static_cast<int32_t*>(d_st.get()), ws.get(), bytes, nullptr),
+              "blsw_sign_batch");
+        hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+        std::vector<uint8_t> sg(n * 96), pk(n * 48);
+        Signed out;
+        out.status.resize(n);
+        d_sig.download(sg.data(), sg.size());
+        d_pk.download(pk.data(), pk.size());
+        d_st.download(out.status.data(), n * 4);
+        out.signatures.resize(n);
+        out.public_keys.resize(n);
+        for (size_t i = 0; i < n; i++) {
+            std::memcpy(out.signatures[i].bytes.data(), &sg[96 * i], 96);
+            std::memcpy(out.public_keys[i].bytes.data(), &pk[48 * i], 48);
+        }
+        return out;
+    }
+    // BLS::verify (bls.rs:427-458) for n (pk, msg, sig) triples: the same pairing check the gadget witnesses, values only (no witness tensor).
+    // An identity or undecodable key / signature is Err(..) in the reference and `false` here, with the reason in `status` ([n][2], BLSW_ST_*).
+    static std::vector<bool> verify(const Parameters&, const std::vector<PublicKey>& pks, const std::vector<std::vector<uint8_t>>& messages,
+                                    const std::vector<Signature>& sigs, std::vector<int32_t>* status = nullptr) {
+        const size_t n = pks.size();
+        if (n == 0 || messages.size() != n || sigs.size() != n) throw Error("BLS::verify: one message and one signature per key", BLSW_ERR_ARG);
+        const uint32_t msg_len = (uint32_t)messages[0].size();
+        std::vector<uint8_t> pk(n * 48), sg(n * 96), msg(n * (size_t)msg_len);
+        for (size_t i = 0; i < n; i++) {
+            if (messages[i].size() != msg_len) throw Error("BLS::verify: messages of one length per batch", BLSW_ERR_ARG);
+            std::memcpy(&pk[48 * i], pks[i].bytes.data(), 48);
+            std::memcpy(&sg[96 * i], sigs[i].bytes.data(), 96);
+            if (msg_len) std::memcpy(&msg[(size_t)msg_len * i], messages[i].data(), msg_len);
+        }
+        blsw_engine_options_t opt;
+        check(blsw_engine_options_default(&opt), "blsw_engine_options_default");
+        uint64_t bytes = 0;
+        check(blsw_engine_workspace_bytes_ex(n, msg_len, 1, 1, &opt, &bytes), "blsw_engine_workspace_bytes_ex");
+        detail::DeviceBytes ws(bytes), d_pk(pk.size()), d_sg(sg.size()), d_msg(msg.size()), d_pk_xy(n * 96), d_sg_xy(n * 192), d_st(n * 8), d_res(n * 4);
+        d_pk.upload(pk.data(), pk.size());
+        d_sg.upload(sg.data(), sg.size());
+        if (!msg.empty()) d_msg.upload(msg.data(), msg.size());
+        blsw_engine_t* e = nullptr;
+        check(blsw_engine_create_ex(&e, n, msg_len, 1, 1, &opt, ws.get(), bytes), "blsw_engine_create_ex");
+        int rc = blsw_engine_submit_bytes(e, static_cast<const uint8_t*>(d_pk.get()), static_cast<const uint8_t*>(d_sg.get()), static_cast<const uint8_t*>(d_msg.get()),
+                                          static_cast<uint64_t*>(d_pk_xy.get()), static_cast<uint64_t*>(d_sg_xy.get()), static_cast<int32_t*>(d_st.get()), nullptr, 0,
+                                          static_cast<int32_t*>(d_res.get()), nullptr);
+        if (rc == BLSW_OK) rc = blsw_engine_flush(e, nullptr);
+        hipError_t he = hipDeviceSynchronize();
+        blsw_engine_destroy(e);
+        check(rc, "blsw_engine_submit_bytes / flush");
+        hip_check(he, "hipDeviceSynchronize");
+        std::vector<int32_t> r(n);
+        d_res.download(r.data(), n * 4);
+        if (status) {
+            status->resize(2 * n);
+            d_st.download(status->data(), n * 8);
+        }
+        std::vector<bool> out(n);
+        for (size_t i = 0; i < n; i++) out[i] = r[i] == 1;
+        return out;
     }
 };
 

@@ -2,9 +2,13 @@
 // above the C ABI. Same inputs, same statements, same assertion; the three messages of the reference's loop are the three systems of one
 // ConstraintSystem batch here. Prints key=value pairs for tests/test_gpu_parity.py (witness digest of system 0 against the oracle).
 //   gadget_test [constant|witness] [count-constraints]
+//   gadget_test sign <file>    every line "<sk hex, big-endian> <msg32 hex>": BLS::sign + PublicKey::from(&sk) for the batch (tests/tests.rs:202-237); prints
+//                              "<status> <sig96 hex> <pk48 hex>" per line
+//   gadget_test verify <file>  every line "<pk48 hex> <msg32 hex> <sig96 hex>": BLS::verify for the batch (tests/tests.rs:239-268); prints "<0/1> <st_pk> <st_sig>"
 //   gadget_test aggregate      the reference's test_aggregate_verify and test_aggregate_verify_neg (constraints.rs:378-521) as the two systems of one batch
 #include <cstdio>
 #include <cstring>
+#include <string>
 
 #include "blsw.hpp"
 
@@ -43,7 +47,57 @@ static int aggregate_tests() {
     return 0;
 }
 
+static std::string hex(const uint8_t* p, size_t n) {
+    static const char* d = "0123456789abcdef";
+    std::string s;
+    for (size_t i = 0; i < n; i++) {
+        s += d[p[i] >> 4];
+        s += d[p[i] & 15];
+    }
+    return s;
+}
+// the native scheme through the same header: BLS::sign / BLS::verify over the lines of a file
+static int native_tests(const char* what, const char* path) {
+    FILE* f = fopen(path, "r");
+    if (!f) return 20;
+    char a[256], b[256], c[256];
+    if (!strcmp(what, "sign")) {
+        std::vector<SecretKey> sks;
+        std::vector<std::vector<uint8_t>> msgs;
+        while (fscanf(f, "%255s %255s", a, b) == 2) {
+            sks.push_back(SecretKey::try_from(a));
+            msgs.push_back(detail::unhex(b, 32));
+        }
+        fclose(f);
+        const BLS::Signed r = BLS::sign(Parameters{}, sks, msgs);
+        for (size_t i = 0; i < sks.size(); i++)
+            printf("%d %s %s\n", r.status[i], hex(r.signatures[i].bytes.data(), 96).c_str(), hex(r.public_keys[i].bytes.data(), 48).c_str());
+        return 0;
+    }
+    std::vector<PublicKey> pks;
+    std::vector<Signature> sigs;
+    std::vector<std::vector<uint8_t>> msgs;
+    while (fscanf(f, "%255s %255s %255s", a, b, c) == 3) {
+        pks.push_back(PublicKey::try_from(a));
+        msgs.push_back(detail::unhex(b, 32));
+        sigs.push_back(Signature::try_from(c));
+    }
+    fclose(f);
+    std::vector<int32_t> st;
+    const std::vector<bool> ok = BLS::verify(Parameters{}, pks, msgs, sigs, &st);
+    for (size_t i = 0; i < pks.size(); i++) printf("%d %d %d\n", (int)ok[i], st[2 * i], st[2 * i + 1]);
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc > 2 && (!strcmp(argv[1], "sign") || !strcmp(argv[1], "verify"))) {
+        try {
+            return native_tests(argv[1], argv[2]);
+        } catch (const Error& e) {
+            fprintf(stderr, "%s\n", e.what());
+            return 10;
+        }
+    }
     if (argc > 1 && !strcmp(argv[1], "aggregate")) {
         try {
             return aggregate_tests();

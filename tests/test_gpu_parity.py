@@ -1222,6 +1222,38 @@ def test_c_caller_submit_bytes_fixtures(pkg, tmp_path):
     assert all((a == 0 and b == 0) or not c["output"] for (a, b), c in zip(st, cases))
 
 
+def test_cpp_host_mirror_native_scheme(pkg, oracle, tmp_path):
+    """The native scheme through include/blsw.hpp: BLS::sign + PublicKey::from(&sk) over the reference's sign fixtures (tests/tests.rs:202-237; a zero
+    key is Err(InvalidSecretKey)) and BLS::verify over all 29 verify fixtures (tests/tests.rs:239-268), each as one batch from a C++ host."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "tests", "cpp_caller")])
+    exe = os.path.join(root, "tests", "cpp_caller", "gadget_test")
+    cases = [c for _, c in eth_cases("sign")]
+    f = tmp_path / "sign.txt"
+    f.write_text("".join("%s %s\n" % (c["input"]["privkey"][2:], c["input"]["message"][2:]) for c in cases))
+    lines = subprocess.check_output([exe, "sign", str(f)], text=True, timeout=300).split("\n")[:len(cases)]
+    n_err = 0
+    for ln, c in zip(lines, cases):
+        st, sig, pk = ln.split()
+        if c["output"] is None:
+            assert int(st) == pkg.ST_INVALID_SECRET_KEY
+            n_err += 1
+        else:
+            assert int(st) == 0 and sig == c["output"][2:]
+            assert bytes.fromhex(pk) == oracle.sk_to_pk(int(c["input"]["privkey"], 16))
+    assert n_err == 1
+    cases = [c for _, c in eth_cases("verify")]
+    f = tmp_path / "verify.txt"
+    f.write_text("".join("%s %s %s\n" % (c["input"]["pubkey"][2:], c["input"]["message"][2:], c["input"]["signature"][2:]) for c in cases))
+    lines = subprocess.check_output([exe, "verify", str(f)], text=True, timeout=300).split("\n")[:len(cases)]
+    for ln, c in zip(lines, cases):
+        ok, st_pk, st_sig = (int(v) for v in ln.split())
+        assert bool(ok) == bool(c["output"])
+        assert not c["output"] or (st_pk, st_sig) == (0, 0)
+
+
 def test_gpu_witness_satisfies_product_matrices(pkg, oracle):
     """f1: witness vectors produced by the HIP kernels satisfy the constraint matrices emitted by the product
     (blsw_matrices_*: A z o B z = C z on every one of the 713 891 constraints; evaluator in the test harness) — single-key
