@@ -45,8 +45,13 @@ __global__ __launch_bounds__(64) BLSW_CHAIN_ATTR void BLSW_K(k_cofactor_chunk)(G
     const uint64_t I = t - (uint64_t)c * N;
     LaneId id = lane_id(g, I);
     Proj<OpsFp2> q0 = ld_proj2(g.ws.q + I, N), q1 = ld_proj2(g.ws.q + 6 * N + I, N);
+#if defined(BLSW_COFACTOR_LDS) && !defined(BLSW_KVARIANT_INL)
+    chain_cofactor_chunk(EMITJ(g, id, off_add, stride_hash), EMITJ(g, id, off_cofactor, stride_hash), q0, q1, c, CoeffStrided{g.ws.coeff_h + I, N}, true);
+#else
     chain_cofactor_chunk(EMITJ(g, id, off_add, stride_hash), EMITJ(g, id, off_cofactor, stride_hash), q0, q1, c, CoeffStrided{g.ws.coeff_h + I, N});
+#endif
 }
+
 __global__ __launch_bounds__(64) BLSW_CHAIN_ATTR void BLSW_K(k_cofactor_join)(Group g) {
     if (g.chain_prio) __builtin_amdgcn_s_setprio(3);
     uint64_t I = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -390,6 +390,9 @@ __global__ void k_place_runs(const Fp* __restrict__ tiles, uint64_t first, uint3
                              uint32_t K, uint32_t tile_w);
 __global__ void k_place_rows(const Fp* __restrict__ rows, uint32_t n_rows, uint32_t dst_off, uint64_t* __restrict__ d_witness, uint64_t stride);
 // the two compilations of the chain units as one table
+#if defined(BLSW_COFACTOR_LDS)
+__global__ void k_cofactor_loop_lds(Group g);
+#endif
 struct ChainKernels {
     void (*sha)(Group, int, int);
     void (*g1)(Group);
@@ -407,6 +410,9 @@ inline void launch_cofactor(const ChainKernels& ck, bool chunked, const Group& g
     const unsigned g1 = (unsigned)((g.N + 63) / 64), g3 = (unsigned)((3 * g.N + 63) / 64);
     if (chunked) {
         hipLaunchKernelGGL(ck.cofactor_chunk, dim3(g3), dim3(64), 0, st, g);
+#if defined(BLSW_COFACTOR_LDS)
+        if (ck.cofactor_chunk == k_cofactor_chunk) hipLaunchKernelGGL(k_cofactor_loop_lds, dim3(g3), dim3(64), 0, st, g);
+#endif
         hipLaunchKernelGGL(ck.cofactor_join, dim3(g1), dim3(64), 0, st, g);
     } else {
         hipLaunchKernelGGL(ck.cofactor, dim3(g1), dim3(64), 0, st, g);
