@@ -141,7 +141,26 @@ def cpu_baseline(args, d_pk, d_msg, d_sig, n):
     t1 = time.perf_counter()
     oracle.witness_batch(h_pk, h_msg, h_sig, threads=cores, want_digests=False)
     all_dt = time.perf_counter() - t1
+    # SURVEY 8d config 1 as written: the single instance the reference hard-codes (constraints.rs:337-343 =
+    # tests/test_cases/verify/verify_valid_case_2ea479adf8c40300.json), constraint synthesis + witness generation on one thread
+    single_ms, single_ok = None, None
+    try:
+        case = json.load(open(os.path.join(ROOT, "tests", "golden", "ethereum_bls12_381_v0.1.2", "verify", "verify_valid_case_2ea479adf8c40300.json")))
+        unhex = oracle_lib.unhex
+        pk_xy = oracle.g1_decompress(unhex(case["input"]["pubkey"]))[1]
+        sig_xy = oracle.g2_decompress(unhex(case["input"]["signature"]))[1]
+        msg = unhex(case["input"]["message"])
+        oracle.witness(pk_xy, msg, sig_xy, want_vector=False)  # warm
+        reps = 5
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            r = oracle.witness(pk_xy, msg, sig_xy, want_vector=False)
+        single_ms = (time.perf_counter() - t1) / reps * 1e3
+        single_ok = bool(r[2]) == bool(case["output"])
+    except Exception as exc:  # noqa: BLE001 (the baseline line survives a missing fixture)
+        single_ok = "%s: %s" % (type(exc).__name__, exc)
     return {"value": m / all_dt, "unit": "instances/s", "cores": cores, "kind": "port", "value_1thread": m1 / one_dt,
+            "single_case_ms": single_ms, "single_case": "verify_valid_case_2ea479adf8c40300.json (= constraints.rs:337-343), one thread, mean of 5", "single_case_result_ok": single_ok,
             "sample": "first %d instances of the bench batch through the C++ restatement of the reference path (oracle/, %s), %d threads: %.2f s; "
                       "first %d instances on one thread: %.2f s" % (m, build, cores, all_dt, m1, one_dt)}
 
@@ -158,7 +177,7 @@ def allgather_leg(args, pkg, sharding, dist, dev, inputs, lay, world):
     # consumer mode: groups of chains run ahead into the staging, a step is expanded into its ring tensor when the gather has
     # released that tensor's previous user
     group = max(1, min(args.allgather_group, steps // 2))
-    eng = pkg.WitnessEngine(n, 32, max_steps=group, device=dev, n_buffers=max(2, min(3, (steps + group - 1) // group)), consumer_mode=1)
+    eng = pkg.WitnessEngine(n, 32, max_steps=group, device=dev, n_buffers=max(2, min(3, (steps + group - 1) // group)), consumer_mode=1, group_ramp=1)
     outs = [eng.new_witness_tensor() for _ in range(ring)]
     results = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(ring)]
     chunk = max(1, min(args.allgather_chunk, n))
@@ -209,7 +228,7 @@ def allgather_leg(args, pkg, sharding, dist, dev, inputs, lay, world):
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     eng.close()
-    return float(t.item()), steps, {"form": "full", "micro_batch_instances_per_rank": chunk, "ring": ring, "group_steps": group, "consumer_mode": True,
+    return float(t.item()), steps, {"form": "full", "world": world, "backend": dist.get_backend(), "micro_batch_instances_per_rank": chunk, "ring": ring, "group_steps": group, "consumer_mode": True,
                                     "consumer": "blsw_witness_digest over each gathered micro-batch",
                                     "bytes_received_per_gpu_per_step": (world - 1) * n * lay["n_witness"] * 48}
 
@@ -225,7 +244,7 @@ def allgather_leg_compact(args, pkg, sharding, dist, dev, inputs, lay, world):
     steps = min(args.allgather_steps, args.steps)
     group = max(1, min(args.allgather_group, steps // 2))
     ring = 4  # compact buffers; consumer mode: a step leaves for its buffer when the gather has released the buffer's previous user
-    eng = pkg.WitnessEngine(n, 32, max_steps=group, device=dev, n_buffers=max(2, min(3, (steps + group - 1) // group)), consumer_mode=1)
+    eng = pkg.WitnessEngine(n, 32, max_steps=group, device=dev, n_buffers=max(2, min(3, (steps + group - 1) // group)), consumer_mode=1, group_ramp=1)
     cbufs = eng.new_compact_buffer(ring)
     results = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(ring)]
     wit = eng.new_witness_tensor()
@@ -286,7 +305,7 @@ def allgather_leg_compact(args, pkg, sharding, dist, dev, inputs, lay, world):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     cb = eng.compact_bytes()
     eng.close()
-    return float(t.item()), steps, {"form": "compact", "world": world, "rccl_ranks": dist.get_world_size(), "group_steps": group, "ring": ring, "consumer_mode": True,
+    return float(t.item()), steps, {"form": "compact", "world": world, "backend": dist.get_backend(), "ranks": dist.get_world_size(), "group_steps": group, "ring": ring, "consumer_mode": True,
                                     "overlap": "all-gather of step k + 1 on a communication stream beside expansion + digest of step k (two gathered buffers)" if overlap else "none (one stream: world 1, the gather is a local copy)",
                                     "wire_bytes_per_instance": cb / n,
                                     "bytes_received_per_gpu_per_step": (world - 1) * cb,
@@ -388,8 +407,12 @@ def main():
     # witness vectors a direct-mode engine (chains write in place, no staging, no expansion ordering) produces for that batch
     ring_digests = [pkg.witness_digest(o).cpu() for o in outs]
     gathered_ok = None
+    per_rank_dt = [dt]
     if dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)  # each rank's own clock over its timed region: a straggler shows as min << max
+        per_rank_dt = [float(x.item()) for x in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         allres = sharding.all_gather_results(results[0], n * world)  # result shards only (multi-GPU)
@@ -435,7 +458,8 @@ def main():
         try:  # the second leg never takes the headline line down with it
             ag = leg(args, pkg, sharding, dist, dev, (d_pk, d_msg, d_sig), lay, world)
         except Exception as exc:  # noqa: BLE001 (reported in the JSON line)
-            ag = (None, 0, {"form": args.allgather_form, "error": "%s: %s" % (type(exc).__name__, exc)})
+            ag = (None, 0, {"form": args.allgather_form, "backend": dist.get_backend(), "error": "%s: %s" % (type(exc).__name__, exc)})
+    dist_backend = dist.get_backend() if dist else None
     if dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -476,6 +500,10 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
+        # generation only: no data-path collective inside the timed region (the all-gather leg is value_with_allgather below)
+        "value_generation_only": value,
+        "per_rank": {"instances_per_s_min": n * args.steps / max(per_rank_dt), "instances_per_s_max": n * args.steps / min(per_rank_dt),
+                     "seconds": per_rank_dt, "backend": dist_backend},
         "dtype": "u32 (381-bit Montgomery integers mod the BLS12-381 prime as 12 x 32-bit limbs in memory, products on 14 x 28-bit limbs with 64-bit columns; SHA-256 words)",
         "data": "synthetic",
         "config": {"workload": "configs[1]: batch of 1024 independent BLS-verify instances per GPU per step (1024 distinct messages, 16 keys, every 16th tampered), 32-byte messages, full witness vectors written",

@@ -29,7 +29,7 @@ class blsw_layout_t(ctypes.Structure):
 
 
 class blsw_engine_options_t(ctypes.Structure):
-    _fields_ = [("device", ctypes.c_int32)] + [(n, ctypes.c_uint32) for n in "n_keys pairing_mode g2_mode expand_variant expand_store prio_mode place_lds consumer_mode output_form chain_variant n_pairs cofactor_mode params_mode".split()]
+    _fields_ = [("device", ctypes.c_int32)] + [(n, ctypes.c_uint32) for n in "n_keys pairing_mode g2_mode expand_variant expand_store prio_mode place_lds consumer_mode output_form chain_variant n_pairs cofactor_mode params_mode group_ramp".split()]
 
 
 class blsw_matrices_info_t(ctypes.Structure):
@@ -172,7 +172,7 @@ def engine_options(**overrides):
         o.pairing_mode = 1
     if env.get("BLSW_G2", "")[:1] == "t" and o.pairing_mode == 0:
         o.g2_mode = 1
-    for var, field in (("BLSW_CHAIN_VARIANT", "chain_variant"), ("BLSW_COFACTOR_MODE", "cofactor_mode"), ("BLSW_EXPAND_VARIANT", "expand_variant"), ("BLSW_EXPAND_NT", "expand_store"), ("BLSW_PRIO_MODE", "prio_mode"), ("BLSW_PLACE_LDS", "place_lds")):
+    for var, field in (("BLSW_CHAIN_VARIANT", "chain_variant"), ("BLSW_COFACTOR_MODE", "cofactor_mode"), ("BLSW_EXPAND_VARIANT", "expand_variant"), ("BLSW_EXPAND_NT", "expand_store"), ("BLSW_PRIO_MODE", "prio_mode"), ("BLSW_PLACE_LDS", "place_lds"), ("BLSW_GROUP_RAMP", "group_ramp")):
         if env.get(var):
             setattr(o, field, int(env[var]))
     names = {"pairing_mode": {"team": 0, "lane": 1}, "g2_mode": {"lane": 0, "team": 1}, "params_mode": PARAMS_MODES}
@@ -401,7 +401,7 @@ class WitnessEngine:
         does not overwrite it earlier."""
         rc = lib().blsw_engine_output_consumed(self._e, witness.data_ptr(), self._stream(stream))
         if rc:
-            raise BlswError("blsw_engine_output_consumed failed: %d" % rc)
+            raise (BlswBusy if rc == ERR_BUSY else BlswError)("blsw_engine_output_consumed failed: %d" % rc)
 
     def expand_stats(self):
         """(number of k_sha_expand launches since the last call, their average duration in ms); synchronises with them."""
@@ -650,7 +650,7 @@ def verify_multi(parameters, public_keys, messages, signature, want_witness=True
     return res, wit
 
 
-DIGEST_C = (0x9E3779B97F4A7C15, 0xC2B2AE3D27D4EB4F)
+DIGEST_KEY, DIGEST_A = 0x9E3779B1, 0x85EBCA6B  # include/blsw.h: blsw_witness_digest
 
 
 def witness_digest(witness, n_witness=None, out=None, stream=None):
@@ -668,22 +668,19 @@ def witness_digest(witness, n_witness=None, out=None, stream=None):
 
 
 def witness_digest_reference(words):
-    """The same digest in numpy (host-side definition used by consumers / tests): `words` = the instance's u64 words."""
+    """The same digest in numpy (host-side definition used by consumers / tests; include/blsw.h): `words` = the instance's u64 words."""
     import numpy as np
 
-    w = np.ascontiguousarray(words, dtype=np.uint64).reshape(-1)
-    k = np.arange(1, w.size + 1, dtype=np.uint64)
-    out = []
+    x = np.ascontiguousarray(words, dtype=np.uint64).reshape(-1).view(np.uint32).reshape(-1, 4)  # 16-byte pieces of little-endian u32 words
+    key = ((np.arange(1, x.shape[0] + 1, dtype=np.uint64) * np.uint64(DIGEST_KEY)) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    a = np.uint32(DIGEST_A)
     with np.errstate(over="ignore"):
-        for c in DIGEST_C:
-            z = w + k * np.uint64(c)
-            z ^= z >> np.uint64(30)
-            z *= np.uint64(0xBF58476D1CE4E5B9)
-            z ^= z >> np.uint64(27)
-            z *= np.uint64(0x94D049BB133111EB)
-            z ^= z >> np.uint64(31)
-            out.append(int(z.sum(dtype=np.uint64)))
-    return out
+        t = [(x[:, 0] + key), (x[:, 1] + key + a), (x[:, 2] + key + np.uint32(2) * a), (x[:, 3] + key + np.uint32(3) * a)]
+        prod = t[0].astype(np.uint64) * t[1].astype(np.uint64) + t[2].astype(np.uint64) * t[3].astype(np.uint64)
+        d0 = int(prod.sum(dtype=np.uint64))
+        lo = int(((x[:, 0] ^ key) + (x[:, 2] ^ ~key)).sum(dtype=np.uint32))
+        hi = int(((x[:, 1] ^ key) + (x[:, 3] ^ ~key)).sum(dtype=np.uint32))
+    return [d0, lo | (hi << 32)]
 
 
 def microbench(which, iters=4096, blocks=4096):

@@ -111,6 +111,8 @@ struct blsw_engine {
     hipEvent_t consumed_ev[BLSW_MAX_CONSUMED];
     bool consumed_live[BLSW_MAX_CONSUMED];  // a release has been recorded and not yet waited for
     bool held[BLSW_MAX_CONSUMED];           // consumer mode: a step was materialised into this output and it has not been released
+    uint32_t refs[BLSW_MAX_CONSUMED];       // consumer mode: accepted steps that will be materialised into this output (slot reserved at submit)
+    uint32_t ramp_pos = 0;                  // options.group_ramp: launch groups since creation / the last flush (group sizes 2, 4, 8, ... max_steps)
     bool staged = false;  // false: direct mode (max_steps == 1, no staging; witnesses written in place by the chains)
     bool chains_inlined = false;  // which compilation of the chain kernels (options.chain_variant; kcommon.cuh: BLSW_K)
     uint32_t cofactor_mode = 0;  // clear_cofactor2 with its three chunks on three lanes: 0 by group size, 1 never, 2 always (options.cofactor_mode)
@@ -200,19 +202,24 @@ constexpr uint32_t dbg_skip = 0;
 
 static int consumed_slot(blsw_engine* e, const void* ptr) {
     for (int c = 0; c < BLSW_MAX_CONSUMED; c++)
-        if (e->consumed_ptr[c] == ptr && (e->consumed_live[c] || e->held[c])) return c;
+        if (e->consumed_ptr[c] == ptr && (e->consumed_live[c] || e->held[c] || e->refs[c])) return c;
     return -1;
 }
 // a free slot of the release table; a recorded release whose event has completed needs no wait any more and is recycled
 static int free_consumed_slot(blsw_engine* e) {
     for (int c = 0; c < BLSW_MAX_CONSUMED; c++)
-        if (!e->consumed_live[c] && !e->held[c]) return c;
+        if (!e->consumed_live[c] && !e->held[c] && !e->refs[c]) return c;
     for (int c = 0; c < BLSW_MAX_CONSUMED; c++)
-        if (e->consumed_live[c] && !e->held[c] && hipEventQuery(e->consumed_ev[c]) == hipSuccess) {
+        if (e->consumed_live[c] && !e->held[c] && !e->refs[c] && hipEventQuery(e->consumed_ev[c]) == hipSuccess) {
             e->consumed_live[c] = false;
             return c;
         }
     return -1;
+}
+// consumer mode: the output a step will be materialised into (its witness tensor, else its compact buffer), or nullptr if untracked
+static const void* tracked_output(const blsw_engine* e, const StepDesc& d) {
+    const void* ptr = d.out ? static_cast<const void*>(d.out) : d.compact;
+    return (e->opt.consumer_mode && e->staged) ? ptr : nullptr;
 }
 // a consumer's release of an output (blsw_engine_output_consumed): the stream that is about to overwrite it waits for it
 static void wait_released(blsw_engine* e, hipStream_t stream, const void* ptr) {
@@ -281,21 +288,18 @@ static int pump(blsw_engine* e) {
         const Job j = e->jobs.front();
         GroupBuf& b = e->buf[j.buf];
         const StepDesc& d = b.h_desc[j.s];
-        const void* ptr = d.out ? static_cast<const void*>(d.out) : d.compact;
-        const bool track = e->opt.consumer_mode && e->staged && ptr;
+        const void* ptr = tracked_output(e, d);
         int slot = -1;
-        if (track) {
-            slot = consumed_slot(e, ptr);
-            if (slot >= 0 && e->held[slot]) break;
-            if (slot < 0) slot = free_consumed_slot(e);
-            if (slot < 0) return BLSW_ERR_ARG;  // more than BLSW_MAX_CONSUMED outputs in use: nothing issued, the step stays queued
-        }
-        if (slot >= 0 && e->consumed_ptr[slot] != ptr) {  // a fresh slot for this output (an existing one keeps its recorded release)
-            e->consumed_ptr[slot] = ptr;
-            e->consumed_live[slot] = false;
+        if (ptr) {
+            slot = consumed_slot(e, ptr);  // reserved when the step was accepted (engine_submit): it exists
+            if (slot < 0) return BLSW_ERR_ARG;
+            if (e->held[slot]) break;
         }
         materialise(e, j.buf, j.s);
-        if (slot >= 0) e->held[slot] = true;
+        if (slot >= 0) {
+            e->held[slot] = true;
+            e->refs[slot]--;
+        }
         e->jobs.pop_front();
         e->materialised++;
         if (--b.jobs_left == 0) hipEventRecord(b.ev_done, e->place);
@@ -416,6 +420,7 @@ static int launch_group(blsw_engine* e) {
     b.steps = steps;
     e->launched += steps;
     e->pending = 0;
+    if (e->ramp_pos < 30) e->ramp_pos++;
     e->cur = (e->cur + 1) % e->nbuf;
     if (hip_ok(hipGetLastError(), "launch")) return BLSW_ERR_HIP;
     return pump(e);
@@ -453,6 +458,7 @@ int blsw_engine_options_default(blsw_engine_options_t* o) {
     o->n_pairs = 0;
     o->cofactor_mode = 0;
     o->params_mode = 0;
+    o->group_ramp = 0;
     return BLSW_OK;
 }
 
@@ -491,7 +497,7 @@ int blsw_engine_create_ex(blsw_engine_t** out, uint64_t n, uint32_t msg_len, uin
     // place while the chains run and could not honour a held output
     if (options->consumer_mode > 1 || (options->consumer_mode == 1 && max_steps == 1 && n_buffers == 1)) return BLSW_ERR_ARG;
     if (options->pairing_mode > 1 || options->g2_mode > 1 || (options->g2_mode == 1 && options->pairing_mode != 0) || options->expand_store > 3 ||
-        options->prio_mode > 2 || options->output_form > 1 || options->chain_variant > 2 || options->cofactor_mode > 2 || (options->expand_variant & 0xff) > 5 || (options->expand_variant >> 9) || options->n_keys > 65535 ||
+        options->prio_mode > 2 || options->group_ramp > 1 || options->output_form > 1 || options->chain_variant > 2 || options->cofactor_mode > 2 || (options->expand_variant & 0xff) > 9 || (options->expand_variant >> 9) || options->n_keys > 65535 ||
         (options->n_keys && options->g2_mode) || options->n_pairs > 4096)
         return BLSW_ERR_ARG;
     // N+1-pair product (options.n_pairs = K > 1): a staged engine with the default kernel modes; its expansion launch has one row of
@@ -544,6 +550,7 @@ int blsw_engine_create_ex(blsw_engine_t** out, uint64_t n, uint32_t msg_len, uin
         e->consumed_ev[i] = nullptr;
         e->consumed_live[i] = false;
         e->held[i] = false;
+        e->refs[i] = 0;
     }
     e->nbuf = (int)n_buffers;
     int rc = BLSW_OK;
@@ -626,22 +633,48 @@ int blsw_engine_destroy(blsw_engine_t* e) {
     return BLSW_OK;
 }
 
+// Can a step with this output be accepted now? BLSW_ERR_BUSY (nothing queued, nothing issued) when the buffer's previous group still
+// has steps waiting for their outputs, or when the release table has no slot for a new output (BLSW_MAX_CONSUMED distinct outputs
+// held, reserved or with an unfinished release: the caller drains / releases and calls again).
+static int submit_admissible(blsw_engine* e, const void* tracked) {
+    GroupBuf& b = e->buf[e->cur];
+    if (e->pending == 0 && b.used && b.jobs_left) return BLSW_ERR_BUSY;
+    if (tracked && consumed_slot(e, tracked) < 0 && free_consumed_slot(e) < 0) return BLSW_ERR_BUSY;
+    return BLSW_OK;
+}
+// steps of the next launch group: max_steps, or with options.group_ramp 2, 4, 8, ... up to max_steps for the first groups after creation /
+// a flush (the first outputs exist after the chain latency of a SMALL group: a consumer starts ~25 ms earlier)
+static uint32_t group_target(const blsw_engine* e) {
+    if (!e->opt.group_ramp || e->ramp_pos >= 30) return e->max_steps;
+    const uint32_t t = 2u << e->ramp_pos;
+    return t < e->max_steps ? t : e->max_steps;
+}
 static int engine_submit(blsw_engine_t* e, const StepDesc& step, void* stream_) {
     if (step.out && step.out_stride < e->L.n_witness) return BLSW_ERR_ARG;
     DeviceGuard guard(e->device);
     GroupBuf& b = e->buf[e->cur];
+    const void* tracked = tracked_output(e, step);
+    // the buffer's previous group must have been fully placed before its staging is overwritten; in consumer mode some of its steps
+    // may still wait for their outputs: the caller has to drain (wait_step / output_consumed) first. Checked before anything is taken.
+    if (int rc = submit_admissible(e, tracked)) return rc;
     if (e->pending == 0 && b.used) {
-        // the buffer's previous group must have been fully placed before its staging is overwritten; in consumer mode some of
-        // its steps may still wait for their outputs: the caller has to drain (wait_step / output_consumed) first
-        if (b.jobs_left) return BLSW_ERR_BUSY;
         if (hip_ok(hipEventSynchronize(b.ev_done), "event sync")) return BLSW_ERR_HIP;
         b.used = false;
     }
     if (hip_ok(hipEventRecord(b.ev_in[e->pending], reinterpret_cast<hipStream_t>(stream_)), "event record")) return BLSW_ERR_HIP;
+    if (tracked) {  // reserve the output's slot of the release table: pump() can no longer run out of slots for an accepted step
+        int slot = consumed_slot(e, tracked);
+        if (slot < 0) {
+            slot = free_consumed_slot(e);
+            e->consumed_ptr[slot] = tracked;
+            e->consumed_live[slot] = false;
+        }
+        e->refs[slot]++;
+    }
     b.h_desc[e->pending] = step;
     e->pending++;
     e->submitted++;
-    if (e->pending == e->max_steps) return launch_group(e);
+    if (e->pending >= group_target(e)) return launch_group(e);
     return BLSW_OK;
 }
 int blsw_engine_submit(blsw_engine_t* e, const uint64_t* d_pk_xy, const uint64_t* d_sig_xy, const uint8_t* d_msg, uint64_t* d_witness,
@@ -667,8 +700,7 @@ int blsw_engine_submit_bytes(blsw_engine_t* e, const uint8_t* d_pk48, const uint
     if (d_witness && witness_stride < e->L.n_witness) return BLSW_ERR_ARG;
     DeviceGuard guard(e->device);
     // the decode is issued only if the step can be taken (same conditions as engine_submit: nothing may be half done on BUSY)
-    GroupBuf& b = e->buf[e->cur];
-    if (e->pending == 0 && b.used && b.jobs_left) return BLSW_ERR_BUSY;
+    if (int rc = submit_admissible(e, (e->opt.consumer_mode && e->staged) ? static_cast<const void*>(d_witness) : nullptr)) return rc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream_);
     hipLaunchKernelGGL(k_decode, dim3((unsigned)((2 * e->n + 63) / 64)), dim3(64), 0, st, d_pk48, d_sig96, e->n, d_pk_xy, d_sig_xy, d_status);
     if (hip_ok(hipGetLastError(), "launch")) return BLSW_ERR_HIP;
@@ -740,6 +772,7 @@ int blsw_engine_flush(blsw_engine_t* e, void* stream_) {
     DeviceGuard guard(e->device);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream_);
     int rc = launch_group(e);
+    e->ramp_pos = 0;  // the pipeline drains: the next submits start with small groups again (options.group_ramp)
     if (rc) return rc;
     if ((rc = pump(e))) return rc;
     for (int k = 0; k < e->nbuf; k++)
@@ -780,7 +813,7 @@ int blsw_engine_output_consumed(blsw_engine_t* e, const void* d_output, void* st
     DeviceGuard guard(e->device);
     int slot = consumed_slot(e, d_output);
     if (slot < 0) slot = free_consumed_slot(e);
-    if (slot < 0) return BLSW_ERR_ARG;  // more than BLSW_MAX_CONSUMED distinct outputs with a pending release or a held step
+    if (slot < 0) return BLSW_ERR_BUSY;  // more than BLSW_MAX_CONSUMED distinct outputs with a pending release, a held or an accepted step
     if (!e->consumed_ev[slot] && hip_ok(hipEventCreateWithFlags(&e->consumed_ev[slot], hipEventDisableTiming), "event create")) return BLSW_ERR_HIP;
     if (hip_ok(hipEventRecord(e->consumed_ev[slot], reinterpret_cast<hipStream_t>(stream_)), "event record")) return BLSW_ERR_HIP;
     e->consumed_ptr[slot] = d_output;

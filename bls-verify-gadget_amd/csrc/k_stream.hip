@@ -101,30 +101,76 @@ __global__ __launch_bounds__(THREADS) void k_sha_expand(ExpandArgs a) {
         }
     }
 }
-// variant 1: one piece per thread, workgroup b >= 1 writes exactly one 4 KiB-aligned chunk
-template <int NT>
-__global__ __launch_bounds__(256) void k_sha_expand_chunk(ExpandArgs a) {
+// variants 1 / 6 / 7: one piece per thread, workgroup b >= 1 writes exactly one chunk of THREADS pieces aligned to its own size
+// (256 threads: 4 KiB — alone the fastest geometry on this chip, 6.7 TB/s; 512 / 1024 threads: 8 / 16 KiB chunks, 2 / 4 x fewer workgroups)
+template <int THREADS, int NT>
+__global__ __launch_bounds__(THREADS) void k_sha_expand_chunk(ExpandArgs a) {
     if (a.prio) __builtin_amdgcn_s_setprio(3);
     uint4* out;
     const uint32_t* b;
     expand_locate(a, out, b);
     const uint32_t n_pieces = a.sha_bits * 3;
-    const uint32_t P0 = (256 - (uint32_t)((reinterpret_cast<uintptr_t>(out) >> 4) % 256)) % 256;
+    const uint32_t P0 = (THREADS - (uint32_t)((reinterpret_cast<uintptr_t>(out) >> 4) % THREADS)) % THREADS;
     expand_head<NT>(out, b, P0, n_pieces, a.canonical);
-    const uint32_t p = P0 + blockIdx.x * 256 + threadIdx.x;
+    const uint32_t p = P0 + blockIdx.x * THREADS + threadIdx.x;
     if (p >= n_pieces) return;
     const uint32_t e = p / 3, c = p - 3 * e;
     const uint32_t m = 0u - ((expand_word(b, e >> 5) >> (e & 31)) & 1u);
     const uint4 rc = expand_column(c, a.canonical);
     expand_store<NT>(&out[p], make_uint4(rc.x & m, rc.y & m, rc.z & m, rc.w & m));
 }
-// variant: low byte 0..3 = geometry, bit 8 = raised wave priority; store: 0 plain, 1 nontemporal, 2 sc1, 3 sc0 sc1 (variant 0 only)
+// variant 8: the geometry of variant 0 (384 threads x ITERS pieces 6 KiB apart, pieces counted from the first 256-byte boundary) with the
+// bit words in SCALAR registers: the 64 lanes of a wave cover 21.3 consecutive elements, i.e. one or two bit words per iteration, which
+// the wave fetches with scalar loads (wave-uniform addresses, constant address space) — 12 vector registers per lane instead of 21, so
+// that five of these waves (instead of three) fit beside a 417-register chain wave on the same SIMD
+typedef const uint32_t __attribute__((address_space(4))) * blsw_cptr;
+template <int ITERS>
+__global__ __launch_bounds__(384) void k_sha_expand_s(ExpandArgs a) {
+    constexpr int THREADS = 384;
+    uint4* out;
+    const uint32_t* b;
+    expand_locate(a, out, b);
+    const uint32_t n_pieces = a.sha_bits * 3;
+    const uint32_t P0 = (16 - (uint32_t)((reinterpret_cast<uintptr_t>(out) >> 4) % 16)) % 16;
+    expand_head<0>(out, b, P0, n_pieces, a.canonical);
+    const uint32_t pt = P0 + threadIdx.x, c = pt % 3;
+    const uint32_t e0 = blockIdx.x * ((THREADS / 3) * ITERS) + pt / 3;
+    const uint4 rc = expand_column(c, a.canonical);
+    const uint32_t sh = e0 & 31, w0 = e0 >> 5;
+    uint4* dst = out + (uint64_t)e0 * 3 + c;
+    // one path for every workgroup (the last one or two of an instance check each piece; their word indices are clamped into the
+    // instance's padded stream: a piece beyond the segment is never stored)
+    const uint32_t wu = __builtin_amdgcn_readfirstlane(w0);  // the wave's first word; a lane needs word wu or wu + 1
+    const bool second = w0 != wu;
+    const uint32_t w_last = (uint32_t)a.sha_words - 1;
+    blsw_cptr bc = (blsw_cptr)(uintptr_t)b;
+    uint32_t wa[ITERS], wb[ITERS];
+#pragma unroll
+    for (int k = 0; k < ITERS; k++) {
+        uint32_t w = wu + k * (THREADS / 96), w1 = w + 1;
+        w = w < w_last ? w : w_last;
+        w1 = w1 < w_last ? w1 : w_last;
+        wa[k] = bc[(uint64_t)(w / BLSW_BITS_CHUNK_WORDS) * (64 * BLSW_BITS_CHUNK_WORDS) + (w % BLSW_BITS_CHUNK_WORDS)];
+        wb[k] = bc[(uint64_t)(w1 / BLSW_BITS_CHUNK_WORDS) * (64 * BLSW_BITS_CHUNK_WORDS) + (w1 % BLSW_BITS_CHUNK_WORDS)];
+    }
+    const bool whole = blockIdx.x * ((THREADS / 3) * ITERS) + (P0 + THREADS - 1) / 3 + (THREADS / 3) * (ITERS - 1) < a.sha_bits;
+#pragma unroll
+    for (int k = 0; k < ITERS; k++) {
+        const uint32_t m = 0u - (((second ? wb[k] : wa[k]) >> sh) & 1u);
+        if (whole || e0 + (THREADS / 3) * k < a.sha_bits) expand_store<0>(dst + (uint64_t)k * THREADS, make_uint4(rc.x & m, rc.y & m, rc.z & m, rc.w & m));
+    }
+}
+// variant: low byte 0..9 = geometry, bit 8 = raised wave priority; store: 0 plain, 1 nontemporal, 2 sc1, 3 sc0 sc1 (variant 0 only)
 void launch_expand(uint32_t variant, uint32_t store, unsigned lds, hipStream_t st, ExpandArgs a, unsigned n_y) {
     a.prio = (variant >> 8) & 1;
     const uint32_t n_pieces = a.sha_bits * 3;
     auto grid = [&](uint32_t per_wg) { return dim3((n_pieces + per_wg - 1) / per_wg + 1, n_y); };
     switch (variant & 0xff) {
-        case 1: hipLaunchKernelGGL(k_sha_expand_chunk<0>, grid(256), dim3(256), lds, st, a); break;
+        case 1: hipLaunchKernelGGL((k_sha_expand_chunk<256, 0>), grid(256), dim3(256), lds, st, a); break;
+        case 6: hipLaunchKernelGGL((k_sha_expand_chunk<512, 0>), grid(512), dim3(512), lds, st, a); break;
+        case 7: hipLaunchKernelGGL((k_sha_expand_chunk<1024, 0>), grid(1024), dim3(1024), lds, st, a); break;
+        case 8: hipLaunchKernelGGL(k_sha_expand_s<8>, grid(384 * 8), dim3(384), lds, st, a); break;
+        case 9: hipLaunchKernelGGL(k_sha_expand_s<4>, grid(384 * 4), dim3(384), lds, st, a); break;
         case 2: hipLaunchKernelGGL((k_sha_expand<768, 8, 256, 0>), grid(768 * 8), dim3(768), lds, st, a); break;
         case 3: hipLaunchKernelGGL((k_sha_expand<768, 4, 256, 0>), grid(768 * 4), dim3(768), lds, st, a); break;
         case 4: hipLaunchKernelGGL((k_sha_expand<768, 16, 256, 0>), grid(768 * 16), dim3(768), lds, st, a); break;
@@ -216,39 +262,63 @@ __global__ __launch_bounds__(256) void k_place_rows(const Fp* __restrict__ rows,
         if (q < npieces) out[q] = src[q];
 }
 
-// Digest of witness vectors (blsw_witness_digest): d[c] = sum_k mix64(w_k + (k + 1) * C_c) over the instance's u64 words.
-// grid (chunks, n); 256 threads, each 16 bytes per iteration; block partial sums -> two atomics per block.
-__device__ __forceinline__ uint64_t mix64(uint64_t z) {
-    z ^= z >> 30;
-    z *= 0xbf58476d1ce4e5b9ull;
-    z ^= z >> 27;
-    z *= 0x94d049bb133111ebull;
-    z ^= z >> 31;
-    return z;
-}
+// Digest of witness vectors (blsw_witness_digest; the definition is in include/blsw.h). With x_j the little-endian u32 words of an
+// instance's vector, 16-byte piece q = (x_4q .. x_4q+3) and key_q = (q + 1) * BLSW_DIGEST_KEY mod 2^32:
+//   d[0] = sum_q (x_4q + key_q) (x_4q+1 + key_q + A) + (x_4q+2 + key_q + 2 A) (x_4q+3 + key_q + 3 A)   mod 2^64
+//          (32-bit sums, 32 x 32 -> 64-bit products: the NH family of UMAC with a position-derived key; ONE multiply per 8 bytes)
+//   d[1] = lo | hi << 32:  lo = sum_q (x_4q ^ key_q) + (x_4q+2 ^ ~key_q),  hi = sum_q (x_4q+1 ^ key_q) + (x_4q+3 ^ ~key_q)   mod 2^32
+// 12 vector instructions per 16 bytes (round 3: four splitmix finalizers = 90, VALU-bound at 3.9 TB/s). grid (chunks, n); 256 threads,
+// BLSW_DIGEST_ITERS pieces per thread 4 KiB apart, the loads of four pieces in flight per thread; one atomic triple per workgroup.
 __global__ __launch_bounds__(256) void k_digest(const uint64_t* __restrict__ w, uint64_t stride, uint64_t n_words, uint64_t* __restrict__ digest) {
     const uint64_t inst = blockIdx.y;
-    const ulonglong2* src = reinterpret_cast<const ulonglong2*>(w + inst * stride * 6);
-    const uint64_t n_pairs = n_words / 2;  // n_witness * 6 is even
-    uint64_t q = ((uint64_t)blockIdx.x * BLSW_DIGEST_ITERS) * 256 + threadIdx.x;
-    uint64_t d0 = 0, d1 = 0;
-#pragma unroll 4
-    for (int it = 0; it < BLSW_DIGEST_ITERS; it++, q += 256) {
-        if (q < n_pairs) {
-            ulonglong2 v = src[q];
-            const uint64_t k = 2 * q + 1;  // (index of v.x) + 1
-            d0 += mix64(v.x + k * 0x9E3779B97F4A7C15ull) + mix64(v.y + (k + 1) * 0x9E3779B97F4A7C15ull);
-            d1 += mix64(v.x + k * 0xC2B2AE3D27D4EB4Full) + mix64(v.y + (k + 1) * 0xC2B2AE3D27D4EB4Full);
+    const u32x4* src = reinterpret_cast<const u32x4*>(w + inst * stride * 6);
+    const uint32_t n_pieces = (uint32_t)(n_words / 2);  // n_witness * 6 is even
+    const uint32_t q0 = blockIdx.x * (BLSW_DIGEST_ITERS * 256) + threadIdx.x;
+    uint32_t key = (q0 + 1) * BLSW_DIGEST_KEY;
+    uint64_t d0 = 0;
+    uint32_t lo = 0, hi = 0;
+    auto piece = [&](const u32x4& v) {
+        d0 += (uint64_t)(v.x + key) * (uint64_t)(v.y + key + BLSW_DIGEST_A);
+        d0 += (uint64_t)(v.z + key + 2 * BLSW_DIGEST_A) * (uint64_t)(v.w + key + 3 * BLSW_DIGEST_A);
+        lo += (v.x ^ key) + (v.z ^ ~key);
+        hi += (v.y ^ key) + (v.w ^ ~key);
+        key += 256 * BLSW_DIGEST_KEY;
+    };
+    if (blockIdx.x * (BLSW_DIGEST_ITERS * 256) + BLSW_DIGEST_ITERS * 256 <= n_pieces) {  // whole workgroup in range
+#pragma unroll 1
+        for (int it = 0; it < BLSW_DIGEST_ITERS; it += 4) {
+            u32x4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] = __builtin_nontemporal_load(&src[q0 + (it + k) * 256]);
+#pragma unroll
+            for (int k = 0; k < 4; k++) piece(v[k]);
+        }
+    } else {
+        uint32_t q = q0;
+#pragma unroll 1
+        for (int it = 0; it < BLSW_DIGEST_ITERS; it++, q += 256) {
+            if (q < n_pieces) piece(src[q]);  // (the key advances only with the pieces read: it is not used afterwards)
         }
     }
-    // wave reduction, then one atomic pair per wave
+    // wave reduction, workgroup reduction through LDS, then one atomic triple per workgroup (the halves of d[1] are sums mod 2^32)
     for (int off = 32; off > 0; off >>= 1) {
         d0 += __shfl_down(d0, off, 64);
-        d1 += __shfl_down(d1, off, 64);
+        lo += __shfl_down(lo, off, 64);
+        hi += __shfl_down(hi, off, 64);
     }
+    __shared__ uint64_t s_d0[4];
+    __shared__ uint32_t s_lo[4], s_hi[4];
     if ((threadIdx.x & 63) == 0) {
-        atomicAdd(reinterpret_cast<unsigned long long*>(digest + inst * 2), (unsigned long long)d0);
-        atomicAdd(reinterpret_cast<unsigned long long*>(digest + inst * 2 + 1), (unsigned long long)d1);
+        s_d0[threadIdx.x >> 6] = d0;
+        s_lo[threadIdx.x >> 6] = lo;
+        s_hi[threadIdx.x >> 6] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(digest + inst * 2), (unsigned long long)(s_d0[0] + s_d0[1] + s_d0[2] + s_d0[3]));
+        uint32_t* d1 = reinterpret_cast<uint32_t*>(digest + inst * 2 + 1);
+        atomicAdd(d1, s_lo[0] + s_lo[1] + s_lo[2] + s_lo[3]);
+        atomicAdd(d1 + 1, s_hi[0] + s_hi[1] + s_hi[2] + s_hi[3]);
     }
 }
 

@@ -1,6 +1,8 @@
-"""Instance sharding across ranks (one process per GPU). Instances are fully independent:
-contiguous blocks per rank, no data-path collective. Only the per-instance result booleans (and, on request,
-fixed-size witness chunks) are exchanged, with torch.distributed (backend "nccl" = RCCL on ROCm, "gloo" on CPU)."""
+"""Instance sharding across ranks (one process per GPU). Instances are fully independent: contiguous blocks per
+rank, and GENERATION needs no collective. What is exchanged, with torch.distributed (backend "nccl" = RCCL on ROCm, "gloo" on CPU):
+the per-instance result booleans (all_gather_results), and — the north star's all-gather of witness shards — every step's batch,
+either as full witness tensors in micro-batches (stream_allgather) or in the compact wire form that each receiver expands
+(stream_allgather_compact, CompactGatherPipeline: the gather of step k + 1 beside expansion + consumption of step k)."""
 
 
 def shard_range(n_total, rank, world):
@@ -89,11 +91,14 @@ class CompactGatherPipeline:
 
     push() issues the gather of its batch FIRST and only then the expansion + consumption of the previous batch, so the device
     has both in flight. `expand(compact_r)` -> witness tensor, `consume(witness, rank, batch_index)`; both run under the consumer
-    stream. Streams may be None (CPU tensors with gloo: everything is synchronous, the order of operations is the same)."""
+    stream. Both streams or neither: None, None for CPU tensors with gloo (everything is synchronous, the order of operations is the
+    same); one stream without the other would leave the gather and the expansion unordered and is refused."""
 
     def __init__(self, world, nbytes, device, expand, consume, group=None, comm_stream=None, consumer_stream=None):
         import torch
 
+        if (comm_stream is None) != (consumer_stream is None):
+            raise ValueError("CompactGatherPipeline: pass both comm_stream and consumer_stream (they may be the same stream), or neither")
         self.torch, self.world, self.group = torch, world, group
         self.expand, self.consume = expand, consume
         self.comm, self.consumer = comm_stream, consumer_stream
@@ -154,12 +159,14 @@ class CompactGatherPipeline:
             self._consume(*prev)
 
 
-def stream_shard(pkg, n_shard=8192, batch=1024, ring=2, rank=0, world=8, buffers=6, seed=0x5EED, device=None, group=None):
+def stream_shard(pkg, n_shard=8192, batch=1024, ring=2, rank=0, world=8, buffers=6, seed=0x5EED, device=None, group=None, ramp=True):
     """One rank's shard of a sharded batch (BASELINE configs[2]: 65 536 instances over 8 GPUs = 8 192 per rank) streamed in
     micro-batches of `batch` instances through a ring of `ring` witness tensors: every tensor is drained by a consumer (the digest
     kernel blsw_witness_digest, standing in for a per-GPU prover or the gather of a micro-batch) before the engine may overwrite it.
     group > 0: consumer-mode engine with groups of `group` steps (chains run ahead into the staging, a step is expanded into its
     ring tensor when the consumer has released that tensor's previous user); group = 0: free-running engine with groups of `ring`.
+    ramp: the consumer-mode engine starts with groups of 2, 4, 8, ... steps (options.group_ramp): nothing can be consumed before the first
+    group's chains end, and a small group (cofactor chain on three lanes) ends first.
     Inputs are minted on the GPU before the timed region. -> dict (instances_per_s, digests [n_shard, 2] uint64, ...)."""
     import importlib
     import time
@@ -175,7 +182,8 @@ def stream_shard(pkg, n_shard=8192, batch=1024, ring=2, rank=0, world=8, buffers
     if group is None:
         group = max(1, min(16, steps // 2))
     if group:
-        eng = pkg.WitnessEngine(batch, 32, max_steps=group, device=dev, n_buffers=max(2, min(3, (steps + group - 1) // group)), consumer_mode=1)
+        n_groups = (steps + group - 1) // group + (2 if ramp and group > 2 else 0)
+        eng = pkg.WitnessEngine(batch, 32, max_steps=group, device=dev, n_buffers=max(2, min(3, n_groups)), consumer_mode=1, group_ramp=1 if ramp else 0)
     else:
         eng = pkg.WitnessEngine(batch, 32, max_steps=ring, device=dev, n_buffers=min(buffers, max(1, steps // ring)))
     outs = [eng.new_witness_tensor() for _ in range(ring)]
@@ -218,6 +226,6 @@ def stream_shard(pkg, n_shard=8192, batch=1024, ring=2, rank=0, world=8, buffers
     expect = np.stack(expects)
     eng.close()
     return {"rank": rank, "world": world, "first_instance": lo, "n_shard": n_shard, "batch": batch, "ring": ring, "group_steps": group or ring,
-            "consumer_mode": bool(group), "steps": steps, "seconds": dt,
+            "consumer_mode": bool(group), "group_ramp": bool(group and ramp), "steps": steps, "seconds": dt,
             "instances_per_s": n_shard / dt, "results_ok": bool((res == expect).all()), "digests": digests.cpu().numpy().view(np.uint64).reshape(n_shard, 2),
             "inputs": inputs, "sampled": 0}

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define BLSW_ABI_VERSION 8
+#define BLSW_ABI_VERSION 9
 
 #define BLSW_OK 0
 #define BLSW_ERR_ARG 1
@@ -116,7 +116,9 @@ typedef struct {
     uint32_t pairing_mode; /* 0 = six lanes per instance (default), 1 = one lane per instance (9.7 KB stack: A/B runs only) */
     uint32_t g2_mode;      /* 0 = one lane per instance (default), 1 = six lanes per instance (needs pairing_mode 0) */
     uint32_t expand_variant; /* store geometry of the SHA expansion kernel, low byte: 0 = 384 threads x 8 pieces, 1 = one 4 KiB-aligned
-                              * chunk per 256-thread workgroup, 2 / 3 / 4 = 768 threads x 8 / 4 / 16 pieces in 4 KiB-aligned chunks, 5 = 384 x 16; | 0x100 = raised wave priority */
+                              * chunk per 256-thread workgroup, 2 / 3 / 4 = 768 threads x 8 / 4 / 16 pieces in 4 KiB-aligned chunks, 5 = 384 x 16, 6 / 7 = one
+                              * 8 / 16 KiB-aligned chunk per 512- / 1024-thread workgroup, 8 / 9 = 384 x 8 / 4 with the bit words in scalar registers
+                              * (14 vector registers per lane); | 0x100 = raised wave priority */
     uint32_t expand_store; /* stores of the SHA expansion kernel: 0 plain (default), 1 nontemporal, 2 sc1, 3 sc0 sc1 (variant 0) */
     uint32_t prio_mode;    /* stream priorities: 0 chains high, 1 placement high (default), 2 equal */
     uint32_t place_lds;    /* optional occupancy limiter of the expansion kernel: bytes of dynamic LDS per workgroup */
@@ -146,6 +148,10 @@ typedef struct {
                               1 Witness (blsw_layout_params): the generator is allocated like a public key, prepare_g1(-g1) and the ell of
                               the (-g1, sig) pair emit witnesses. Single-key circuit with the default kernel modes only (n_keys 0, n_pairs <= 1,
                               pairing_mode 0). */
+    uint32_t group_ramp;   /* 0 (default): every launch group is max_steps batches (the last one of a flush: what is pending). 1: the first groups
+                              after creation / a flush are 2, 4, 8, ... batches, up to max_steps: the first witness tensors exist after the chain
+                              latency of a small group (its cofactor chain on three lanes), which is what a consumer-mode caller waits for
+                              before it can consume anything. Same witnesses either way. */
 } blsw_engine_options_t;
 /* the defaults (pure: the library reads no environment variable; measurement scripts set the fields they want to vary) */
 int blsw_engine_options_default(blsw_engine_options_t* out);
@@ -216,8 +222,10 @@ int blsw_engine_flush(blsw_engine_t* e, void* stream);
  * (max_steps <= ring). consumer_mode 1: no such rule — steps are written into their outputs in submission order, each as soon
  * as its output has been released; blsw_engine_submit returns BLSW_ERR_BUSY instead of blocking when the group buffer it needs
  * still has unwritten steps (drain: wait_step + output_consumed of the materialised steps, then submit again).
- * At most 64 distinct output pointers may have a pending release or a held step at one time (BLSW_ERR_ARG beyond; releases
- * whose event has completed are recycled). */
+ * At most 64 distinct output pointers may have a pending release, a held step or an accepted (not yet written) step at one time:
+ * a consumer-mode submit reserves its output's slot BEFORE the step is taken and returns BLSW_ERR_BUSY with nothing queued or
+ * launched when the table is full, and so does blsw_engine_output_consumed for an output the table has no slot for (releases whose
+ * event has completed are recycled: release / drain and call again). */
 int blsw_engine_submitted(blsw_engine_t* e, uint64_t* seq);
 int blsw_engine_launched(blsw_engine_t* e, uint64_t* seq);
 int blsw_engine_materialised(blsw_engine_t* e, uint64_t* seq);
@@ -249,10 +257,13 @@ int blsw_engine_expand_compact(blsw_engine_t* e, const void* d_compact, uint64_t
 int blsw_engine_expand_stats(blsw_engine_t* e, uint32_t* count, float* avg_ms);
 
 /* Position-dependent, order-independent 128-bit digest of each instance's witness vector (the consumer-side check of the
- * sharded runs): with w_k the k-th little-endian u64 word of the instance's n_witness * 6 words,
- *     d[c] = sum_k mix64(w_k + (k + 1) * C_c)  mod 2^64,  c = 0, 1,  mix64 = the splitmix64 finalizer
- *     (z ^= z >> 30; z *= 0xBF58476D1CE4E5B9; z ^= z >> 27; z *= 0x94D049BB133111EB; z ^= z >> 31),
- *     C = {0x9E3779B97F4A7C15, 0xC2B2AE3D27D4EB4F}.
+ * sharded runs). With x_j the little-endian u32 words of the instance's n_witness * 12 words, 16-byte
+ * piece q = (x_4q, x_4q+1, x_4q+2, x_4q+3), key_q = (q + 1) * 0x9E3779B1 mod 2^32 and A = 0x85EBCA6B (all sums of 32-bit words mod 2^32,
+ * products 32 x 32 -> 64 bits):
+ *     d[0] = sum_q (x_4q + key_q) * (x_4q+1 + key_q + A) + (x_4q+2 + key_q + 2 A) * (x_4q+3 + key_q + 3 A)   mod 2^64
+ *            (the NH family of UMAC with a position-derived key: one multiply per 8 bytes)
+ *     d[1] = lo | hi << 32,  lo = sum_q (x_4q ^ key_q) + (x_4q+2 ^ ~key_q),  hi = sum_q (x_4q+1 ^ key_q) + (x_4q+3 ^ ~key_q)   mod 2^32
+ *   (ABI 9; ABI <= 8 summed a splitmix64 finalizer per u64 word: four 64-bit multiplies per 16 bytes made the kernel VALU-bound.)
  *   d_witness [n][witness_stride] elements, d_digest [n][2] u64. Reads the tensor once at HBM speed. */
 int blsw_witness_digest(const uint64_t* d_witness, uint64_t witness_stride, uint64_t n, uint32_t n_witness, uint64_t* d_digest, void* stream);
 

@@ -265,6 +265,8 @@ struct BlsSignatureVerifyGadget {
         const size_t n = cs.n_;
         if (public_key.keys_.size() != n || signature.sigs_.size() != n || message.bytes().size() != n * cs.msg_len_)
             throw Error("verify: variables of another ConstraintSystem", BLSW_ERR_ARG);
+        // one circuit shape per ConstraintSystem: aggregate_verify has replaced the layout (num_witness_variables would be the aggregate circuit's)
+        if (cs.layout_.n_keys) throw Error("verify: this ConstraintSystem was synthesised by aggregate_verify; use a new one", BLSW_ERR_ARG);
         if (!cs.engine_) {
             blsw_engine_options_t opt;
             check(blsw_engine_options_default(&opt), "blsw_engine_options_default");
@@ -309,8 +311,11 @@ struct BlsSignatureVerifyGadget {
 
     // constraints.rs:153-167 for the n systems of `cs`: public_keys[k] / bitmap[k] hold key k / bit k of every system (the reference passes
     // slices of K variables of one system). Returns (result, effective public key count). The circuit is the one of blsw_layout_aggregate:
-    // keys, bitmap, msg, sig allocated in the order of constraints.rs:378-441, Constant parameters. A key or signature that does not decode
-    // makes its system false (status()), as in verify. Synchronous; direct-mode batch entry blsw_aggregate_verify_batch.
+    // keys, bitmap, msg, sig allocated in the order of constraints.rs:378-441, Constant parameters. A key that FAILS TO DECODE (bad encoding,
+    // not on the curve, not in the subgroup) or a signature that does not decode to a non-identity point makes its system false (status()),
+    // as in verify. The infinity encoding of a KEY decodes (PublicKey::try_from accepts it, and a key whose bitmap bit is 0 never enters
+    // the aggregate, constraints.rs:169-191): such a system returns the gadget's own Boolean. Synchronous; direct-mode batch entry
+    // blsw_aggregate_verify_batch.
     static std::pair<Boolean, UInt32> aggregate_verify(const ParametersVar& parameters, const std::vector<PublicKeyVar>& public_keys, const std::vector<Boolean>& bitmap,
                                                        const MessageVar& message, const SignatureVar& signature) {
         if (!parameters.cs_) throw Error("aggregate_verify: parameters were not allocated in a ConstraintSystem", BLSW_ERR_ARG);
@@ -371,12 +376,15 @@ struct BlsSignatureVerifyGadget {
         UInt32 count;
         count.v_.resize(n);
         d_count.download(count.v_.data(), n * 4);
-        // status(i): the first key of system i that did not decode (or OK), and the signature's
+        // status(i): the first key of system i that failed to decode (else OK: a well-formed identity key is not a failure), and the signature's
         cs.status_.assign(2 * n, BLSW_ST_OK);
         Boolean b;
         b.v_.resize(n);
         for (size_t i = 0; i < n; i++) {
-            for (size_t k = 0; k < K && cs.status_[2 * i] == BLSW_ST_OK; k++) cs.status_[2 * i] = st_keys[2 * (i * K + k)];
+            for (size_t k = 0; k < K && cs.status_[2 * i] == BLSW_ST_OK; k++) {
+                const int32_t st = st_keys[2 * (i * K + k)];
+                if (st != BLSW_ST_IDENTITY) cs.status_[2 * i] = st;
+            }
             cs.status_[2 * i + 1] = st_sig[2 * i + 1];
             b.v_[i] = r[i] == 1 && cs.status_[2 * i] == BLSW_ST_OK && cs.status_[2 * i + 1] == BLSW_ST_OK;
         }

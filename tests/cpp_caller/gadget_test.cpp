@@ -47,6 +47,42 @@ static int aggregate_tests() {
     return 0;
 }
 
+// a well-formed identity key (PublicKey::try_from accepts the infinity encoding) masked out (system 0) and unmasked (system 1): the C++ mirror
+// must return the gadget's own Boolean, not force false; and verify() on a ConstraintSystem that aggregate_verify has synthesised is refused
+static int aggregate_identity_tests() {
+    ConstraintSystem cs(2, 32);
+    const PublicKey pub_key1 = PublicKey::try_from("a491d1b0ecd9bb917989f0e74f0dea0422eac4a873e5e2644f368dffb9a6e20fd6e10c1b77654d067c0618f6e5a7f79a");
+    const PublicKey pub_key2 = PublicKey::try_from("b301803f8b5ac4a1133581fc676dfedc60d891dd5fa99028805e5ea5b08d3491af75d0707adab3b70c6a6a580217bf81");
+    const PublicKey infinity = PublicKey::try_from("c00000000000000000000000000000000000000000000000000000000000000000000000000000000000000000000000");
+    std::vector<PublicKeyVar> pub_keys;
+    pub_keys.push_back(PublicKeyVar::new_variable(cs, {pub_key1, pub_key1}, AllocationMode::Witness));
+    pub_keys.push_back(PublicKeyVar::new_variable(cs, {pub_key2, pub_key2}, AllocationMode::Witness));
+    pub_keys.push_back(PublicKeyVar::new_variable(cs, {infinity, infinity}, AllocationMode::Witness));
+    std::vector<Boolean> bitmap;
+    bitmap.push_back(Boolean::new_witness(cs, {true, true}));
+    bitmap.push_back(Boolean::new_witness(cs, {true, true}));
+    bitmap.push_back(Boolean::new_witness(cs, {false, true}));
+    const std::vector<uint8_t> m = detail::unhex("5656565656565656565656565656565656565656565656565656565656565656", 32);
+    const MessageVar msg = UInt8::new_witness_vec(cs, {m, m});
+    const Signature sig = Signature::try_from(
+        "912c3615f69575407db9392eb21fee18fff797eeb2fbe1816366ca2a08ae574d8824dbfafb4c9eaa1cf61b63c6f9b69911f269b664c42947dd1b53ef1081926c1e82bb2a465f927124b08391a5249"
+        "036146d6f3f1e17ff5f162f779746d830d1");
+    const ParametersVar params = ParametersVar::new_variable(cs, Parameters{}, AllocationMode::Constant);
+    const SignatureVar sig_var = SignatureVar::new_variable(cs, {sig, sig}, AllocationMode::Witness);
+    const auto [result, count] = BlsSignatureVerifyGadget::aggregate_verify(params, pub_keys, bitmap, msg, sig_var);
+    printf("verification_result_0=%d verification_result_1=%d effective_public_key_count_0=%u effective_public_key_count_1=%u status_pk_0=%d status_pk_1=%d num_witness_variables=%llu",
+           (int)result.value()[0], (int)result.value()[1], count.value()[0], count.value()[1], cs.status(0)[0], cs.status(1)[0], (unsigned long long)cs.num_witness_variables());
+    printf(" digest0=%llu digest1=%llu", (unsigned long long)digest(cs.witness_assignment(0)), (unsigned long long)digest(cs.witness_assignment(1)));
+    int refused = 0;
+    try {
+        BlsSignatureVerifyGadget::verify(params, pub_keys[0], msg, sig_var);
+    } catch (const Error&) {
+        refused = 1;
+    }
+    printf(" verify_after_aggregate_refused=%d\n", refused);
+    return refused ? 0 : 3;
+}
+
 static std::string hex(const uint8_t* p, size_t n) {
     static const char* d = "0123456789abcdef";
     std::string s;
@@ -93,6 +129,14 @@ int main(int argc, char** argv) {
     if (argc > 2 && (!strcmp(argv[1], "sign") || !strcmp(argv[1], "verify"))) {
         try {
             return native_tests(argv[1], argv[2]);
+        } catch (const Error& e) {
+            fprintf(stderr, "%s\n", e.what());
+            return 10;
+        }
+    }
+    if (argc > 1 && !strcmp(argv[1], "aggregate-identity")) {
+        try {
+            return aggregate_identity_tests();
         } catch (const Error& e) {
             fprintf(stderr, "%s\n", e.what());
             return 10;

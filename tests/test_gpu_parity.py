@@ -1,6 +1,7 @@
 """GPU parity (run with -m gpu on an MI355X): the HIP path, called through the C ABI, against the CPU oracle on the
 same inputs — bit-exact on every witness element — plus the reference's golden vectors."""
 import importlib
+import importlib.util
 import json
 import os
 
@@ -733,6 +734,89 @@ def test_engine_1024_instances_grouped(pkg, oracle):
     eng.close()
 
 
+def test_engine_bench_shape_against_oracle(pkg, oracle):
+    """The engine shape bench.py times (BASELINE configs[1]): 1024 instances per step, launch groups of up to 10 steps (25 steps are
+    balanced into 9 + 8 + 8), 3 group buffers, a ring of TWO output tensors, free running, 25 steps of DISTINCT batches. What the ring
+    holds afterwards — steps 23 and 24 — against the oracle on every witness element of seven sampled instances per tensor (staging
+    tile edges, pairing-wave edges), and all 25 x 1024 results against the tamper rule."""
+    import torch
+
+    bench_spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(bench_spec)
+    bench_spec.loader.exec_module(bench)
+    n, steps, ring = 1024, 25, 2
+    coalesce = bench.balanced_coalesce(steps, 10)
+    assert coalesce == 9
+    workload = importlib.import_module("bls-verify-gadget_amd.workload")
+    dev = torch.device("cuda:0")
+    eng = pkg.WitnessEngine(n, 32, max_steps=coalesce, device=dev, n_buffers=3)
+    outs = [eng.new_witness_tensor() for _ in range(ring)]
+    for o in outs:
+        o.fill_(-1)
+    ins, ress = [], []
+    for k in range(steps):
+        pk, msg, sig, expect = workload.make_batch(pkg, n, seed=0x5EED, device=dev, start=(7 + k) * n)
+        ins.append((pk, msg, sig, expect))
+        ress.append(torch.empty(n, dtype=torch.int32, device=dev))
+    torch.cuda.synchronize()
+    for k in range(steps):
+        eng.submit(ins[k][0], ins[k][2], ins[k][1], witness=outs[k % ring], result=ress[k])
+    eng.flush()
+    torch.cuda.synchronize()
+    assert eng.launched() == steps and eng.materialised() == steps
+    for k in range(steps):
+        assert np.array_equal(ress[k].cpu().numpy().astype(bool), ins[k][3]), "results of step %d" % k
+    pick = [0, 63, 64, 127, 639, 640, 1023]
+    for k in (steps - 2, steps - 1):
+        pk, msg, sig, _ = ins[k]
+        hp, hm, hs = pk.cpu().numpy().view(np.uint64), msg.cpu().numpy(), sig.cpu().numpy().view(np.uint64)
+        w = outs[k % ring][pick].cpu().numpy().view(np.uint64)
+        for a, i in enumerate(pick):
+            nw, _, r, ow = oracle.witness(hp[i], hm[i].tobytes(), hs[i])
+            assert nw == w.shape[1] and r == bool(ins[k][3][i])
+            bad = np.nonzero((ow != w[a]).any(axis=1))[0]
+            assert len(bad) == 0, "ring tensor %d (step %d) instance %d: first mismatching witness index %d" % (k % ring, k, i, bad[0])
+    eng.close()
+
+
+def test_release_table_full_is_busy_and_nothing_is_queued(pkg):
+    """Consumer mode with more distinct outputs than the release table holds (64): every accepted step reserves its output's slot when it is
+    submitted, so the 65th distinct output is refused with BUSY BEFORE anything is queued or launched (round 3: the group was launched
+    and the step counted, then the call failed) — and goes through once an output has been released."""
+    import torch
+
+    n = 2
+    workload = importlib.import_module("bls-verify-gadget_amd.workload")
+    dev = torch.device("cuda:0")
+    pk, msg, sig, expect = workload.make_batch(pkg, n, seed=0x5EED, device=dev, start=40)
+    eng = pkg.WitnessEngine(n, 32, max_steps=2, device=dev, n_buffers=2, consumer_mode=1)
+    outs = [eng.new_witness_tensor() for _ in range(66)]
+    res = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(66)]
+    for k in range(64):
+        eng.submit(pk, sig, msg, witness=outs[k], result=res[k])
+    assert eng.submitted() == 64 and eng.launched() == 64 and eng.materialised() == 64
+    with pytest.raises(pkg.BlswBusy):
+        eng.submit(pk, sig, msg, witness=outs[64], result=res[64])
+    assert eng.submitted() == 64 and eng.launched() == 64  # nothing taken, nothing launched
+    with pytest.raises(pkg.BlswBusy):
+        eng.output_consumed(outs[65])  # an output the engine has never seen needs a slot too
+    eng.wait_step(0)
+    eng.output_consumed(outs[0])
+    torch.cuda.synchronize()  # the release has completed: its slot is recycled
+    eng.submit(pk, sig, msg, witness=outs[64], result=res[64])
+    eng.output_consumed(outs[1])
+    torch.cuda.synchronize()
+    eng.submit(pk, sig, msg, witness=outs[65], result=res[65])
+    eng.flush()
+    torch.cuda.synchronize()
+    assert eng.submitted() == 66 and eng.materialised() == 66
+    d = [pkg.witness_digest(outs[k]).cpu().numpy() for k in (0, 63, 64, 65)]
+    assert all(np.array_equal(d[0], x) for x in d[1:]) and d[0].any()
+    for k in (0, 63, 64, 65):
+        assert np.array_equal(res[k].cpu().numpy().astype(bool), expect)
+    eng.close()
+
+
 def test_engine_compact_form_round_trip(pkg, oracle):
     """The compact wire form of a step (blsw_engine_submit_compact: bit-packed SHA witnesses + staged field witnesses, what the
     multi-GPU all-gather ships) expanded on the 'receiver' (blsw_engine_expand_compact, here a SECOND engine) gives bit for bit
@@ -780,11 +864,13 @@ def test_engine_compact_form_round_trip(pkg, oracle):
     recv.close()
 
 
-def test_engine_consumer_mode_small_ring(pkg, oracle):
+@pytest.mark.parametrize("ramp", [0, 1])
+def test_engine_consumer_mode_small_ring(pkg, oracle, ramp):
     """options.consumer_mode = 1: ten steps of 64 instances in groups of four through a ring of TWO output tensors (fewer than
     one group): a step is written into its tensor only after the consumer released the previous user of that tensor, so every
     step's digests must equal those of a free-running engine that had ten separate tensors. The consumer is the digest
-    kernel on its own stream; submit returning BUSY is answered by draining."""
+    kernel on its own stream; submit returning BUSY is answered by draining. ramp = 1: options.group_ramp — the first groups are
+    2 and 4 steps (the group of 2 is launched by the second submit), same bytes."""
     import torch
 
     n, steps, ring = 64, 10, 2
@@ -804,12 +890,13 @@ def test_engine_consumer_mode_small_ring(pkg, oracle):
     del ref_out
     torch.cuda.empty_cache()
     # consumer mode, ring of two
-    eng = pkg.WitnessEngine(n, 32, max_steps=4, device=dev, n_buffers=2, consumer_mode=1)
+    eng = pkg.WitnessEngine(n, 32, max_steps=4, device=dev, n_buffers=2, consumer_mode=1, group_ramp=ramp)
     outs = [eng.new_witness_tensor() for _ in range(ring)]
     res = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(steps)]
     got = [torch.empty((n, 2), dtype=torch.int64, device=dev) for _ in range(steps)]
     consumer = torch.cuda.Stream(device=dev)
     state = {"next": 0, "busy": 0}
+    launched_after = []
 
     def drain():
         while state["next"] < eng.materialised():
@@ -829,6 +916,7 @@ def test_engine_consumer_mode_small_ring(pkg, oracle):
                 before = state["next"]
                 drain()
                 assert state["next"] > before, "BUSY with nothing to drain"
+        launched_after.append(eng.launched())
         drain()
     eng.flush()
     while state["next"] < steps:
@@ -836,6 +924,7 @@ def test_engine_consumer_mode_small_ring(pkg, oracle):
         drain()
         assert state["next"] > before
     assert eng.materialised() == steps
+    assert launched_after == ([0, 2, 2, 2, 2, 6, 6, 6, 6, 10] if ramp else [0, 0, 0, 4, 4, 4, 4, 8, 8, 8])
     with pytest.raises(pkg.BlswError):
         eng.wait_step(steps)  # not submitted
     consumer.synchronize()
@@ -1201,6 +1290,16 @@ def test_cpp_host_mirror_reference_gadget_test(pkg, oracle):
         n, res, c, _, ow = oracle.witness_aggregate(keys, bits, bytes([0x56]) * 32, s)
         assert int(kv["num_witness_variables"]) == n and res == (i == 0) and c == (2, 512)[i]
         assert int(kv["digest%d" % i]) == digest(ow), "aggregate system %d" % i
+    # a well-formed identity key, masked out (system 0) and unmasked (system 1): the gadget's Boolean, not a forced false; verify() afterwards is refused
+    out = subprocess.check_output([os.path.join(root, "tests", "cpp_caller", "gadget_test"), "aggregate-identity"], text=True, timeout=600)
+    kv = dict(p.split("=") for p in out.split())
+    keys3 = np.stack([p1, p2, np.zeros(12, dtype=np.uint64)])
+    for i, bits in enumerate((np.array([1, 1, 0], dtype=np.uint8), np.array([1, 1, 1], dtype=np.uint8))):
+        n, res, c, _, ow = oracle.witness_aggregate(keys3, bits, bytes([0x56]) * 32, s)
+        assert int(kv["num_witness_variables"]) == n and kv["verification_result_%d" % i] == str(int(res)) and int(kv["effective_public_key_count_%d" % i]) == c
+        assert int(kv["digest%d" % i]) == digest(ow), "aggregate system %d with an identity key" % i
+        assert kv["status_pk_%d" % i] == "0"
+    assert kv["verification_result_0"] == "1" and kv["verify_after_aggregate_refused"] == "1"
 
 
 def test_c_caller_submit_bytes_fixtures(pkg, tmp_path):

@@ -50,3 +50,22 @@ def test_two_ranks_on_one_gpu_rehearsal():
     assert p.returncode == 0 and lines, p.stderr[-2000:]
     out = json.loads(lines[-1])
     assert out["world_size"] == 2 and out["backend"] == "gloo" and out["all_ranks_ok"] and out["mismatches_rank0"] == []
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_gloo_child():
+    """`python bench.py --gpus 2 --steps 4` as the driver would start it for N = 2 (bench.py spawns its own child torch.distributed.run),
+    with BLSW_TEST_BACKEND=gloo so that both ranks may share the one GPU of the builder's box: the line must carry the world size, the
+    backend, per-rank rates, generation-only next to the all-gather leg, and right witnesses. Not a measurement."""
+    env = dict(os.environ, BLSW_TEST_BACKEND="gloo")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--batch", "128", "--allgather-steps", "4",
+                        "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert p.returncode == 0 and lines, p.stderr[-2000:]
+    out = json.loads(lines[-1])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["witness_ok"] and out["config"]["results_ok"] and out["config"]["result_shards_gathered"]
+    assert out["per_rank"]["backend"] == "gloo" and len(out["per_rank"]["seconds"]) == 2
+    assert out["per_rank"]["instances_per_s_min"] <= out["per_rank"]["instances_per_s_max"]
+    assert out["value_generation_only"] == out["value"] and out["value"] >= 2 * out["per_rank"]["instances_per_s_min"] * 0.999
+    ag = out["allgather"]
+    assert ag["backend"] == "gloo" and ag["world"] == 2 and ag["ranks"] == 2 and "error" not in ag and out["value_with_allgather"] > 0
