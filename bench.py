@@ -184,7 +184,11 @@ def allgather_leg(args, pkg, sharding, dist, dev, inputs, lay, world):
     gathered = torch.empty((world * chunk, lay["n_witness"], 6), dtype=torch.int64, device=dev)
     dig = torch.empty((world * chunk, 2), dtype=torch.int64, device=dev)
     acc = torch.zeros(2, dtype=torch.int64, device=dev)
-    consumer = torch.cuda.Stream(device=dev)
+    # the consumer's stream in the HIGH-priority pool of hardware queues (with the engine's sha / expand / place streams): the runtime backs each
+    # priority level with four hardware queues, and a fifth normal-priority stream (null stream + three group buffers' main streams + this one) shares
+    # a queue with the null stream — every submit's input-ready marker then queues behind the consumer's waiting digests and the next launch group
+    # starts ~70 ms late (profiles/r04_consumer_timeline.txt)
+    consumer = torch.cuda.Stream(device=dev, priority=-1)
     state = {"next": 0}
 
     def drain():
@@ -250,7 +254,11 @@ def allgather_leg_compact(args, pkg, sharding, dist, dev, inputs, lay, world):
     wit = eng.new_witness_tensor()
     dig = torch.empty((n, 2), dtype=torch.int64, device=dev)
     acc = torch.zeros(2, dtype=torch.int64, device=dev)
-    consumer = torch.cuda.Stream(device=dev)
+    # the consumer's stream in the HIGH-priority pool of hardware queues (with the engine's sha / expand / place streams): the runtime backs each
+    # priority level with four hardware queues, and a fifth normal-priority stream (null stream + three group buffers' main streams + this one) shares
+    # a queue with the null stream — every submit's input-ready marker then queues behind the consumer's waiting digests and the next launch group
+    # starts ~70 ms late (profiles/r04_consumer_timeline.txt)
+    consumer = torch.cuda.Stream(device=dev, priority=-1)
     comm = torch.cuda.Stream(device=dev)
     d_pk, d_msg, d_sig = inputs
     state = {"next": 0}

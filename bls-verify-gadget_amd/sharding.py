@@ -189,7 +189,11 @@ def stream_shard(pkg, n_shard=8192, batch=1024, ring=2, rank=0, world=8, buffers
     outs = [eng.new_witness_tensor() for _ in range(ring)]
     digests = torch.zeros((steps, batch, 2), dtype=torch.int64, device=dev)
     results = torch.zeros((steps, batch), dtype=torch.int32, device=dev)
-    consumer = torch.cuda.Stream(device=dev)
+    # the consumer's stream in the HIGH-priority pool of hardware queues (with the engine's sha / expand / place streams): the runtime backs each
+    # priority level with four hardware queues, and a fifth normal-priority stream (null stream + three group buffers' main streams + this one) shares
+    # a queue with the null stream — every submit's input-ready marker then queues behind the consumer's waiting digests and the next launch group
+    # starts ~70 ms late (profiles/r04_consumer_timeline.txt)
+    consumer = torch.cuda.Stream(device=dev, priority=-1)
     inputs, expects = [], []
     for k in range(steps):  # inputs are resident before the timed region (minted by the product's signer)
         pk, msg, sig, expect = workload.make_batch(pkg, batch, seed=seed, device=dev, start=lo + k * batch)

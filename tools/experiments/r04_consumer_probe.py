@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Round 4 probe: the consumer-mode shard legs of bench.py (sharding.stream_shard) repeated in one process — run-to-run spread, the
+group ramp on / off, group sizes. One line per run."""
+import importlib
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+
+    pkg = importlib.import_module("bls-verify-gadget_amd")
+    sharding = importlib.import_module("bls-verify-gadget_amd.sharding")
+    dev = torch.device("cuda:0")
+    n = 1024
+    sharding.stream_shard(pkg, 2 * n, n, 2, 0, 1, device=dev)
+    torch.cuda.empty_cache()
+    plans = [(8192, None, True), (8192, None, False), (8192, None, True), (8192, None, False), (8192, 6, True), (8192, 8, True), (8192, 2, False),
+             (32768, None, True), (32768, None, False), (32768, None, True), (32768, 8, True), (32768, 10, True)]
+    if len(sys.argv) > 1:
+        plans = [tuple(json.loads(a)) for a in sys.argv[1:]]
+    for shard, group, ramp in plans:
+        cs = sharding.stream_shard(pkg, shard, n, 2, 0, 1, device=dev, group=group, ramp=ramp)
+        print(json.dumps({"shard": shard, "group": cs["group_steps"], "ramp": cs["group_ramp"], "instances_per_s": round(cs["instances_per_s"]), "seconds": round(cs["seconds"], 4),
+                          "results_ok": cs["results_ok"]}), flush=True)
+        del cs
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
