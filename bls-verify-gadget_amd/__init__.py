@@ -158,6 +158,19 @@ def _require_cuda():
     return torch
 
 
+def check_capacity(device, what, *byte_counts):
+    """Refuses (BlswError) before anything is allocated when the buffers a direct call needs — its workspace and, with want_witness, n witness
+    vectors (a 128-pair instance is 4.19 GB) — exceed the free HBM of `device`: a clear error instead of an allocator exception half-way."""
+    torch = _require_cuda()
+    need = int(sum(byte_counts))
+    free_b, _ = torch.cuda.mem_get_info(device)
+    # memory torch has cached but not in use is reusable by the allocations that follow
+    reusable = torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
+    if need > free_b + reusable:
+        raise BlswError("%s needs %.2f GB of HBM (workspace + witness vectors) and %.2f GB are free on %s: pass fewer instances per call, "
+                        "want_witness=False, or stream the batch through a WitnessEngine with a small ring of outputs" % (what, need / 1e9, (free_b + reusable) / 1e9, device))
+
+
 def engine_options(**overrides):
     """blsw_engine_options_default with keyword overrides: device, pairing_mode ("team"/"lane" or 0/1), g2_mode ("lane"/"team"
     or 0/1), expand_variant, expand_store, prio_mode, place_lds, consumer_mode, output_form, n_keys. The library itself reads no
@@ -458,6 +471,11 @@ class BlsSignatureVerifyGadget:
 
     def __init__(self, n, msg_len=32, device=None, want_witness=True, max_steps=1, **options):
         """options: blsw_engine_options_t fields; params_mode="witness" builds the circuit for ParametersVar.new_witness()."""
+        if want_witness and not options.get("n_keys") and not options.get("n_pairs"):
+            torch = _require_cuda()
+            dev = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+            check_capacity(dev, "BlsSignatureVerifyGadget (n = %d)" % n, engine_workspace_bytes(n, msg_len, max_steps, 3 if max_steps > 1 else 1),
+                           n * layout(msg_len, PARAMS_MODES.get(options.get("params_mode"), options.get("params_mode") or 0))["n_witness"] * 48)
         self.engine = WitnessEngine(n, msg_len, max_steps=max_steps, device=device, **options)
         torch = self.engine.torch
         self.torch = torch
@@ -565,6 +583,7 @@ def aggregate_verify(parameters, public_keys, bitmap, message, signature, want_w
     wb = ctypes.c_uint64(0)
     lib().blsw_aggregate_workspace_bytes(n, msg_len, K, ctypes.byref(wb))
     dev = pks.device
+    check_capacity(dev, "aggregate_verify (n = %d, %d keys)" % (n, K), wb.value, n * lay["n_witness"] * 48 if want_witness else 0)
     ws = torch.empty(wb.value, dtype=torch.uint8, device=dev)
     res = torch.empty(n, dtype=torch.int32, device=dev)
     cnt = torch.empty(n, dtype=torch.int32, device=dev)
@@ -639,6 +658,7 @@ def verify_multi(parameters, public_keys, messages, signature, want_witness=True
     if rc:
         raise BlswError("blsw_verify_multi_workspace_bytes failed: %d" % rc)
     dev = pks.device
+    check_capacity(dev, "verify_multi (n = %d, %d pairs)" % (n, K), wb.value, n * lay["n_witness"] * 48 if want_witness else 0)
     ws = torch.empty(wb.value, dtype=torch.uint8, device=dev)
     res = torch.empty(n, dtype=torch.int32, device=dev)
     wit = torch.empty((n, lay["n_witness"], 6), dtype=torch.int64, device=dev) if want_witness else None

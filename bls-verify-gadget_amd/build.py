@@ -12,16 +12,24 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libblsw.so")
 OBJ = os.path.join(HERE, "build_obj")
-SOURCES = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+# the shipped translation units, listed: a stray or experimental .hip file in csrc/ is an error, not silently linked
+SOURCES = ["engine.hip", "k_bench.hip", "k_cofactor.hip", "k_g1.hip", "k_g2.hip", "k_map.hip", "k_miller_par.hip", "k_pairing_lane.hip", "k_prepare.hip", "k_sha.hip",
+           "k_sign.hip", "k_stream.hip", "k_team.hip", "k_values.hip"]
 HOST_SOURCES = ["r1cs.cpp"]  # host-only C++: compiled by g++, linked into the same library
-HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith((".cuh", ".h")))
-# the one-instance-per-lane chain units are compiled a second time with their programs inlined (kernels *_inl: kcommon.cuh)
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith((".hpp", ".h")))
+# the one-instance-per-lane chain units are compiled a second time with their programs inlined (kernels *_inl: kcommon.hpp)
 DUAL = ["k_sha.hip", "k_g1.hip", "k_g2.hip", "k_map.hip", "k_cofactor.hip", "k_prepare.hip"]
 HIP_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas"]
 
 
 def needs_build():
     if not os.path.exists(OUT):
+        return True
+    try:  # built by other compilers / flags than the present ones: rebuild (the tag is written next to the library)
+        if open(OUT + ".tag").read().strip() != build_tag():
+            return True
+    except OSError:
         return True
     t = os.path.getmtime(OUT)
     deps = [os.path.join(CSRC, f) for f in SOURCES + HOST_SOURCES + HEADERS] + [os.path.join(HERE, "..", "include", "blsw.h")]
@@ -39,15 +47,39 @@ def _compile(job):
     return p.stdout
 
 
-def build(force=False, verbose=False, out=None, defines=(), only=None):
+_TOOL_VERSION = {}
+
+
+def _tool_version(tool):
+    if tool not in _TOOL_VERSION:
+        try:
+            _TOOL_VERSION[tool] = subprocess.run([tool, "--version"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True).stdout
+        except OSError:
+            _TOOL_VERSION[tool] = "missing"
+    return _TOOL_VERSION[tool]
+
+
+def build_tag(defines=()):
+    """Key of the object cache: everything that shapes an object besides its source and headers — the compilers (path and --version: the
+    ROCm release), the flags, the defines and the list of doubly compiled units. "std" names the shipped configuration's logs
+    (resource_table); the objects carry the hash."""
+    hipcc, cxx = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), os.environ.get("CXX", "g++")
+    key = "\n".join([hipcc, _tool_version(hipcc), cxx, _tool_version(cxx), " ".join(HIP_FLAGS), " ".join(HOST_FLAGS), " ".join(defines), " ".join(DUAL)])
+    return hashlib.sha1(key.encode()).hexdigest()[:8]
+
+
+def build(force=False, verbose=False, out=None, defines=()):
     """out / defines: an alternative build next to the shipped one (A/B runs: BLSW_LIB=<out> selects it at import).
-    Objects are cached per (source, flags): a unit is recompiled when it, a header or its flags changed."""
+    Objects are cached per (source, build_tag): a unit is recompiled when it, a header, a compiler or a flag changed."""
+    stray = sorted(set(f for f in os.listdir(CSRC) if f.endswith(".hip")) - set(SOURCES))
+    if stray or any(not os.path.exists(os.path.join(CSRC, f)) for f in SOURCES + HOST_SOURCES):
+        raise RuntimeError("csrc/ does not hold exactly the listed translation units (unlisted: %s)" % ", ".join(stray))
     if out is None and not force and not needs_build():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     out = os.path.abspath(out) if out else None
     os.makedirs(OBJ, exist_ok=True)
-    tag = hashlib.sha1(" ".join(defines).encode()).hexdigest()[:8] if defines else "std"
+    tag = build_tag(defines)
     hdr_time = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
     hdr_time = max(hdr_time, os.path.getmtime(os.path.join(HERE, "..", "include", "blsw.h")))
     jobs, objs = [], []
@@ -59,7 +91,7 @@ def build(force=False, verbose=False, out=None, defines=(), only=None):
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), hdr_time):
             continue
         if src.endswith(".cpp"):
-            cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas", "-c", path, "-o", obj]
+            cmd = [os.environ.get("CXX", "g++")] + HOST_FLAGS + ["-c", path, "-o", obj]
             jobs.append((cmd, None))
         else:
             cmd = [hipcc] + HIP_FLAGS + list(defines) + list(extra) + ["-c", path, "-o", obj, "-Rpass-analysis=kernel-resource-usage"]
@@ -69,14 +101,16 @@ def build(force=False, verbose=False, out=None, defines=(), only=None):
     with concurrent.futures.ThreadPoolExecutor(max_workers=max(1, min(8, os.cpu_count() or 1))) as ex:
         list(ex.map(_compile, jobs))
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out or OUT] + objs, cwd=CSRC)
+    open((out or OUT) + ".tag", "w").write(tag + "\n")
     return out or OUT
 
 
-def resource_table(tag="std"):
+def resource_table(tag=None):
     """kernel -> registers / scratch / occupancy, from the compile logs (-Rpass-analysis=kernel-resource-usage)"""
     import re
 
     rows = []
+    tag = tag or build_tag()
     for f in sorted(os.listdir(OBJ)):
         if not f.endswith(".%s.o.log" % tag):
             continue
@@ -99,8 +133,7 @@ if __name__ == "__main__":
     defs = [a for a in sys.argv[1:] if a.startswith("-D")]
     build(force="--force" in sys.argv, verbose=True, out=out, defines=defs)
     if "--table" in sys.argv:
-        tag = hashlib.sha1(" ".join(defs).encode()).hexdigest()[:8] if defs else "std"
-        for r in resource_table(tag):
+        for r in resource_table(build_tag(defs)):
             name = r["name"]
             if "k_sha_expand" in name and "ILi384ELi8ELi16ELi0" not in name:
                 continue

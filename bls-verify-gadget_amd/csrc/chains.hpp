@@ -8,8 +8,8 @@
 //   chain_pairing       constraints.rs:121-127 (miller_loop, final_exponentiation, is_one)
 // Segment sizes are fixed by the circuit shape (layout.h); tests pin them against the CPU oracle.
 #pragma once
-#include "curve.cuh"
-#include "tower.cuh"
+#include "curve.hpp"
+#include "tower.hpp"
 
 namespace blsw {
 

@@ -3,7 +3,7 @@
 // scalar_mul_le walks the 636 bits of h_eff in chunks of 255: within a chunk an affine double-and-add loop over all
 // but the last two bits, then a handful of projective additions that fold the chunk into the running result and the chunk's last two
 // doublings. The loop of chunk c starts from mopt_c = 2^(255 c) * P and is otherwise independent of the other chunks; only the folding
-// additions chain the chunks together. As ONE chain (chains.cuh: chain_cofactor, the statement of the segment) that is 636 dependent
+// additions chain the chunks together. As ONE chain (chains.hpp: chain_cofactor, the statement of the segment) that is 636 dependent
 // affine steps with an inversion each — 53 ms alone, the longest kernel of every launch group. Here:
 //   phase A (lane per chunk)   chunk 0 emits Q0 + Q1 and the to_affine of the sum; chunks 1, 2 compute their start point as a VALUE
 //                              (the same sum and affine point without a cursor, then 255 c Jacobian doublings and one inversion:
@@ -14,8 +14,8 @@
 // over the bits of h_eff (cofactor_plan), checked against the segment length.
 // Compiles for the host as well: tests/hostsim runs the phases in any order against the oracle.
 #pragma once
-#include "chains.cuh"
-#include "vcurve.cuh"
+#include "chains.hpp"
+#include "vcurve.hpp"
 
 namespace blsw {
 
@@ -82,7 +82,7 @@ BLSW_HD Aff2 cof_ld_aff(const LD& s, uint32_t row) {
 
 // phase A, chunk c of one instance. e_add: cursor of the "add" segment, e: cursor at the start of the cofactor segment.
 template <class ST>
-BLSW_FN void chain_cofactor_chunk(Emitter e_add, Emitter e, const Proj<OpsFp2>& q0, const Proj<OpsFp2>& q1, int c, const ST& store, bool head_only = false) {
+BLSW_FN void chain_cofactor_chunk(Emitter e_add, Emitter e, const Proj<OpsFp2>& q0, const Proj<OpsFp2>& q1, int c, const ST& store) {
     constexpr CofactorPlan plan = cofactor_plan();
     constexpr uint32_t HE[20] = BLSW_H_EFF_WORDS;
     Emitter ev_add = e_add, ev = e;  // cursors of the sum and its affine form: real for chunk 0 (they are its witnesses), dummies otherwise
@@ -115,7 +115,6 @@ BLSW_FN void chain_cofactor_chunk(Emitter e_add, Emitter e, const Proj<OpsFp2>& 
     const int split = n < 253 ? n : 253;
     Aff2 acc = mopt;
     cof_st_aff(store, 12 * c + 4, mopt);  // init
-    if (head_only) return;  // the loop runs in a kernel of its own (BLSW_COFACTOR_LDS experiment)
     mopt = nz_double_w(w, mopt);
 #pragma unroll 1
     for (int i = 1; i < split; i++) {
@@ -183,82 +182,5 @@ BLSW_FN Proj<OpsFp2> chain_cofactor_join(Emitter e, const LD& load) {
         h.z = fp2_select_w(e, infinity, fp2_zero(), mul_result.z);
     return h;
 }
-
-#if defined(__HIPCC__) && defined(BLSW_COFACTOR_LDS)
-// EXPERIMENT (-DBLSW_COFACTOR_LDS, profiles/r03_ab_chain_builds.txt section 11): the loop of a chunk as its own kernel at two waves per SIMD with
-// hand-placed LDS temporaries. The accumulator lives in LDS (loaded only by the addition steps), the x coordinate of the doubling point is parked
-// there across the Fp inversion: what stays in registers across that call is the product being inverted, one coordinate and the cursor.
-// Column layout: element (slot, piece) of this lane at col[(3 slot + piece) * 64]; 6 slots = 18 KB per wave, 8 waves per CU = 144 KB of 160.
-typedef __attribute__((address_space(3))) blsw_u32x4 cof_lds_u32x4;
-__device__ __forceinline__ void cof_park(cof_lds_u32x4* col, int slot, const Fp& v) {
-    col[(3 * slot + 0) * 64] = blsw_u32x4{v.l[0], v.l[1], v.l[2], v.l[3]};
-    col[(3 * slot + 1) * 64] = blsw_u32x4{v.l[4], v.l[5], v.l[6], v.l[7]};
-    col[(3 * slot + 2) * 64] = blsw_u32x4{v.l[8], v.l[9], v.l[10], v.l[11]};
-}
-__device__ __forceinline__ Fp cof_unpark(const cof_lds_u32x4* col, int slot) {
-    const blsw_u32x4 a = col[(3 * slot + 0) * 64], b = col[(3 * slot + 1) * 64], c = col[(3 * slot + 2) * 64];
-    Fp r;
-    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
-    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
-    r.l[8] = c.x; r.l[9] = c.y; r.l[10] = c.z; r.l[11] = c.w;
-    return r;
-}
-__device__ __forceinline__ void cof_park_aff(cof_lds_u32x4* col, const Aff2& a) {
-    cof_park(col, 0, a.x.c0);
-    cof_park(col, 1, a.x.c1);
-    cof_park(col, 2, a.y.c0);
-    cof_park(col, 3, a.y.c1);
-}
-__device__ __forceinline__ Aff2 cof_unpark_aff(const cof_lds_u32x4* col) {
-    return {{cof_unpark(col, 0), cof_unpark(col, 1)}, {cof_unpark(col, 2), cof_unpark(col, 3)}};
-}
-// the loop of chunk c (the part of chain_cofactor_chunk after `init` is stored): reads init from the rows, leaves acc and mopt there
-template <class ROWS>
-__device__ __forceinline__ void chain_cofactor_chunk_loop_lds(Emitter e, int c, const ROWS& rows, cof_lds_u32x4* col) {
-    constexpr CofactorPlan plan = cofactor_plan();
-    constexpr uint32_t HE[20] = BLSW_H_EFF_WORDS;
-    Emitter w = e;
-    w.pos = e.pos + plan.start[c];
-    const int off = 255 * c;
-    const int n = BLSW_H_EFF_NBITS - off < 255 ? BLSW_H_EFF_NBITS - off : 255;
-    const int split = n < 253 ? n : 253;
-    Aff2 mopt = cof_ld_aff(rows, 12 * c + 4);
-    cof_park_aff(col, mopt);  // acc = init
-    mopt = nz_double_w(w, mopt);
-#pragma unroll 1
-    for (int i = 1; i < split; i++) {
-        const bool add = bit_of(HE, off + i);
-        Fp2 inv_dbl;
-        if (add) {
-            Fp2 inv_add;
-            Aff2 acc = cof_unpark_aff(col);
-            Fp2 a = fp2_sub(mopt.x, acc.x), b = fp2_dbl(mopt.y);
-            if (fp2_is_zero(a) || fp2_is_zero(b)) {
-                fp2_inv2_inl(a, b, inv_add, inv_dbl);
-            } else {
-                const Fp2 p = fp2_mul_inl(a, b);
-                const Fp nn = fp_add(fp_sqr(p.c0), fp_sqr(p.c1));
-                cof_park(col, 4, mopt.x.c0);
-                cof_park(col, 5, mopt.x.c1);
-                const Fp ni = fp_inv(nn);  // across this call: p, mopt.y, the cursor
-                mopt.x = {cof_unpark(col, 4), cof_unpark(col, 5)};
-                acc = cof_unpark_aff(col);
-                const Fp2 pi = {fp_mul(p.c0, ni), fp_neg(fp_mul(p.c1, ni))};
-                a = fp2_sub(mopt.x, acc.x);
-                b = fp2_dbl(mopt.y);
-                inv_add = fp2_mul_inl(b, pi);
-                inv_dbl = fp2_mul_inl(a, pi);
-            }
-            acc = nz_add_unchecked_pre_inl(w, acc, mopt, inv_add);
-            cof_park_aff(col, acc);
-        } else {
-            inv_dbl = fp2_inv_inl(fp2_dbl(mopt.y));
-        }
-        mopt = nz_double_pre_inl(w, mopt, inv_dbl);
-    }
-    cof_st_aff(rows, 12 * c, cof_unpark_aff(col));
-    cof_st_aff(rows, 12 * c + 8, mopt);
-}
-#endif
 
 }  // namespace blsw

@@ -6,8 +6,8 @@
 //  * NonZeroAffineVar incomplete affine double/add (non_zero_affine.rs) used by scalar_mul_le.
 //  * value-only Jacobian arithmetic for the native `mul_by_cofactor_inv` that precedes G1 allocation.
 #pragma once
-#include "constants.cuh"
-#include "gadgets.cuh"
+#include "constants.hpp"
+#include "gadgets.hpp"
 
 namespace blsw {
 

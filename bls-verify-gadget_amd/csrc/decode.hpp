@@ -3,7 +3,7 @@
 // 316-339) -> affine Montgomery coordinates + a status code. Checks: flags, x < p, on curve, prime-order subgroup.
 // Pinned by tests/test_cases/deserialization_G1/*.json (10) and deserialization_G2/*.json (12).
 #pragma once
-#include "constants.cuh"
+#include "constants.hpp"
 
 namespace blsw {
 

@@ -1,7 +1,7 @@
 // libblsw.so — the execution engine and the C ABI of include/blsw.h (host code; the kernels are in k_*.hip).
 #include <deque>
 #include <map>
-#include "kcommon.cuh"
+#include "kcommon.hpp"
 
 using namespace blsw;
 
@@ -73,9 +73,9 @@ struct GroupBuf {
     void* base = nullptr;
     StepDesc* h_desc = nullptr;  // pinned host
     StepDesc* d_desc = nullptr;
-    hipStream_t st[3] = {nullptr, nullptr, nullptr};  // main, aux, aux2 (only in -DBLSW_AUX2 builds: prepare(sig) and the G1 / key chains beside the G2
-                                                      // allocation — measured slower, profiles/r03_ab_chain_builds.txt section 7)
-    hipEvent_t ev_start = nullptr, ev_aux = nullptr, ev_aux2 = nullptr, ev_sha = nullptr, ev_chains = nullptr, ev_done = nullptr;
+    hipStream_t st[2] = {nullptr, nullptr};  // main, aux (a second aux stream for prepare(sig) / the key chains beside the G2 allocation measured slower:
+                                             // profiles/r03_ab_chain_builds.txt section 7)
+    hipEvent_t ev_start = nullptr, ev_aux = nullptr, ev_sha = nullptr, ev_chains = nullptr, ev_done = nullptr;
     hipEvent_t* ev_in = nullptr;    // [max_steps] inputs of step s valid (recorded on the submitting stream)
     hipEvent_t* ev_x = nullptr;     // [max_steps] expansion of step s issued and finished
     hipEvent_t* ev_step = nullptr;  // [max_steps] step s complete (witness tensor + results)
@@ -114,7 +114,7 @@ struct blsw_engine {
     uint32_t refs[BLSW_MAX_CONSUMED];       // consumer mode: accepted steps that will be materialised into this output (slot reserved at submit)
     uint32_t ramp_pos = 0;                  // options.group_ramp: launch groups since creation / the last flush (group sizes 2, 4, 8, ... max_steps)
     bool staged = false;  // false: direct mode (max_steps == 1, no staging; witnesses written in place by the chains)
-    bool chains_inlined = false;  // which compilation of the chain kernels (options.chain_variant; kcommon.cuh: BLSW_K)
+    bool chains_inlined = false;  // which compilation of the chain kernels (options.chain_variant; kcommon.hpp: BLSW_K)
     uint32_t cofactor_mode = 0;  // clear_cofactor2 with its three chunks on three lanes: 0 by group size, 1 never, 2 always (options.cofactor_mode)
 };
 
@@ -124,9 +124,9 @@ static void engine_free(blsw_engine* e) {
         GroupBuf& b = e->buf[k];
         if (b.h_desc) hipHostFree(b.h_desc);
         if (b.d_desc) hipFree(b.d_desc);
-        for (int i = 0; i < 3; i++)
+        for (int i = 0; i < 2; i++)
             if (b.st[i]) hipStreamDestroy(b.st[i]);
-        hipEvent_t single[] = {b.ev_start, b.ev_aux, b.ev_aux2, b.ev_sha, b.ev_chains, b.ev_done};
+        hipEvent_t single[] = {b.ev_start, b.ev_aux, b.ev_sha, b.ev_chains, b.ev_done};
         for (hipEvent_t ev : single)
             if (ev) hipEventDestroy(ev);
         hipEvent_t* arrays[] = {b.ev_in, b.ev_x, b.ev_step};
@@ -194,12 +194,6 @@ static void launch_canonical(blsw_engine* e, hipStream_t st, uint64_t* out, uint
     hipLaunchKernelGGL(k_canonical_rows, dim3((rows + 255) / 256, (unsigned)e->n), dim3(256), 0, st, out, out_stride, e->L.off_expand, e->L.sha_bits, rows, K, e->L.stride_hash);
 }
 
-#ifdef BLSW_DEBUG_KNOBS  // timing experiments only (wrong witnesses): BLSW_DEBUG_SKIP bit 0 chains, bit 1 placement, bit 2 expansion
-static const uint32_t dbg_skip = getenv("BLSW_DEBUG_SKIP") ? (uint32_t)atoi(getenv("BLSW_DEBUG_SKIP")) : 0u;
-#else
-constexpr uint32_t dbg_skip = 0;
-#endif
-
 static int consumed_slot(blsw_engine* e, const void* ptr) {
     for (int c = 0; c < BLSW_MAX_CONSUMED; c++)
         if (e->consumed_ptr[c] == ptr && (e->consumed_live[c] || e->held[c] || e->refs[c])) return c;
@@ -248,7 +242,7 @@ static void materialise(blsw_engine* e, int k, uint32_t s) {
         if (timed) hipEventRecord(e->ev_exp[2 * e->n_timed], e->expand);
         const uint32_t K = e->L.n_pairs;  // 1 except for the N+1-pair product: one SHA segment per (instance, pair)
         ExpandArgs xa = {ws.bits, ws.sha_words, (uint64_t)s * e->n * K, e->L.sha_bits, e->L.off_expand, d.out, d.out_stride, K, K > 1 ? e->L.stride_hash : 0u, 0, (int)e->opt.output_form};
-        if (!(dbg_skip & 4)) launch_expand(e->opt.expand_variant, e->opt.expand_store, e->opt.place_lds, e->expand, xa, (unsigned)(e->n * K));
+        launch_expand(e->opt.expand_variant, e->opt.expand_store, e->opt.place_lds, e->expand, xa, (unsigned)(e->n * K));
         if (timed) {
             hipEventRecord(e->ev_exp[2 * e->n_timed + 1], e->expand);
             e->n_timed++;
@@ -270,7 +264,7 @@ static void materialise(blsw_engine* e, int k, uint32_t s) {
         }
         if (cf.pair_bytes) hipMemcpyAsync(dst + cf.off_pair, ws.pair + (uint64_t)s * e->n * ws.pair_rows, cf.pair_bytes, hipMemcpyDeviceToDevice, e->place);
     }
-    if (d.out && e->staged && !(dbg_skip & 2)) {
+    if (d.out && e->staged) {
         if (e->L.n_pairs > 1)
             launch_place_multi(e, e->place, ws, ws.staging, (uint64_t)s * e->n * e->L.n_pairs, ws.staging_inst, (uint64_t)s * e->n, 64u,
                                ws.pair + (uint64_t)s * e->n * ws.pair_rows, d.out, d.out_stride);
@@ -377,37 +371,30 @@ static int launch_group(blsw_engine* e) {
             ma.ffinal = take(gs.N);
             launch_miller_par(gs, ma, st, nullptr, nullptr, nullptr);  // one stream: other groups run beside this one
         }
-    } else
-    // main, first part: the hash-to-G2 critical path
-    if (!(dbg_skip & 1)) {
-    hipLaunchKernelGGL(k_sha_values, dim3(g1), dim3(64), 0, st, g);
-    hipLaunchKernelGGL(ck.map, dim3(g2), dim3(64), 0, st, g);
-    launch_cofactor(ck, e->cofactor_mode == 2 || (e->cofactor_mode == 0 && g.N <= BLSW_COFACTOR_CHUNKED_MAX_LANES), g, st);
-    hipLaunchKernelGGL(ck.prepare, dim3(g1), dim3(64), 0, st, g, 0);
-    // aux: prepare_g2(sig) and the group allocations (53 ms alone beside the 86 ms of the main stream's first part); with a second aux
-    // stream the G2 allocation (the longest of them) runs beside the other two
-    hipStream_t sb = b.st[2] ? b.st[2] : b.st[1];
-    if (b.st[2]) hipStreamWaitEvent(sb, b.ev_start, 0);
-    hipLaunchKernelGGL(ck.prepare, dim3(g1), dim3(64), 0, sb, g, 1);
-    if (e->L.n_keys) {  // aggregate_verify: one lane per (instance, key) allocates, then mapped_aggregate + pk != 0 + prepare_g1 per instance
-        hipLaunchKernelGGL(ck.agg_keys, dim3((unsigned)((g.N * e->L.n_keys + 63) / 64)), dim3(64), 0, sb, g, g.ws.keyproj);
-        hipLaunchKernelGGL(ck.agg_sum, dim3(g1), dim3(64), 0, sb, g, (const Fp*)g.ws.keyproj);
-    } else  // params_mode: lanes [N, 2 N) allocate and prepare the generator (k_g1)
-        hipLaunchKernelGGL(ck.g1, dim3(e->L.params_mode ? (unsigned)((2 * g.N + 63) / 64) : g1), dim3(64), 0, sb, g);
-    if (e->modes.g2_team)
-        hipLaunchKernelGGL(k_g2_alloc_team, dim3(gt), dim3(64), 0, b.st[1], g);
-    else
-        hipLaunchKernelGGL(ck.g2_alloc, dim3(g1), dim3(64), 0, b.st[1], g);
-    if (b.st[2]) {
-        hipEventRecord(b.ev_aux2, sb);
-        hipStreamWaitEvent(st, b.ev_aux2, 0);
-    }
+    } else {
+        // main, first part: the hash-to-G2 critical path
+        hipLaunchKernelGGL(k_sha_values, dim3(g1), dim3(64), 0, st, g);
+        hipLaunchKernelGGL(ck.map, dim3(g2), dim3(64), 0, st, g);
+        launch_cofactor(ck, e->cofactor_mode == 2 || (e->cofactor_mode == 0 && g.N <= BLSW_COFACTOR_CHUNKED_MAX_LANES), g, st);
+        hipLaunchKernelGGL(ck.prepare, dim3(g1), dim3(64), 0, st, g, 0);
+        // aux: prepare_g2(sig) and the group allocations (53 ms alone beside the 86 ms of the main stream's first part)
+        hipStream_t sb = b.st[1];
+        hipLaunchKernelGGL(ck.prepare, dim3(g1), dim3(64), 0, sb, g, 1);
+        if (e->L.n_keys) {  // aggregate_verify: one lane per (instance, key) allocates, then mapped_aggregate + pk != 0 + prepare_g1 per instance
+            hipLaunchKernelGGL(ck.agg_keys, dim3((unsigned)((g.N * e->L.n_keys + 63) / 64)), dim3(64), 0, sb, g, g.ws.keyproj);
+            hipLaunchKernelGGL(ck.agg_sum, dim3(g1), dim3(64), 0, sb, g, (const Fp*)g.ws.keyproj);
+        } else  // params_mode: lanes [N, 2 N) allocate and prepare the generator (k_g1)
+            hipLaunchKernelGGL(ck.g1, dim3(e->L.params_mode ? (unsigned)((2 * g.N + 63) / 64) : g1), dim3(64), 0, sb, g);
+        if (e->modes.g2_team)
+            hipLaunchKernelGGL(k_g2_alloc_team, dim3(gt), dim3(64), 0, b.st[1], g);
+        else
+            hipLaunchKernelGGL(ck.g2_alloc, dim3(g1), dim3(64), 0, b.st[1], g);
     }
     if (K == 1) {
         hipEventRecord(b.ev_aux, b.st[1]);
         // main, second part: the pairing
         hipStreamWaitEvent(st, b.ev_aux, 0);
-        if (!(dbg_skip & 1)) launch_pairing(g, e->modes, st);
+        launch_pairing(g, e->modes, st);
     }
     hipStreamWaitEvent(st, b.ev_sha, 0);
     hipEventRecord(b.ev_chains, st);
@@ -575,10 +562,7 @@ int blsw_engine_create_ex(blsw_engine_t** out, uint64_t n, uint32_t msg_len, uin
         chk(hipMalloc(reinterpret_cast<void**>(&b.d_desc), sizeof(StepDesc) * max_steps), "desc alloc");
         chk(hipStreamCreateWithPriority(&b.st[0], hipStreamNonBlocking, main_prio), "stream create");
         chk(hipStreamCreateWithPriority(&b.st[1], hipStreamNonBlocking, aux_prio), "stream create");
-#ifdef BLSW_AUX2
-        chk(hipStreamCreateWithPriority(&b.st[2], hipStreamNonBlocking, aux_prio), "stream create");
-#endif
-        hipEvent_t* single[] = {&b.ev_start, &b.ev_aux, &b.ev_aux2, &b.ev_sha, &b.ev_chains, &b.ev_done};
+        hipEvent_t* single[] = {&b.ev_start, &b.ev_aux, &b.ev_sha, &b.ev_chains, &b.ev_done};
         for (hipEvent_t* ev : single) chk(hipEventCreateWithFlags(ev, hipEventDisableTiming), "event create");
         b.ev_in = new hipEvent_t[max_steps]();
         b.ev_x = new hipEvent_t[max_steps]();
@@ -993,7 +977,7 @@ int blsw_verify_multi_batch(const uint64_t* d_pks_xy, const uint8_t* d_msgs, uin
     if (d_witness && witness_stride < L.n_witness) return BLSW_ERR_ARG;
     StepDesc* d_desc = reinterpret_cast<StepDesc*>(d_workspace);
     Workspace ws = carve(reinterpret_cast<char*>(d_workspace) + 256, NP, L, false, DEFAULT_MODES, n);
-    const bool par = n_pairs >= BLSW_MILLER_PAR_MIN_PAIRS;  // pairs in parallel (miller_par.cuh); few pairs: one team walks the chain
+    const bool par = n_pairs >= BLSW_MILLER_PAR_MIN_PAIRS;  // pairs in parallel (miller_par.hpp); few pairs: one team walks the chain
     if (ws.total_bytes + 256 + (par ? miller_par_bytes(n, n_pairs, BLSW_MILLER_CHUNK_DEFAULT) : 0) > workspace_bytes) return BLSW_ERR_WORKSPACE;
     Group gp = direct_group(n, n_pairs, msg_len, L, d_desc, ws);  // per-pair work: N = n * n_pairs lanes
     Group gs = direct_group(n, 1, msg_len, L, d_desc, ws);        // per-signature work: N = n lanes

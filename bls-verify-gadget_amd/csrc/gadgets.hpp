@@ -3,9 +3,9 @@
 // ConstraintSystem::witness_assignment for the corresponding Var x Var operation, in the same order,
 // and stores them (48 B, Montgomery, little-endian limbs) at the lane's cursor.
 // Operations with a constant operand are linear combinations in the circuit (no witness): callers use
-// the plain value functions of fp.cuh for those.  Rules: SURVEY.md App. A.1, A.2.
+// the plain value functions of fp.hpp for those.  Rules: SURVEY.md App. A.1, A.2.
 #pragma once
-#include "fp.cuh"
+#include "fp.hpp"
 
 namespace blsw {
 
@@ -23,9 +23,7 @@ struct Emitter {
             pos++;
             return;
         }
-#if defined(__HIP_DEVICE_COMPILE__) && defined(BLSW_DEBUG_NO_EMIT)  // timing experiment: chains without their staging stores
-        if (v.l[0] == 0x12345678u && v.l[7] == 0x9abcdef0u) *reinterpret_cast<uint32_t*>(base + (size_t)pos * stride) = 1;
-#elif defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__)
         // witnesses live in global memory (staging or an output tensor): say so — a generic pointer makes these FLAT stores, which count on
         // lgkmcnt as well and hold up every later wait for an LDS operation (the team kernels) until their addresses are resolved
         blsw_global_u32x4* d = (blsw_global_u32x4*)(base + (size_t)pos * stride);

@@ -1,13 +1,13 @@
-// libblsw.so, one translation unit per kernel family (see kcommon.cuh, build.py).
-// Two compilations (build.py, kcommon.cuh: BLSW_K). Grouped-engine compilation of THIS unit: programs out of line, one wave per SIMD with
+// libblsw.so, one translation unit per kernel family (see kcommon.hpp, build.py).
+// Two compilations (build.py, kcommon.hpp: BLSW_K). Grouped-engine compilation of THIS unit: programs out of line, one wave per SIMD with
 // ~100 registers left to the streaming kernels on the same SIMD (inlined it takes the whole file and the expansion starves; inlined at
 // 256 registers it spills 2 400 registers into its hot loop: profiles/r03_ab_chain_builds.txt); -DBLSW_INL_COFACTOR / -DBLSW_W2_COFACTOR for A/B runs.
 // Direct-mode compilation (*_inl): inlined, the whole register file.
 #if defined(BLSW_KVARIANT_INL) || defined(BLSW_INL_COFACTOR)
 #define BLSW_INLINE_CHAINS 1
 #endif
-#include "kcommon.cuh"
-#include "cofactor_par.cuh"
+#include "kcommon.hpp"
+#include "cofactor_par.hpp"
 #if !defined(BLSW_KVARIANT_INL) && defined(BLSW_W2_COFACTOR)
 #define BLSW_CHAIN_ATTR BLSW_ATTR_W2
 #else
@@ -33,7 +33,7 @@ __global__ __launch_bounds__(64) BLSW_CHAIN_ATTR void BLSW_K(k_cofactor)(Group g
     st_fp(o + 5 * N, h.z.c1);
 }
 
-// The same segment with the three 255-bit chunks of the scalar on three lanes (cofactor_par.cuh): lanes [0, N) run chunk 0 (and emit
+// The same segment with the three 255-bit chunks of the scalar on three lanes (cofactor_par.hpp): lanes [0, N) run chunk 0 (and emit
 // Q0 + Q1 and the to_affine of the sum), [N, 2N) chunk 1, [2N, 3N) chunk 2 — waves are chunk-homogeneous, so a wave still appends
 // whole 3 KiB rows to its tile; what the chunks leave for the join is parked in the line-coefficient rows of prepare_g2(H(m)),
 // which that kernel writes afterwards.
@@ -45,11 +45,7 @@ __global__ __launch_bounds__(64) BLSW_CHAIN_ATTR void BLSW_K(k_cofactor_chunk)(G
     const uint64_t I = t - (uint64_t)c * N;
     LaneId id = lane_id(g, I);
     Proj<OpsFp2> q0 = ld_proj2(g.ws.q + I, N), q1 = ld_proj2(g.ws.q + 6 * N + I, N);
-#if defined(BLSW_COFACTOR_LDS) && !defined(BLSW_KVARIANT_INL)
-    chain_cofactor_chunk(EMITJ(g, id, off_add, stride_hash), EMITJ(g, id, off_cofactor, stride_hash), q0, q1, c, CoeffStrided{g.ws.coeff_h + I, N}, true);
-#else
     chain_cofactor_chunk(EMITJ(g, id, off_add, stride_hash), EMITJ(g, id, off_cofactor, stride_hash), q0, q1, c, CoeffStrided{g.ws.coeff_h + I, N});
-#endif
 }
 
 __global__ __launch_bounds__(64) BLSW_CHAIN_ATTR void BLSW_K(k_cofactor_join)(Group g) {

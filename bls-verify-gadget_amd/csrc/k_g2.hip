@@ -1,12 +1,12 @@
-// libblsw.so, one translation unit per kernel family (see kcommon.cuh, build.py).
-// Two compilations (build.py, kcommon.cuh: BLSW_K). Grouped-engine compilation of THIS unit: programs out of line, one wave per SIMD with
+// libblsw.so, one translation unit per kernel family (see kcommon.hpp, build.py).
+// Two compilations (build.py, kcommon.hpp: BLSW_K). Grouped-engine compilation of THIS unit: programs out of line, one wave per SIMD with
 // ~100 registers left to the streaming kernels on the same SIMD (inlined it takes the whole file and the expansion starves; inlined at
 // 256 registers it spills 2 400 registers into its hot loop: profiles/r03_ab_chain_builds.txt); -DBLSW_INL_G2 / -DBLSW_W2_G2 for A/B runs.
 // Direct-mode compilation (*_inl): inlined, the whole register file.
 #if defined(BLSW_KVARIANT_INL) || defined(BLSW_INL_G2)
 #define BLSW_INLINE_CHAINS 1
 #endif
-#include "kcommon.cuh"
+#include "kcommon.hpp"
 #if !defined(BLSW_KVARIANT_INL) && defined(BLSW_W2_G2)
 #define BLSW_CHAIN_ATTR BLSW_ATTR_W2
 #else

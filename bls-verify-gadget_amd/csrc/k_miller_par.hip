@@ -1,9 +1,9 @@
-// libblsw.so, one translation unit per kernel family (see kcommon.cuh, build.py).
-// N+1-pair product (blsw_verify_multi_batch) with the pairs in parallel: the four phases of miller_par.cuh as kernels, and the
+// libblsw.so, one translation unit per kernel family (see kcommon.hpp, build.py).
+// N+1-pair product (blsw_verify_multi_batch) with the pairs in parallel: the four phases of miller_par.hpp as kernels, and the
 // final exponentiation + is_one of the six-lane team program started from the stored Miller value.
-#include "kcommon.cuh"
-#include "miller_par.cuh"
-#include "team_multi.cuh"
+#include "kcommon.hpp"
+#include "miller_par.hpp"
+#include "team_multi.hpp"
 
 namespace blsw {
 
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(64) void k_miller_spine_team(Group gs, MillerParArg
         st_fp(a.ffinal + (uint64_t)(2 * j + 1) * gs.N + I, f.c1);
     }
 }
-// final exponentiation + is_one of the stored Miller values, six lanes per instance (team.cuh)
+// final exponentiation + is_one of the stored Miller values, six lanes per instance (team.hpp)
 __global__ __launch_bounds__(64) void k_final_team(Group gs, MillerParArgs a) {
     __shared__ Fp2 lds[BLSW_TEAMS_PER_WAVE * TS_NSLOTS];
     const uint32_t team = threadIdx.x / 6, j = threadIdx.x % 6;

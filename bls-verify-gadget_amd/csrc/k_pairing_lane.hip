@@ -1,5 +1,5 @@
-// libblsw.so, one translation unit per kernel family (see kcommon.cuh, build.py).
-#include "kcommon.cuh"
+// libblsw.so, one translation unit per kernel family (see kcommon.hpp, build.py).
+#include "kcommon.hpp"
 
 namespace blsw {
 

@@ -1,11 +1,11 @@
-// libblsw.so, one translation unit per kernel family (see kcommon.cuh, build.py).
-// Two compilations (build.py, kcommon.cuh: BLSW_K). Grouped-engine compilation of THIS unit: programs inlined into the kernel and
+// libblsw.so, one translation unit per kernel family (see kcommon.hpp, build.py).
+// Two compilations (build.py, kcommon.hpp: BLSW_K). Grouped-engine compilation of THIS unit: programs inlined into the kernel and
 // two waves per SIMD (<= 256 registers) — measured +4 % on the 20-step job, neutral in the steady state (profiles/r03_ab_chain_builds.txt);
 // -DBLSW_OUTLINE_SHA restores the out-of-line build for A/B runs. Direct-mode compilation (*_inl): inlined, the whole register file.
 #if defined(BLSW_KVARIANT_INL) || !defined(BLSW_OUTLINE_SHA)
 #define BLSW_INLINE_CHAINS 1
 #endif
-#include "kcommon.cuh"
+#include "kcommon.hpp"
 #if !defined(BLSW_KVARIANT_INL) && !defined(BLSW_OUTLINE_SHA)
 #define BLSW_CHAIN_ATTR BLSW_ATTR_W2
 #else

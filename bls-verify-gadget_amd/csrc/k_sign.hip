@@ -1,7 +1,7 @@
-// libblsw.so, one translation unit per kernel family (see kcommon.cuh, build.py).
-#include "kcommon.cuh"
-#include "values.cuh"
-#include "vsign.cuh"
+// libblsw.so, one translation unit per kernel family (see kcommon.hpp, build.py).
+#include "kcommon.hpp"
+#include "values.hpp"
+#include "vsign.hpp"
 
 namespace blsw {
 
@@ -19,7 +19,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         bool inf = true;
         if (st == SIGN_OK) {
             Proj<OpsFp2> h = ld_proj2(ws.h + i, n);
-            if (!fp2_is_zero(h.z)) {  // sig = sk * H(m): joint ladder over the four base-|x| digits of sk (vsign.cuh)
+            if (!fp2_is_zero(h.z)) {  // sig = sk * H(m): joint ladder over the four base-|x| digits of sk (vsign.hpp)
                 // homogeneous (x, y, z) = affine (x / z, y / z) = Jacobian (x z, y z^2, z)
                 const Jac2 q = {fp2_mul_inl(h.x, h.z), fp2_mul_inl(h.y, v_sqr(h.z)), h.z};
                 const Jac2 acc = v_g2_mul_gls(ParkRows{ws.coeff_h + i, n}, q, k);
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     } else {
         Fp x = fp_zero(), y = fp_zero();
         bool inf = true;
-        if (st == SIGN_OK) {  // pk = sk * g1: fixed-base windows (vsign.cuh)
+        if (st == SIGN_OK) {  // pk = sk * g1: fixed-base windows (vsign.hpp)
             const Jac1v acc = v1_mul_g1_fixed(k);
             if (!fp_is_zero(acc.z)) {
                 const Fp ai = fp_inv(acc.z), ai2 = fp_sqr(ai);

@@ -1,5 +1,5 @@
-// libblsw.so, one translation unit per kernel family (see kcommon.cuh, build.py).
-#include "kcommon.cuh"
+// libblsw.so, one translation unit per kernel family (see kcommon.hpp, build.py).
+#include "kcommon.hpp"
 
 namespace blsw {
 
@@ -41,9 +41,6 @@ __device__ __forceinline__ void expand_locate(const ExpandArgs& a, uint4*& out, 
 }
 // word w of the instance whose stream starts at b (64-byte runs of 16 words, 64 instances interleaved per chunk)
 __device__ __forceinline__ uint32_t expand_word(const uint32_t* b, uint32_t w) {
-    #ifdef BLSW_DEBUG_EXPAND_NOREAD  // timing experiment
-    return 0x55555555u + w;
-#endif
     return b[(uint64_t)(w / BLSW_BITS_CHUNK_WORDS) * (64 * BLSW_BITS_CHUNK_WORDS) + (w % BLSW_BITS_CHUNK_WORDS)];
 }
 // pieces [0, P0) in front of the first boundary: written by workgroup 0 of every variant
@@ -77,11 +74,6 @@ __global__ __launch_bounds__(THREADS) void k_sha_expand(ExpandArgs a) {
     if (blockIdx.x * ((THREADS / 3) * ITERS) + (P0 + THREADS - 1) / 3 + (THREADS / 3) * (ITERS - 1) < a.sha_bits) {
         // whole workgroup in range (all but the last one or two of an instance): all bit words first, then the stores back to
         // back — no bounds checks, no wait between a store and the next load
-#ifdef BLSW_DEBUG_EXPAND_CONST  // timing experiment: the stores without the bit logic (wrong witnesses)
-#pragma unroll
-        for (int k = 0; k < ITERS; k++) expand_store<NT>(dst + (uint64_t)k * THREADS, rc);
-        return;
-#endif
         uint32_t w[ITERS];
 #pragma unroll
         for (int k = 0; k < ITERS; k++) w[k] = expand_word(b, w0 + k * (THREADS / 96));

@@ -1,10 +1,10 @@
-// libblsw.so, one translation unit per kernel family (see kcommon.cuh, build.py).
-#include "kcommon.cuh"
-#include "team_multi.cuh"
+// libblsw.so, one translation unit per kernel family (see kcommon.hpp, build.py).
+#include "kcommon.hpp"
+#include "team_multi.hpp"
 
 namespace blsw {
 
-// Miller loop + final exponentiation + is_one, SIX LANES PER INSTANCE (team.cuh): ten instances per wave, every Fp12
+// Miller loop + final exponentiation + is_one, SIX LANES PER INSTANCE (team.hpp): ten instances per wave, every Fp12
 // value distributed over the team's registers, operands and products exchanged through the team's 3.5 KB slot file in LDS
 __global__ __launch_bounds__(64) void k_pairing_team(Group g) {
     __shared__ Fp2 lds[BLSW_TEAMS_PER_WAVE * TS_NSLOTS];

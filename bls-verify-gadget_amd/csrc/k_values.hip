@@ -1,6 +1,6 @@
-// libblsw.so, one translation unit per kernel family (see kcommon.cuh, build.py).
-#include "kcommon.cuh"
-#include "values.cuh"
+// libblsw.so, one translation unit per kernel family (see kcommon.hpp, build.py).
+#include "kcommon.hpp"
+#include "values.hpp"
 
 namespace blsw {
 

@@ -5,7 +5,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
-#include "chains.cuh"
+#include "chains.hpp"
 #include "layout.h"
 
 namespace blsw {
@@ -365,7 +365,7 @@ __global__ void k_bench_fpmul(uint32_t iters, uint32_t* out);
 __global__ void k_bench_fpmul32(uint32_t iters, uint32_t* out);
 __global__ void k_bench_fpinv(uint32_t iters, uint32_t* out);
 __global__ void k_bench_fp2mulw(uint32_t iters, uint32_t* out);
-// pair-parallel Miller product (k_miller_par.hip, miller_par.cuh): value stores of n instances, element-major Fp12 rows
+// pair-parallel Miller product (k_miller_par.hip, miller_par.hpp): value stores of n instances, element-major Fp12 rows
 struct MillerParArgs {
     Fp* cprod;   // [12][n * 68 * C] chunk products
     Fp* q;       // [12][n * 68 * C] prefixes over the chunks of a step
@@ -392,9 +392,6 @@ __global__ void k_place_runs(const Fp* __restrict__ tiles, uint64_t first, uint3
                              uint32_t K, uint32_t tile_w);
 __global__ void k_place_rows(const Fp* __restrict__ rows, uint32_t n_rows, uint32_t dst_off, uint64_t* __restrict__ d_witness, uint64_t stride);
 // the two compilations of the chain units as one table
-#if defined(BLSW_COFACTOR_LDS)
-__global__ void k_cofactor_loop_lds(Group g);
-#endif
 struct ChainKernels {
     void (*sha)(Group, int, int);
     void (*g1)(Group);
@@ -404,7 +401,7 @@ struct ChainKernels {
     void (*map)(Group);
     void (*cofactor)(Group);
     void (*prepare)(Group, int);
-    void (*cofactor_chunk)(Group);  // the cofactor segment with its three chunks on three lanes, and the join (cofactor_par.cuh)
+    void (*cofactor_chunk)(Group);  // the cofactor segment with its three chunks on three lanes, and the join (cofactor_par.hpp)
     void (*cofactor_join)(Group);
 };
 // clear_cofactor2 of N lanes on `st`: chunked (three lanes per (pk, msg) pair + the join) or as one chain per lane
@@ -412,9 +409,6 @@ inline void launch_cofactor(const ChainKernels& ck, bool chunked, const Group& g
     const unsigned g1 = (unsigned)((g.N + 63) / 64), g3 = (unsigned)((3 * g.N + 63) / 64);
     if (chunked) {
         hipLaunchKernelGGL(ck.cofactor_chunk, dim3(g3), dim3(64), 0, st, g);
-#if defined(BLSW_COFACTOR_LDS)
-        if (ck.cofactor_chunk == k_cofactor_chunk) hipLaunchKernelGGL(k_cofactor_loop_lds, dim3(g3), dim3(64), 0, st, g);
-#endif
         hipLaunchKernelGGL(ck.cofactor_join, dim3(g1), dim3(64), 0, st, g);
     } else {
         hipLaunchKernelGGL(ck.cofactor, dim3(g1), dim3(64), 0, st, g);

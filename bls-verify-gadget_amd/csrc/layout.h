@@ -1,11 +1,11 @@
 // Witness-vector segment table (host side). Segment sizes are properties of the circuit shape:
-// the SHA-256 segment is obtained by running the mask propagation of sha.cuh in count-only mode
+// the SHA-256 segment is obtained by running the mask propagation of sha.hpp in count-only mode
 // (no values, no stores); the field segments are the fixed constants below (pinned by tests against
 // the CPU oracle's allocation trace).
 #pragma once
 #include <vector>
 #include "../../include/blsw.h"
-#include "sha.cuh"
+#include "sha.hpp"
 
 namespace blsw {
 

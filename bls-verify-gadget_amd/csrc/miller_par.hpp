@@ -9,10 +9,10 @@
 //                                    f_{k+1} = f1_k T[k]; stores f1_k                                 (68 steps instead of 68 (K + 1))
 //   m3  (lane per step k, chunk c)   f = f1_k Q[k][c], then the chunk's B witness-emitting ell(f, pair j) at their places
 // Field products are commutative and every value is a canonical residue, so the witnesses are bit for bit those of the serial
-// chain (chains.cuh: chain_miller_multi; team.cuh: team_miller_multi), which stay as the statement of the segment.
+// chain (chains.hpp: chain_miller_multi; team.hpp: team_miller_multi), which stay as the statement of the segment.
 // Compiles for the host as well: tests/hostsim runs the four phases as loops against the oracle.
 #pragma once
-#include "chains.cuh"
+#include "chains.hpp"
 
 namespace blsw {
 

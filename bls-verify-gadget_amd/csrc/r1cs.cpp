@@ -11,13 +11,13 @@
 // OptimizationGoal::Constraints: constants fold, constant x variable and sums are linear combinations,
 // every variable x variable product, inverse, is_eq, select and boolean operation allocates and constrains. It shares no
 // code with oracle/ (the test oracle has its own value-carrying restatement; tests compare the two row by row and check
-// A z o B z = C z on GPU-produced witnesses). Constants come from constants.cuh / sha.cuh like the kernels'.
+// A z o B z = C z on GPU-produced witnesses). Constants come from constants.hpp / sha.hpp like the kernels'.
 #include <string.h>
 #include <algorithm>
 #include <mutex>
 #include <vector>
 #include "../../include/blsw.h"
-#include "constants.cuh"
+#include "constants.hpp"
 #include "layout.h"
 
 namespace blsw {

@@ -6,7 +6,7 @@
 // values, so the kernel emits exactly the bits arkworks would allocate, in allocation order.
 // Output of this stage is a BITSTREAM (1 bit per boolean witness); sha_expand turns it into 48-byte Fp elements.
 #pragma once
-#include "fp.cuh"
+#include "fp.hpp"
 
 namespace blsw {
 

@@ -1,9 +1,9 @@
 // Six lanes per instance ("team") for the Fp12 part of the path: miller_loop, final_exponentiation, is_one
-// (constraints.rs:121-127). Same witnesses, in the same order, as chains.cuh::chain_miller /
+// (constraints.rs:121-127). Same witnesses, in the same order, as chains.hpp::chain_miller /
 // chain_final_exp_is_one, which stay as the single-lane statement of the segment (host harness, aggregate path).
 //
 // Lane j of a team owns the Fp2 coefficient j of every Fp12 value, (c0.c0, c0.c1, c0.c2, c1.c0, c1.c1, c1.c2), in
-// registers. A tower operation is one pass over an op table (team_tables.cuh, generated from the tower formulas):
+// registers. A tower operation is one pass over an op table (team_tables.hpp, generated from the tower formulas):
 //   publish the operand coefficients in the team's slot file (LDS)  ->  rounds of <= 6 independent Fp2 products, one per
 //   lane, operands gathered as small linear combinations of slots, witnesses stored at the task's offset  ->  every lane
 //   gathers its coefficient of the result from the product slots.
@@ -13,8 +13,8 @@
 // implementation (one lane per thread, wave barrier between phases), tests/hostsim runs the same program and the same
 // lane routines with a loop over the six lanes.
 #pragma once
-#include "team_tables.cuh"
-#include "tower.cuh"
+#include "team_tables.hpp"
+#include "tower.hpp"
 
 namespace blsw {
 
@@ -338,7 +338,7 @@ BLSW_HD typename TEAM::Reg team_exp_by_x(TEAM& t, const typename TEAM::Reg& f) {
     return t.exp_by_x(f);
 }
 // [k] ge for the bits of `words` (big-endian, the top bit is ge itself): the in-circuit subgroup check of G2 allocation
-// (curve.cuh::proj_mul_bits_be_w<OpsFp2>). Points are distributed over lanes 0..2 of a team (x, y, z).
+// (curve.hpp::proj_mul_bits_be_w<OpsFp2>). Points are distributed over lanes 0..2 of a team (x, y, z).
 template <class TEAM>
 BLSW_HD typename TEAM::Reg team_g2_mul_bits(TEAM& t, const typename TEAM::Reg& ge, const uint32_t* words, int nbits) {
     typename TEAM::Reg result = ge;
@@ -350,7 +350,7 @@ BLSW_HD typename TEAM::Reg team_g2_mul_bits(TEAM& t, const typename TEAM::Reg& g
     }
     return result;
 }
-// final_exponentiation . is_one (chains.cuh::chain_final_exp_is_one); the cursor of `t` must be at off_final_exp
+// final_exponentiation . is_one (chains.hpp::chain_final_exp_is_one); the cursor of `t` must be at off_final_exp
 template <class TEAM>
 BLSW_HD bool team_final_exp_is_one(TEAM& t, const typename TEAM::Reg& f, const Emitter& e_one) {
     typedef typename TEAM::Reg R;

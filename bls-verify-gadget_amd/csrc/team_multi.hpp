@@ -1,7 +1,7 @@
 // Device team with per-pair loads for the N+1-pair product (k_team.hip, k_miller_par.hip).
 #pragma once
-#include "kcommon.cuh"
-#include "team.cuh"
+#include "kcommon.hpp"
+#include "team.hpp"
 
 namespace blsw {
 

@@ -2,8 +2,8 @@
 // ark-r1cs-std ^0.4.0 allocates them: fields/cubic_extension.rs, quadratic_extension.rs, fp6_3over2.rs, fp12.rs
 // (SURVEY.md App. A.2). Every Var x Var Fp2 product is 3 Fp witnesses (Karatsuba), every Fp2 square is 2.
 #pragma once
-#include "constants.cuh"
-#include "gadgets.cuh"
+#include "constants.hpp"
+#include "gadgets.hpp"
 
 namespace blsw {
 

@@ -1,7 +1,7 @@
-// Device side of the value-only entries: vcurve.cuh plus the kernels' common definitions.
+// Device side of the value-only entries: vcurve.hpp plus the kernels' common definitions.
 #pragma once
-#include "kcommon.cuh"
-#include "vcurve.cuh"
+#include "kcommon.hpp"
+#include "vcurve.hpp"
 
 namespace blsw {
 

@@ -2,8 +2,8 @@
 // want group elements and no witnesses (blsw_hash_to_g2_batch, blsw_sign_batch). Compiles for the host as well: tests/hostsim runs
 // the same functions against the CPU oracle.
 #pragma once
-#include "chains.cuh"
-#include "decode.cuh"
+#include "chains.hpp"
+#include "decode.hpp"
 
 namespace blsw {
 

@@ -3,12 +3,12 @@
 //       sk = k0 + k1 |x| + k2 |x|^2 + k3 |x|^3 (four 64-bit digits) and
 //       sk * Q = k0 Q + k1 (-psi Q) + k2 (psi^2 Q) + k3 (-psi^3 Q): one joint ladder of 64 doublings and at most 64 additions from a
 //       table of the 15 non-empty sums of the four bases (Straus), instead of 255 doublings and ~128 additions.
-//   G1: the base is the fixed generator: pk = sum_w T[w][digit_w] with T[w][d - 1] = d 16^w g1 (g1_table.cuh, generated): 64 mixed
+//   G1: the base is the fixed generator: pk = sum_w T[w][digit_w] with T[w][d - 1] = d 16^w g1 (g1_table.hpp, generated): 64 mixed
 //       additions, no doubling.
 // Compiles for the host as well (tests/hostsim: the sign fixtures and the oracle's signer).
 #pragma once
-#include "g1_table.cuh"
-#include "vcurve.cuh"
+#include "g1_table.hpp"
+#include "vcurve.hpp"
 
 namespace blsw {
 

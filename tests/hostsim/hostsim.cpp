@@ -4,13 +4,13 @@
 #include <cstdio>
 #include <cstring>
 #include <vector>
-#include "../../bls-verify-gadget_amd/csrc/chains.cuh"
-#include "../../bls-verify-gadget_amd/csrc/decode.cuh"
+#include "../../bls-verify-gadget_amd/csrc/chains.hpp"
+#include "../../bls-verify-gadget_amd/csrc/decode.hpp"
 #include "../../bls-verify-gadget_amd/csrc/layout.h"
-#include "../../bls-verify-gadget_amd/csrc/team.cuh"
-#include "../../bls-verify-gadget_amd/csrc/vsign.cuh"
-#include "../../bls-verify-gadget_amd/csrc/miller_par.cuh"
-#include "../../bls-verify-gadget_amd/csrc/cofactor_par.cuh"
+#include "../../bls-verify-gadget_amd/csrc/team.hpp"
+#include "../../bls-verify-gadget_amd/csrc/vsign.hpp"
+#include "../../bls-verify-gadget_amd/csrc/miller_par.hpp"
+#include "../../bls-verify-gadget_amd/csrc/cofactor_par.hpp"
 #include <array>
 
 using namespace blsw;
@@ -22,7 +22,7 @@ static Fp load_fp(const uint64_t* p) {
 }
 
 
-// the six-lanes-per-instance program of team.cuh, lanes run one after the other per phase
+// the six-lanes-per-instance program of team.hpp, lanes run one after the other per phase
 struct TeamHost {
     typedef std::array<Fp2, 6> Reg;
     Fp2 slots[TS_NSLOTS];
@@ -116,7 +116,7 @@ struct TeamHost {
     }
 };
 static int g_use_team = 0;
-static int g_cofactor_par = 0;  // 1: clear_cofactor2 through cofactor_par.cuh (chunks in the order 2, 0, 1, then the join)
+static int g_cofactor_par = 0;  // 1: clear_cofactor2 through cofactor_par.hpp (chunks in the order 2, 0, 1, then the join)
 static uint32_t g_miller_chunk = 2;  // pairs per chunk of the pair-parallel Miller product (mode 2)
 // G2 allocation with the scalar multiplication of the subgroup check on the team program (lanes 0..2 own x, y, z)
 static void g2_alloc_segment(uint32_t* base, const blsw_layout_t& L, const Fp2& sx, const Fp2& sy) {
@@ -290,7 +290,7 @@ int hostsim_witness_multi(const uint64_t* pks_xy, const uint8_t* msgs, uint32_t 
     bool sinf = fp2_is_zero(sx) && fp2_is_zero(sy);
     Proj<OpsFp2> sp = {sinf ? fp2_zero() : sx, sinf ? fp2_one() : sy, sinf ? fp2_zero() : fp2_one()};
     chain_prepare_g2({base, L.off_prep_sig}, sp, CoeffLinear{cs.data()});
-    if (g_use_team == 2) {  // miller_par.cuh: the four phases of the pair-parallel Miller product, tasks run one after the other
+    if (g_use_team == 2) {  // miller_par.hpp: the four phases of the pair-parallel Miller product, tasks run one after the other
         HostPairs hp = {&ch, &pk};
         const uint32_t B = g_miller_chunk, C = miller_chunks(K, B), S = BLSW_MILLER_STEPS;
         std::vector<Fp> cprod(12 * S * C), q(12 * S * C), tt(12 * S), f1(12 * S);
@@ -383,7 +383,7 @@ int hostsim_g2_decode(const uint8_t* in, uint64_t* out_xy) {
     memcpy(out_xy + 18, y.c1.l, 48);
     return st;
 }
-// signer logic (vsign.cuh, what k_sign runs per lane): sk (32 LE bytes), H(msg) affine -> sig96, pk48; returns the SIGN_* status
+// signer logic (vsign.hpp, what k_sign runs per lane): sk (32 LE bytes), H(msg) affine -> sig96, pk48; returns the SIGN_* status
 int hostsim_sign(const uint8_t* sk32, const uint64_t* h_xy, uint8_t* sig96, uint8_t* pk48) {
     uint32_t k[8];
     int st = sk_from_le32(sk32, k);
@@ -430,7 +430,7 @@ int64_t hostsim_r1cs_check(uint64_t n_cons, const uint64_t* const* row_ptr, cons
         if (!fp_eq(fp_mul(dot(0, i), dot(1, i)), dot(2, i))) return (int64_t)i;
     return -1;
 }
-// value-only hash_to_g2 (vcurve.cuh: what blsw_hash_to_g2_batch / blsw_sign_batch run per lane): expand_message values,
+// value-only hash_to_g2 (vcurve.hpp: what blsw_hash_to_g2_batch / blsw_sign_batch run per lane): expand_message values,
 // hash_to_field, SSWU + isogeny x 2, Q0 + Q1, psi-based cofactor clearing; affine result (all zero = identity)
 void hostsim_hash_to_g2_values(const uint8_t* msg, uint32_t msg_len, uint64_t* out_xy) {
     uint32_t uw[64];

@@ -80,7 +80,7 @@ def witness_multi(pks_xy, msgs, sig_xy):
 
 
 def hash_to_g2_values(msg):
-    """value-only hash_to_g2 of the device headers (vcurve.cuh) on the host: affine (x.c0, x.c1, y.c0, y.c1) as [24] uint64"""
+    """value-only hash_to_g2 of the device headers (vcurve.hpp) on the host: affine (x.c0, x.c1, y.c0, y.c1) as [24] uint64"""
     out = np.zeros(24, dtype=np.uint64)
     buf = (ctypes.c_uint8 * max(1, len(msg))).from_buffer_copy(bytes(msg) if len(msg) else b"\0")
     load().hostsim_hash_to_g2_values(buf, len(msg), out.ctypes.data_as(u64p))

@@ -1,4 +1,4 @@
-"""Kernel logic without a GPU: the device headers (bls-verify-gadget_amd/csrc/*.cuh) compiled for the host and run on
+"""Kernel logic without a GPU: the device headers (bls-verify-gadget_amd/csrc/*.hpp) compiled for the host and run on
 one "lane" must reproduce the oracle's witness vector bit for bit. Also checks the segment table and the C-ABI exports."""
 import ctypes
 import importlib
@@ -152,7 +152,7 @@ def test_decode_all_verify_fixture_points(oracle):
 
 
 def test_endomorphism_subgroup_tests_against_the_order_r_definition(oracle):
-    """g1_in_subgroup / g2_in_subgroup (decode.cuh: phi(P) = -[x^2]P and psi(P) = [x]P, the tests ark-bls12-381 0.4 itself uses, eprint 2021/1130)
+    """g1_in_subgroup / g2_in_subgroup (decode.hpp: phi(P) = -[x^2]P and psi(P) = [x]P, the tests ark-bls12-381 0.4 itself uses, eprint 2021/1130)
     against the oracle's [r]P == O: random encodings (about half decode to curve points, all of large order outside the subgroup), points of the
     COFACTOR torsion ([r]Q for random curve points Q: the false positives an endomorphism test could have), and their sums with subgroup points."""
     import random
@@ -292,7 +292,7 @@ def test_aggregate_verify_device_logic(oracle):
 
 @pytest.mark.parametrize("name,case", eth_cases("sign"))
 def test_sign_device_logic(oracle, name, case):
-    """Signer ladders + point encoding (decode.cuh) against tests/test_cases/sign/*.json (tests.rs:203-237: big-endian
+    """Signer ladders + point encoding (decode.hpp) against tests/test_cases/sign/*.json (tests.rs:203-237: big-endian
     privkey in the JSON; null output <=> sk == 0); H(msg) is supplied by the oracle, pk is checked against the oracle."""
     sk = int.from_bytes(unhex(case["input"]["privkey"]), "big")
     msg = unhex(case["input"]["message"])
@@ -319,7 +319,7 @@ def test_sign_rejects_noncanonical_secret_key(oracle):
 
 
 def test_team_pairing_program(oracle):
-    """team.cuh (six lanes per instance: op tables + lane routines + the Miller / final-exponentiation program) on the host,
+    """team.hpp (six lanes per instance: op tables + lane routines + the Miller / final-exponentiation program) on the host,
     lanes run one after the other per phase: full witness vector bit-exact against the oracle, true / false / edge inputs."""
     lib = hostsim_lib.load()
     lib.hostsim_use_team(1)
@@ -335,15 +335,15 @@ def test_team_pairing_program(oracle):
 
 
 def test_team_tables_are_current(tmp_path):
-    """team_tables.cuh is generated (tools/gen_team_tables.py expands the tower formulas into op tables): the committed
+    """team_tables.hpp is generated (tools/gen_team_tables.py expands the tower formulas into op tables): the committed
     header must be what the generator emits, and every op's witness count must be the single-lane code's."""
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = tmp_path / "team_tables.cuh"
+    out = tmp_path / "team_tables.hpp"
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_team_tables.py"), str(out)], capture_output=True, text=True, check=True)
-    assert out.read_text() == open(os.path.join(root, "bls-verify-gadget_amd", "csrc", "team_tables.cuh")).read()
+    assert out.read_text() == open(os.path.join(root, "bls-verify-gadget_amd", "csrc", "team_tables.hpp")).read()
     counts = {l.split(":")[0]: int(l.split(" witnesses")[0].split()[-1]) for l in r.stderr.strip().splitlines()}
     # fp12_mul_w 54, fp12_sqr_w 36, cyclotomic square 18, mul_by_014 30 (constant y) / 2 + 36 (variable y), inverse check 18+12+12
     # ... G2 projective double 3 * 2 + 8 * 3, addition 12 * 3
@@ -385,7 +385,7 @@ def test_team_table_invariants():
 
 
 def test_value_only_hash_to_g2_device_logic(oracle):
-    """vcurve.cuh (SSWU + isogeny without witnesses, psi-based cofactor clearing: two 64-bit ladders instead of the 636-bit
+    """vcurve.hpp (SSWU + isogeny without witnesses, psi-based cofactor clearing: two 64-bit ladders instead of the 636-bit
     h_eff ladder of the circuit) gives the point of hash_to_g2_with_cons (hasher.rs:727-740) — the reference's own equality,
     hasher.rs:1004-1026 — for the bls.rs:645 input, the reference's test strings and ragged lengths."""
     msgs = [b"", b"abc", b"abcdef0123456789", b"\x00" * 32, bytes(range(55)), bytes(range(56)), bytes(range(119)), bytes(range(120)), b"q" * 300]
@@ -396,7 +396,7 @@ def test_value_only_hash_to_g2_device_logic(oracle):
 
 
 def test_sign_random_scalars_device_logic(oracle):
-    """vsign.cuh against the oracle's signer on scalars that exercise every digit pattern of the base-|x| decomposition
+    """vsign.hpp against the oracle's signer on scalars that exercise every digit pattern of the base-|x| decomposition
     (small, one-digit, digit borders, near r) and random ones: sig = sk * H(m) through the psi ladder, pk = sk * g1 through the
     fixed-base windows."""
     import random
@@ -415,7 +415,7 @@ def test_sign_random_scalars_device_logic(oracle):
 
 
 def test_cofactor_chunks_in_parallel_device_logic(oracle):
-    """cofactor_par.cuh: clear_cofactor2's three 255-bit chunks as independent programs (chunk order 2, 0, 1: the start points of
+    """cofactor_par.hpp: clear_cofactor2's three 255-bit chunks as independent programs (chunk order 2, 0, 1: the start points of
     chunks 1 and 2 are VALUES — Jacobian doublings and one inversion — not the end of the previous chunk) and the join that folds
     them: the whole witness vector stays bit-exact, for valid / tampered instances, identity inputs and another message length."""
     lib = hostsim_lib.load()

@@ -323,7 +323,7 @@ def test_hash_to_g2_batch_ragged_multi_wave(pkg, oracle, msg_len):
 
 def test_sign_batch_ragged_multi_wave(pkg, oracle):
     """blsw_sign_batch over several waves (n = 200): sig = sk * H(m) through the four-digit psi ladder and pk = sk * g1 through the
-    fixed-base windows (vsign.cuh), scalars with special digit patterns and random ones, against the oracle's signer."""
+    fixed-base windows (vsign.hpp), scalars with special digit patterns and random ones, against the oracle's signer."""
     import random
 
     import torch
@@ -779,6 +779,31 @@ def test_engine_bench_shape_against_oracle(pkg, oracle):
     eng.close()
 
 
+def test_direct_calls_refuse_batches_beyond_free_hbm(pkg):
+    """verify_multi / aggregate_verify / the gadget allocate n witness vectors per call (4.19 GB each at 128 pairs): a batch beyond the free
+    HBM is refused with a BlswError that says so, before anything is allocated (round 3: torch.OutOfMemoryError half-way)."""
+    import torch
+
+    dev = torch.device("cuda:0")
+    free0, _ = torch.cuda.mem_get_info(dev)
+    n, K = 96, 128  # 96 x 4.19 GB = 402 GB
+    pks = torch.zeros((n, K, 12), dtype=torch.int64, device=dev)
+    msgs = torch.zeros((n, K, 32), dtype=torch.uint8, device=dev)
+    sig = torch.zeros((n, 24), dtype=torch.int64, device=dev)
+    with pytest.raises(pkg.BlswError, match="GB of HBM"):
+        pkg.verify_multi(pkg.ParametersVar(), pkg.PublicKeyVar.new_witness(pks), msgs, pkg.SignatureVar.new_witness(sig))
+    n2, K2 = 4096, 512  # 4096 x 82.8 MB = 339 GB
+    with pytest.raises(pkg.BlswError, match="GB of HBM"):
+        pkg.aggregate_verify(pkg.ParametersVar(), pkg.PublicKeyVar.new_witness(torch.zeros((n2, K2, 12), dtype=torch.int64, device=dev)),
+                             torch.ones((n2, K2), dtype=torch.uint8, device=dev), torch.zeros((n2, 32), dtype=torch.uint8, device=dev),
+                             pkg.SignatureVar.new_witness(torch.zeros((n2, 24), dtype=torch.int64, device=dev)))
+    with pytest.raises(pkg.BlswError, match="GB of HBM"):
+        pkg.BlsSignatureVerifyGadget(16384, 32, device=dev)  # 16 384 x 34 MB = 556 GB
+    torch.cuda.empty_cache()
+    free1, _ = torch.cuda.mem_get_info(dev)
+    assert free1 > free0 - (2 << 30)  # nothing of the refused calls stayed allocated
+
+
 def test_release_table_full_is_busy_and_nothing_is_queued(pkg):
     """Consumer mode with more distinct outputs than the release table holds (64): every accepted step reserves its output's slot when it is
     submitted, so the 65th distinct output is refused with BUSY BEFORE anything is queued or launched (round 3: the group was launched
@@ -1038,7 +1063,7 @@ def test_verify_multi_small(pkg, oracle):
 
 
 def test_verify_multi_pair_parallel_batch(pkg, oracle):
-    """The pair-parallel Miller product (miller_par.cuh; K >= 8) on a BATCH: three instances of K = 20 pairs (two chunks of 12 and
+    """The pair-parallel Miller product (miller_par.hpp; K >= 8) on a BATCH: three instances of K = 20 pairs (two chunks of 12 and
     8 pairs; one instance with a tampered message) — every witness element of every instance against the oracle."""
     K = 20
     cases = [synth.make_multi(oracle, K, tamper=t, start=11 * a) for a, t in enumerate([None, 13, None])]

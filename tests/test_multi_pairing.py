@@ -63,7 +63,7 @@ def test_other_message_length(oracle):
 
 @pytest.mark.parametrize("K,chunk,tamper", [(1, 2, None), (3, 2, None), (5, 2, 3), (5, 3, None), (4, 12, None)])
 def test_pair_parallel_miller_on_host_matches_oracle(oracle, K, chunk, tamper):
-    """miller_par.cuh: the Miller product cut into chunks of pairs (chunk products, prefixes over the chunks, the serial spine of
+    """miller_par.hpp: the Miller product cut into chunks of pairs (chunk products, prefixes over the chunks, the serial spine of
     squares and ell(sig), the chunks' witnesses from their prefix) gives the serial chain's witnesses bit for bit — chunk
     boundaries inside and at the end of the pair list, one chunk, more pairs than a chunk."""
     pks, msgs, sig, expect = synth.make_multi(oracle, K, tamper=tamper)

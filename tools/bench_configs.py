@@ -188,6 +188,86 @@ def main():
                       "instances": ne * st, "pairs": Kp * ne * st, "witness_written": True, "seconds": dt, "value": ne * st / dt, "unit": "instances/s", "pairs_per_s": Kp * ne * st / dt,
                       "output_GBps": ne * st * eng.n_witness * 48 / dt / 1e9}))
     eng.close()
+    del eng, outs
+    torch.cuda.empty_cache()
+
+    # configs[3] with a CONSUMER (round 4): a consumer-mode engine (late materialisation out of the 180 MB per instance of staging), ring of two
+    # n x 4.19 GB tensors, the digest kernel reads every tensor before the engine may overwrite it; and the same steps leaving in COMPACT form
+    # (blsw_engine_submit_multi_compact, ~180 MB per instance) through a ring of four buffers, each expanded (blsw_engine_expand_compact) into
+    # one tensor and digested — what a sharded run of this circuit would ship and what its receiver would do. The consumer's stream is in the
+    # high-priority queue pool (profiles/r04_consumer_timeline.txt).
+    consumer = torch.cuda.Stream(device=dev, priority=-1)
+
+    def drive(eng, n_steps, ring_outs, submit, consume):
+        """submit(k, out) / consume(s, out, stream): steps through a ring with BUSY -> drain, as sharding.stream_shard does"""
+        state = {"next": 0}
+
+        def drain():
+            while state["next"] < eng.materialised():
+                s0 = state["next"]
+                out = ring_outs[s0 % len(ring_outs)]
+                eng.wait_step(s0, consumer)
+                consume(s0, out, consumer)
+                eng.output_consumed(out, consumer)
+                state["next"] += 1
+
+        for k in range(n_steps):
+            while True:
+                try:
+                    submit(k, ring_outs[k % len(ring_outs)])
+                    break
+                except pkg.BlswBusy:
+                    drain()
+            drain()
+        eng.flush()
+        while state["next"] < n_steps:
+            drain()
+        consumer.synchronize()
+        torch.cuda.synchronize()
+
+    dig = torch.empty((ne, 2), dtype=torch.int64, device=dev)
+    acc = torch.zeros(2, dtype=torch.int64, device=dev)
+    eng = pkg.WitnessEngine(ne, 32, max_steps=co, device=dev, n_buffers=3, n_pairs=Kp, consumer_mode=1)
+    outs = [eng.new_witness_tensor() for _ in range(2)]
+
+    def consume_tensor(s0, out, stream):
+        with torch.cuda.stream(stream):
+            acc.add_(pkg.witness_digest(out, out=dig, stream=stream).sum(dim=0))
+
+    submit_full = lambda k, out: eng.submit_multi(epks, emsg, esig, witness=out, result=ress[k % 2])
+    drive(eng, co, outs, submit_full, consume_tensor)
+    ref = acc.clone()
+    acc.zero_()
+    dt, _ = timed(lambda: drive(eng, st, outs, submit_full, consume_tensor))
+    # every step has the same inputs: the digest sum of the warm-up's `co` steps and of the `st` timed steps are co x D and st x D (mod 2^64)
+    same = all((int(a) * co - int(r) * st) % (1 << 64) == 0 for a, r in zip(acc.cpu().tolist(), ref.cpu().tolist())) and bool(ref.abs().sum().item() != 0)
+    print(json.dumps({"workload": "configs[3] through the grouped engine in CONSUMER mode: one signature over %d pairs, %d instances per step, %d steps per group, ring of 2 tensors, "
+                                  "blsw_witness_digest reads every tensor before it may be overwritten" % (Kp, ne, co),
+                      "instances": ne * st, "pairs": Kp * ne * st, "seconds": dt, "value": ne * st / dt, "unit": "instances/s", "pairs_per_s": Kp * ne * st / dt,
+                      "hbm_GBps_written_plus_read": 2 * ne * st * eng.n_witness * 48 / dt / 1e9,
+                      "digest_sums_consistent": same}))
+    del outs
+    torch.cuda.empty_cache()
+    if eng.n * Kp % 64 == 0:
+        cb = eng.compact_bytes()
+        cbufs = list(eng.new_compact_buffer(4))
+        wit = eng.new_witness_tensor()
+        submit_c = lambda k, out: eng.submit_multi_compact(epks, emsg, esig, out, result=ress[k % 2])
+
+        def consume_compact(s0, out, stream):
+            eng.expand_compact(out, wit, stream=stream)
+            with torch.cuda.stream(stream):
+                acc.add_(pkg.witness_digest(wit, out=dig, stream=stream).sum(dim=0))
+
+        for label, consume in (("compact form only (no expansion): the sender's side of a sharded run", lambda s0, out, stream: None),
+                               ("compact form, expanded on the 'receiver' (blsw_engine_expand_compact) and digested", consume_compact)):
+            drive(eng, co, cbufs, submit_c, consume)
+            acc.zero_()
+            dt, _ = timed(lambda: drive(eng, st, cbufs, submit_c, consume))
+            print(json.dumps({"workload": "configs[3], consumer-mode engine, steps leave in %s: %d pairs, %d instances per step, ring of 4 compact buffers" % (label, Kp, ne),
+                              "instances": ne * st, "pairs": Kp * ne * st, "seconds": dt, "value": ne * st / dt, "unit": "instances/s", "pairs_per_s": Kp * ne * st / dt,
+                              "wire_bytes_per_instance": cb / ne, "vector_bytes_per_instance": eng.n_witness * 48}))
+    eng.close()
 
 
 if __name__ == "__main__":

@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
-"""Generates bls-verify-gadget_amd/csrc/team_tables.cuh: the op tables of the 6-lanes-per-instance pairing kernel.
+"""Generates bls-verify-gadget_amd/csrc/team_tables.hpp: the op tables of the 6-lanes-per-instance pairing kernel.
 
 An Fp12 value is DISTRIBUTED over the six lanes of a team: lane j owns the Fp2 coefficient j of
 (c0.c0, c0.c1, c0.c2, c1.c0, c1.c1, c1.c2). A tower operation (Fp12 mul / square / cyclotomic square / mul_by_014 ...)
 is a set of independent Fp2 products ("tasks", scheduled 6 per round) whose operands are small linear combinations of
 coefficients published in LDS, followed by a linear recombination per output coefficient. This script expands the
-formulas of tower.cuh (= ark-r1cs-std's allocation order) symbolically and emits, per op:
+formulas of tower.hpp (= ark-r1cs-std's allocation order) symbolically and emits, per op:
   task[round][lane] = {kind, result slot, witness offset, operand A, operand B}     out[lane] = linear combination
 A linear combination is  (sum Lp - sum Ln) + xi * (sum Mp - sum Mn)  over LDS slots, xi = 1 + u.
-Witness offsets follow the order in which the single-lane code (tower.cuh) emits them; tests pin both against the oracle.
+Witness offsets follow the order in which the single-lane code (tower.hpp) emits them; tests pin both against the oracle.
 """
 import os
 import sys
@@ -136,7 +136,7 @@ class Op:
         return rounds
 
 
-# ---- tower formulas on LC-valued coefficients (tower.cuh)
+# ---- tower formulas on LC-valued coefficients (tower.hpp)
 def fp6_add(a, b):
     return [x + y for x, y in zip(a, b)]
 
@@ -255,7 +255,7 @@ def build_ops():
     c1 = op.mul2b(LC.slot(XH1), LC.slot(XPX))
     ops.append(finish(op, fp12_mul_by_014_w(op, a, LC.slot(XH0), c1, LC.slot(XYV), True)))
 
-    # ---- G2 points, homogeneous projective (x, y, z) on lanes 0..2 (curve.cuh: proj_double_w / proj_add_w<0> over Fp2;
+    # ---- G2 points, homogeneous projective (x, y, z) on lanes 0..2 (curve.hpp: proj_double_w / proj_add_w<0> over Fp2;
     # 3b = 12 xi). IN0 = p (slots 0..2), IN1 = q (slots 6..8).
     px, py, pz = LC.slot(IN0 + 0), LC.slot(IN0 + 1), LC.slot(IN0 + 2)
     qx, qy, qz = LC.slot(IN1 + 0), LC.slot(IN1 + 1), LC.slot(IN1 + 2)
@@ -329,7 +329,7 @@ def main():
     ops = build_ops()
     out = []
     w = out.append
-    w("// GENERATED by tools/gen_team_tables.py — do not edit. Op tables of the 6-lanes-per-instance pairing kernel (team.cuh).")
+    w("// GENERATED by tools/gen_team_tables.py — do not edit. Op tables of the 6-lanes-per-instance pairing kernel (team.hpp).")
     w("#pragma once")
     w("#include <stdint.h>")
     w("namespace blsw {")
@@ -366,7 +366,7 @@ def main():
         summary.append("%s: %d tasks in %d rounds %s, %d witnesses, longest output %d terms" % (
             op.name, len(op.tasks), len(rounds), [len(r) for r in rounds], op.woff, max(sum(map(len, o.lists())) for o in op.out)))
     w("}  // namespace blsw")
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bls-verify-gadget_amd", "csrc", "team_tables.cuh")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bls-verify-gadget_amd", "csrc", "team_tables.hpp")
     if len(sys.argv) > 1:
         path = sys.argv[1]
     with open(path, "w") as f:
