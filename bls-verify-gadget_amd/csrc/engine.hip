@@ -830,7 +830,8 @@ int blsw_witness_digest(const uint64_t* d_witness, uint64_t witness_stride, uint
     DeviceGuard guard(stream_device(st));
     if (hip_ok(hipMemsetAsync(d_digest, 0, n * 2 * sizeof(uint64_t), st), "memset")) return BLSW_ERR_HIP;
     const uint64_t n_words = (uint64_t)n_witness * 6, per_block = 2ull * 256 * BLSW_DIGEST_ITERS;
-    dim3 grid((unsigned)((n_words + per_block - 1) / per_block), (unsigned)n);
+    const uint64_t chunks = (n_words + per_block - 1) / per_block;
+    dim3 grid((unsigned)(chunks < BLSW_DIGEST_MAX_BLOCKS ? chunks : BLSW_DIGEST_MAX_BLOCKS), (unsigned)n);  // a workgroup walks its instance's chunks with stride grid.x
     hipLaunchKernelGGL(k_digest, grid, dim3(256), 0, st, d_witness, witness_stride, n_words, d_digest);
     return hip_ok(hipGetLastError(), "launch");
 }

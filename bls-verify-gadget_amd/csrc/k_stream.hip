@@ -265,8 +265,7 @@ __global__ __launch_bounds__(256) void k_digest(const uint64_t* __restrict__ w, 
     const uint64_t inst = blockIdx.y;
     const u32x4* src = reinterpret_cast<const u32x4*>(w + inst * stride * 6);
     const uint32_t n_pieces = (uint32_t)(n_words / 2);  // n_witness * 6 is even
-    const uint32_t q0 = blockIdx.x * (BLSW_DIGEST_ITERS * 256) + threadIdx.x;
-    uint32_t key = (q0 + 1) * BLSW_DIGEST_KEY;
+    uint32_t key = 0;
     uint64_t d0 = 0;
     uint32_t lo = 0, hi = 0;
     auto piece = [&](const u32x4& v) {
@@ -276,20 +275,28 @@ __global__ __launch_bounds__(256) void k_digest(const uint64_t* __restrict__ w, 
         hi += (v.y ^ key) + (v.w ^ ~key);
         key += 256 * BLSW_DIGEST_KEY;
     };
-    if (blockIdx.x * (BLSW_DIGEST_ITERS * 256) + BLSW_DIGEST_ITERS * 256 <= n_pieces) {  // whole workgroup in range
+    // a workgroup walks chunks blockIdx.x, blockIdx.x + gridDim.x, ... of its instance (the host caps gridDim.x: a 4.19 GB vector of the
+    // N+1-pair circuit would otherwise end in 64 k atomic triples on the same three addresses)
+    const uint32_t n_chunks = (n_pieces + BLSW_DIGEST_ITERS * 256 - 1) / (BLSW_DIGEST_ITERS * 256);
 #pragma unroll 1
-        for (int it = 0; it < BLSW_DIGEST_ITERS; it += 4) {
-            u32x4 v[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) v[k] = __builtin_nontemporal_load(&src[q0 + (it + k) * 256]);
-#pragma unroll
-            for (int k = 0; k < 4; k++) piece(v[k]);
-        }
-    } else {
-        uint32_t q = q0;
+    for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        const uint32_t q0 = chunk * (BLSW_DIGEST_ITERS * 256) + threadIdx.x;
+        key = (q0 + 1) * BLSW_DIGEST_KEY;
+        if (chunk * (BLSW_DIGEST_ITERS * 256) + BLSW_DIGEST_ITERS * 256 <= n_pieces) {  // whole chunk in range
 #pragma unroll 1
-        for (int it = 0; it < BLSW_DIGEST_ITERS; it++, q += 256) {
-            if (q < n_pieces) piece(src[q]);  // (the key advances only with the pieces read: it is not used afterwards)
+            for (int it = 0; it < BLSW_DIGEST_ITERS; it += 4) {
+                u32x4 v[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) v[k] = __builtin_nontemporal_load(&src[q0 + (it + k) * 256]);
+#pragma unroll
+                for (int k = 0; k < 4; k++) piece(v[k]);
+            }
+        } else {
+            uint32_t q = q0;
+#pragma unroll 1
+            for (int it = 0; it < BLSW_DIGEST_ITERS; it++, q += 256) {
+                if (q < n_pieces) piece(src[q]);
+            }
         }
     }
     // wave reduction, workgroup reduction through LDS, then one atomic triple per workgroup (the halves of d[1] are sums mod 2^32)

@@ -318,6 +318,7 @@ struct ExpandArgs {
 #define BLSW_PLACE_ITERS 8
 #endif
 #define BLSW_DIGEST_ITERS 16
+#define BLSW_DIGEST_MAX_BLOCKS 4096  // workgroups per instance of k_digest (a single-key vector has 2 073 chunks)
 #define BLSW_DIGEST_KEY 0x9E3779B1u  // odd (golden ratio): key_q = (q + 1) * KEY mod 2^32 is a bijection of q
 #define BLSW_DIGEST_A 0x85EBCA6Bu
 
