@@ -42,7 +42,7 @@ FPMUL_PER_INV = 570
 # what the kernels execute instead of a Fermat inversion: one safegcd inversion = 26.9 Fp-product times (blsw_microbench 2 / 1);
 # 636 of the 940 cofactor-chain inversions are shared with a neighbour (Montgomery's trick: +9 products each, -1 inversion)
 FPMUL_PER_INV_EXECUTED = 27
-TRAFFIC_FILES = ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json")
+TRAFFIC_FILES = ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json")
 
 
 def parse_args():

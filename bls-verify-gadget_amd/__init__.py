@@ -497,6 +497,41 @@ class BlsSignatureVerifyGadget:
         return self.result
 
 
+def verify_mixed_lengths(parameters, public_key, messages, signature, want_witness=True, **options):
+    """`verify` for a batch whose messages differ in LENGTH (constraints.rs:90-95 takes any `&[UInt8]` per call; the circuit — its SHA-256
+    block count, hence n_witness and the matrices — is a function of the length, so a batch shares a layout only per length): the
+    instances are grouped by message length and each group goes through its own gadget (one engine per distinct length).
+    public_key.xy [n, 12], signature.xy [n, 24] cuda tensors; messages: a sequence of n bytes-like objects or 1-D uint8 tensors.
+    Returns (result int32 [n], witnesses): witnesses[i] is instance i's [n_witness(len_i), 6] int64 vector (a view of its group's tensor),
+    or None with want_witness=False. layout(len(messages[i])) / matrices(len(messages[i])) describe instance i's system."""
+    torch = _require_cuda()
+    assert isinstance(parameters, ParametersVar)
+    pk, sig = public_key.xy, signature.xy
+    n = pk.shape[0]
+    if len(messages) != n or sig.shape[0] != n:
+        raise BlswError("verify_mixed_lengths: one message and one signature per key")
+    dev = pk.device
+    groups = {}
+    for i, m in enumerate(messages):
+        b = bytes(m.cpu().numpy().tobytes()) if hasattr(m, "cpu") else bytes(m)
+        groups.setdefault(len(b), []).append((i, b))
+    result = torch.empty(n, dtype=torch.int32, device=dev)
+    witnesses = [None] * n
+    for msg_len, items in sorted(groups.items()):
+        idx = torch.tensor([i for i, _ in items], dtype=torch.long, device=dev)
+        msg = torch.frombuffer(bytearray(b"".join(b for _, b in items)), dtype=torch.uint8).reshape(len(items), msg_len).to(dev) if msg_len else \
+            torch.empty((len(items), 0), dtype=torch.uint8, device=dev)
+        g = BlsSignatureVerifyGadget(len(items), msg_len, device=dev, want_witness=want_witness, **options)
+        res = g.verify(parameters, PublicKeyVar.new_witness(pk[idx].contiguous()), msg, SignatureVar.new_witness(sig[idx].contiguous()))
+        torch.cuda.synchronize(dev)
+        result[idx] = res
+        if want_witness:
+            for k, (i, _) in enumerate(items):
+                witnesses[i] = g.witness[k]
+        g.engine.close()
+    return result, (witnesses if want_witness else None)
+
+
 ST_OK, ST_BAD_ENCODING, ST_NOT_ON_CURVE, ST_NOT_IN_SUBGROUP, ST_IDENTITY = 0, 1, 2, 3, 4
 
 

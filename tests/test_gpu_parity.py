@@ -779,6 +779,29 @@ def test_engine_bench_shape_against_oracle(pkg, oracle):
     eng.close()
 
 
+def test_verify_mixed_message_lengths(pkg, oracle):
+    """verify_mixed_lengths: one batch whose messages have lengths 0, 3, 32, 32, 119, 120, 32 (constraints.rs:90-95 takes any &[UInt8]): grouped by
+    length, one engine per length; every instance's result and whole witness vector against the oracle, in the caller's order."""
+    import torch
+
+    lens = [0, 3, 32, 32, 119, 120, 32]
+    sks = [0x1234567 + 977 * i for i in range(len(lens))]
+    msgs = [bytes((37 * i + 11 * j) & 0xFF for j in range(L)) for i, L in enumerate(lens)]
+    pk = np.stack([oracle.g1_decompress(oracle.sk_to_pk(sk))[1] for sk in sks])
+    sig = np.stack([oracle.g2_decompress(oracle.sign(sk, m))[1] for sk, m in zip(sks, msgs)])
+    sent = list(msgs)
+    sent[3] = bytes([sent[3][0] ^ 1]) + sent[3][1:]  # a tampered 32-byte message: false
+    dev = torch.device("cuda:0")
+    res, wit = pkg.verify_mixed_lengths(pkg.ParametersVar(), pkg.PublicKeyVar.new_witness(torch.from_numpy(pk.view(np.int64)).to(dev)), sent,
+                                        pkg.SignatureVar.new_witness(torch.from_numpy(sig.view(np.int64)).to(dev)))
+    got = res.cpu().numpy().astype(bool)
+    assert got.tolist() == [True, True, True, False, True, True, True]
+    for i, m in enumerate(sent):
+        nw, _, r, ow = oracle.witness(pk[i], m, sig[i])
+        assert r == bool(got[i]) and tuple(wit[i].shape) == (nw, 6) and nw == pkg.layout(len(m))["n_witness"]
+        assert np.array_equal(wit[i].cpu().numpy().view(np.uint64), ow), "instance %d (message length %d)" % (i, len(m))
+
+
 def test_direct_calls_refuse_batches_beyond_free_hbm(pkg):
     """verify_multi / aggregate_verify / the gadget allocate n witness vectors per call (4.19 GB each at 128 pairs): a batch beyond the free
     HBM is refused with a BlswError that says so, before anything is allocated (round 3: torch.OutOfMemoryError half-way)."""
