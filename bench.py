@@ -30,8 +30,13 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# No runtime environment is required: with the six-lanes-per-instance pairing kernel the largest stack of any kernel is
-# 4.6 KB per lane, below the size at which ROCr starts re-allocating scratch for every dispatch.
+# The library needs no runtime environment. This harness sets ONE variable for its own process, before HIP is initialised: the runtime backs the
+# streams of each priority level with GPU_MAX_HW_QUEUES (default 4) hardware queues, and streams that share a queue serialise. One rank has the
+# null stream + up to three group buffers' main streams at normal priority; the all-gather legs add a communication stream and the process
+# group's own RCCL stream: with four queues two of them share one, and a marker behind a waiting command starts the next launch group ~70 ms
+# late (profiles/r04_consumer_timeline.txt). Eight queues per level remove the aliasing; measured neutral to +1 % at N = 1
+# (profiles/r04_consumer_probe.txt, block 3). A value the caller has set is kept.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured float4 copy)
 # algorithmic field work per instance, from the oracle's op counter on the reference gadget case
@@ -55,6 +60,7 @@ def parse_args():
     ap.add_argument("--buffers", type=int, default=3, help="launch groups in flight (each owns streams + a workspace slice)")
     ap.add_argument("--outputs", type=int, default=2, help="ring of output witness tensors (34 MB x batch each)")
     ap.add_argument("--mem-frac", type=float, default=0.68, help="share of the free HBM the engine workspace and the output ring may take")
+    ap.add_argument("--expand-variant", type=int, default=-1, help="options.expand_variant of the timed engine (-1 = the library's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=256, help="instances of the batch timed on the host (all cores, and one thread)")
     ap.add_argument("--consumer-shard", type=int, default=8192,
@@ -380,7 +386,10 @@ def main():
     # leave >= 25 % of HBM to the runtime (per-queue scratch = stacks of the chain kernels)
     while buffers > 1 and pkg.engine_workspace_bytes(n, 32, coalesce, buffers) + n_out * out_bytes > args.mem_frac * free_b:
         buffers -= 1
-    eng = pkg.WitnessEngine(n, 32, max_steps=coalesce, device=dev, n_buffers=buffers)
+    eng_opts = {}
+    if args.expand_variant >= 0:
+        eng_opts["expand_variant"] = args.expand_variant
+    eng = pkg.WitnessEngine(n, 32, max_steps=coalesce, device=dev, n_buffers=buffers, **eng_opts)
     outs = [eng.new_witness_tensor() for _ in range(n_out)]
     results = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(n_out)]
     torch.cuda.synchronize()

@@ -484,7 +484,7 @@ int blsw_engine_create_ex(blsw_engine_t** out, uint64_t n, uint32_t msg_len, uin
     // place while the chains run and could not honour a held output
     if (options->consumer_mode > 1 || (options->consumer_mode == 1 && max_steps == 1 && n_buffers == 1)) return BLSW_ERR_ARG;
     if (options->pairing_mode > 1 || options->g2_mode > 1 || (options->g2_mode == 1 && options->pairing_mode != 0) || options->expand_store > 3 ||
-        options->prio_mode > 2 || options->group_ramp > 1 || options->output_form > 1 || options->chain_variant > 2 || options->cofactor_mode > 2 || (options->expand_variant & 0xff) > 9 || (options->expand_variant >> 9) || options->n_keys > 65535 ||
+        options->prio_mode > 2 || options->group_ramp > 1 || options->output_form > 1 || options->chain_variant > 2 || options->cofactor_mode > 2 || (options->expand_variant & 0xff) > 12 || (options->expand_variant >> 9) || options->n_keys > 65535 ||
         (options->n_keys && options->g2_mode) || options->n_pairs > 4096)
         return BLSW_ERR_ARG;
     // N+1-pair product (options.n_pairs = K > 1): a staged engine with the default kernel modes; its expansion launch has one row of

@@ -152,7 +152,67 @@ __global__ __launch_bounds__(384) void k_sha_expand_s(ExpandArgs a) {
         if (whole || e0 + (THREADS / 3) * k < a.sha_bits) expand_store<0>(dst + (uint64_t)k * THREADS, make_uint4(rc.x & m, rc.y & m, rc.z & m, rc.w & m));
     }
 }
-// variant: low byte 0..9 = geometry, bit 8 = raised wave priority; store: 0 plain, 1 nontemporal, 2 sc1, 3 sc0 sc1 (variant 0 only)
+// variant 10: the geometry of variant 0 with a LIGHT instruction stream — 5 vector instructions per 16-byte store instead of ~20 (profiles/r04_digest.txt:
+// 6.2 x 10^8 VALU wave-instructions per launch, a third of what a step's chain kernels issue). Piece index of a thread = workgroup base + pt + 384 k, so
+//   * the store address is a scalar base (advanced per iteration by the scalar unit) + a 32-bit lane offset pt * 16: global_store ... saddr, no vector add;
+//   * a wave covers 22 consecutive elements: the scalar unit loads the one or two bit words, shifts the pair so that the wave's first element is bit 0
+//     (the shift is a loop invariant: the element advances by 128 per iteration), and a lane extracts its bit with ONE v_bfe_i32 at a fixed index.
+// store to (scalar base + 32-bit lane offset), saddr form. Inline assembly, because instruction selection folds the eight bases of a thread into vector
+// adds + immediate offsets otherwise; the five wait states gfx9 wants between a scalar-unit write of an SGPR and a vector-memory instruction that reads it
+// are part of the statement (the compiler's hazard recogniser does not look into asm: without them the store used a stale base whenever the scheduler
+// had put the scalar add right in front of it — caught by test_expansion_geometries_bit_exact), and so are the two after it that a
+// store of more than 64 bits wants before a vector instruction may overwrite its data registers
+__device__ __forceinline__ void expand_store_s(uint64_t sbase, uint32_t voff, const u32x4& v) {
+    asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+}
+template <int ITERS>
+__global__ __launch_bounds__(384) void k_sha_expand_l(ExpandArgs a) {
+    constexpr int THREADS = 384;
+    uint4* out;
+    const uint32_t* b;
+    expand_locate(a, out, b);
+    const uint32_t n_pieces = a.sha_bits * 3;
+    const uint32_t P0 = (16 - (uint32_t)((reinterpret_cast<uintptr_t>(out) >> 4) % 16)) % 16;
+    expand_head<0>(out, b, P0, n_pieces, a.canonical);
+    const uint32_t pt = P0 + threadIdx.x, c = pt % 3;
+    const uint32_t e_blk = blockIdx.x * ((THREADS / 3) * ITERS);
+    const uint32_t e0 = e_blk + pt / 3;
+    const uint4 rc = expand_column(c, a.canonical);
+    const uint32_t e_first = __builtin_amdgcn_readfirstlane(e0);  // the wave's first element
+    const uint32_t idx = e0 - e_first;                            // 0 .. 21: the lane's bit in the wave's window
+    const uint32_t sh = e_first & 31, wu = e_first >> 5, w_last = (uint32_t)a.sha_words - 1;
+    blsw_cptr bc = (blsw_cptr)(uintptr_t)b;
+    auto window = [&](int k) {  // bits of the wave's 22 elements of iteration k, the first one in bit 0 (scalar loads, scalar shift)
+        uint32_t w = wu + k * (THREADS / 96), w1 = w + 1;
+        w = w < w_last ? w : w_last;  // (the last workgroups of an instance reach beyond its stream: clamped, those pieces are never stored)
+        w1 = w1 < w_last ? w1 : w_last;
+        const uint32_t lo = bc[(uint64_t)(w / BLSW_BITS_CHUNK_WORDS) * (64 * BLSW_BITS_CHUNK_WORDS) + (w % BLSW_BITS_CHUNK_WORDS)];
+        const uint32_t hi = bc[(uint64_t)(w1 / BLSW_BITS_CHUNK_WORDS) * (64 * BLSW_BITS_CHUNK_WORDS) + (w1 % BLSW_BITS_CHUNK_WORDS)];
+        return (uint32_t)((((uint64_t)hi << 32) | lo) >> sh);
+    };
+    const bool whole = e_blk + (P0 + THREADS - 1) / 3 + (THREADS / 3) * (ITERS - 1) < a.sha_bits;
+    const uint64_t sbase = reinterpret_cast<uint64_t>(out) + (uint64_t)e_blk * 48;  // scalar: first byte of the workgroup's pieces
+    const uint32_t voff = pt * 16;
+    if (whole) {  // all but the last one or two workgroups of an instance: every window first (one scalar-load latency per wave), then the stores back to back
+        uint32_t win[ITERS];  // scalar registers
+#pragma unroll
+        for (int k = 0; k < ITERS; k++) win[k] = window(k);
+#pragma unroll
+        for (int k = 0; k < ITERS; k++) {
+            const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe(win[k], idx, 1);
+            const u32x4 v = {rc.x & m, rc.y & m, rc.z & m, rc.w & m};
+            expand_store_s(sbase + (uint64_t)k * (THREADS * 16), voff, v);
+        }
+        return;
+    }
+#pragma unroll 1
+    for (int k = 0; k < ITERS; k++) {
+        const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe(window(k), idx, 1);
+        const u32x4 v = {rc.x & m, rc.y & m, rc.z & m, rc.w & m};
+        if (e0 + (THREADS / 3) * k < a.sha_bits) expand_store_s(sbase + (uint64_t)k * (THREADS * 16), voff, v);
+    }
+}
+// variant: low byte 0..12 = geometry, bit 8 = raised wave priority; store: 0 plain, 1 nontemporal, 2 sc1, 3 sc0 sc1 (variant 0 only)
 void launch_expand(uint32_t variant, uint32_t store, unsigned lds, hipStream_t st, ExpandArgs a, unsigned n_y) {
     a.prio = (variant >> 8) & 1;
     const uint32_t n_pieces = a.sha_bits * 3;
@@ -163,6 +223,9 @@ void launch_expand(uint32_t variant, uint32_t store, unsigned lds, hipStream_t s
         case 7: hipLaunchKernelGGL((k_sha_expand_chunk<1024, 0>), grid(1024), dim3(1024), lds, st, a); break;
         case 8: hipLaunchKernelGGL(k_sha_expand_s<8>, grid(384 * 8), dim3(384), lds, st, a); break;
         case 9: hipLaunchKernelGGL(k_sha_expand_s<4>, grid(384 * 4), dim3(384), lds, st, a); break;
+        case 10: hipLaunchKernelGGL(k_sha_expand_l<8>, grid(384 * 8), dim3(384), lds, st, a); break;
+        case 11: hipLaunchKernelGGL(k_sha_expand_l<16>, grid(384 * 16), dim3(384), lds, st, a); break;
+        case 12: hipLaunchKernelGGL(k_sha_expand_l<32>, grid(384 * 32), dim3(384), lds, st, a); break;
         case 2: hipLaunchKernelGGL((k_sha_expand<768, 8, 256, 0>), grid(768 * 8), dim3(768), lds, st, a); break;
         case 3: hipLaunchKernelGGL((k_sha_expand<768, 4, 256, 0>), grid(768 * 4), dim3(768), lds, st, a); break;
         case 4: hipLaunchKernelGGL((k_sha_expand<768, 16, 256, 0>), grid(768 * 16), dim3(768), lds, st, a); break;

@@ -779,6 +779,52 @@ def test_engine_bench_shape_against_oracle(pkg, oracle):
     eng.close()
 
 
+@pytest.mark.parametrize("msg_len", [32, 3])
+def test_expansion_geometries_bit_exact(pkg, oracle, msg_len):
+    """Every store geometry of the SHA expansion (options.expand_variant 1 .. 12: one piece per thread in 4 / 8 / 16 KiB chunks, 768-thread variants, scalar
+    bit words, the light instruction stream at 8 / 16 / 32 pieces per thread) and the canonical output form through the light kernel write the tensors
+    of the default engine, byte for byte; one instance per message length against the oracle. 70 instances (a ragged tile), two steps, two message lengths (different segment alignments and tail workgroups)."""
+    import torch
+
+    n = 70
+    pk, _, _, _ = synth.make_batch(oracle, n)
+    rng = np.random.default_rng(5 + msg_len)
+    msg = rng.integers(0, 256, size=(n, msg_len), dtype=np.uint8)
+    dev = torch.device("cuda:0")
+    # signatures need not verify: the witness bytes are what is compared (every 16th instance of make_batch is tampered anyway)
+    _, _, sig, _ = synth.make_batch(oracle, n)
+    d_pk, d_sig, d_msg = (torch.from_numpy(pk.view(np.int64)).to(dev), torch.from_numpy(sig.view(np.int64)).to(dev), torch.from_numpy(msg).to(dev))
+    side = torch.cuda.Stream(device=dev)
+
+    def run(**opts):
+        eng = pkg.WitnessEngine(n, msg_len, max_steps=2, device=dev, n_buffers=2, **opts)
+        outs = [eng.new_witness_tensor() for _ in range(2)]
+        res = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(2)]
+        for o in outs:
+            o.fill_(-1)
+        torch.cuda.synchronize()
+        for k in range(2):
+            eng.submit(d_pk, d_sig, d_msg, witness=outs[k], result=res[k], stream=side)
+        eng.flush(stream=side)
+        torch.cuda.synchronize()
+        eng.close()
+        return outs, res
+
+    ref, ref_res = run()
+    assert torch.equal(ref[0], ref[1])
+    nw, _, r, ow = oracle.witness(pk[69], msg[69].tobytes(), sig[69])
+    assert nw == ref[0].shape[1] and np.array_equal(ref[0][69].cpu().numpy().view(np.uint64), ow) and bool(ref_res[0][69].item()) == r
+    for variant in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12):
+        got, res = run(expand_variant=variant)
+        for k in range(2):
+            assert torch.equal(got[k], ref[k]), "expand_variant %d, step %d" % (variant, k)
+            assert torch.equal(res[k], ref_res[k])
+        del got
+    canon_ref, _ = run(output_form=1)
+    canon, _ = run(output_form=1, expand_variant=10)
+    assert torch.equal(canon[0], canon_ref[0]) and not torch.equal(canon_ref[0], ref[0])
+
+
 def test_verify_mixed_message_lengths(pkg, oracle):
     """verify_mixed_lengths: one batch whose messages have lengths 0, 3, 32, 32, 119, 120, 32 (constraints.rs:90-95 takes any &[UInt8]): grouped by
     length, one engine per length; every instance's result and whole witness vector against the oracle, in the caller's order."""
