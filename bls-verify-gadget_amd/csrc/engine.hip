@@ -318,7 +318,12 @@ static int launch_group(blsw_engine* e) {
     g.chain_prio = e->opt.prio_mode == 0;
     const unsigned g1 = (unsigned)((g.N + 63) / 64), g2 = (unsigned)((2 * g.N + 63) / 64);
     const unsigned gt = (unsigned)((g.N + BLSW_TEAMS_PER_WAVE - 1) / BLSW_TEAMS_PER_WAVE);
-    const ChainKernels ck = chain_kernels(e->chains_inlined);
+    // which compilation of the chain kernels: the engine's (options.chain_variant), except that with the default variant a SMALL group (at most 8 192
+    // lanes) that starts a pipeline (the first two after creation / a flush) takes the inlined one — little runs beside it whose registers it could
+    // starve, and its latency is what a consumer waits for before the first tensors exist (8 192-instance consumer-mode shard: +3-5 %,
+    // profiles/r04_consumer_probe.txt block 4; a steady stream of large groups loses 3 % with it, hence the conditions)
+    const bool cold_small = e->opt.chain_variant == 0 && e->staged && e->ramp_pos < 2 && g.N <= BLSW_COFACTOR_CHUNKED_MAX_LANES;
+    const ChainKernels ck = chain_kernels(e->chains_inlined || cold_small);
     hipStream_t st = b.st[0];
     // inputs of every step are ready once its submitting stream reached the point of the submit
     for (uint32_t s = 0; s < steps; s++) hipStreamWaitEvent(st, b.ev_in[s], 0);

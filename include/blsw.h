@@ -136,8 +136,9 @@ typedef struct {
                               engine's option */
     uint32_t chain_variant; /* which compilation of the one-instance-per-lane chain kernels: 0 (default) = out of line in the grouped
                               engine (they leave registers to the streaming kernels that share their SIMDs), inlined in direct mode
-                              (max_steps == 1 and n_buffers == 1: shorter under load, the whole register file); 1 = out of line;
-                              2 = inlined. Same witnesses either way. */
+                              (max_steps == 1 and n_buffers == 1: shorter under load, the whole register file) and for a small launch
+                              group (at most 8 192 lanes) that starts a pipeline — the first two after creation / a flush — whose
+                              latency is what a consumer waits for; 1 = out of line; 2 = inlined. Same witnesses either way. */
     uint32_t n_pairs;      /* 0 / 1 = the single-key circuit; K > 1 = the N+1-pair product (blsw_layout_multi): one signature over K (pk, msg)
                               pairs per instance, batches through blsw_engine_submit_multi. Staged engines only (max_steps > 1 or
                               n_buffers > 1), default kernel modes, n * K <= 65535. Compact wire form (blsw_engine_submit_multi_compact,
