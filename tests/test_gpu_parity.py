@@ -321,6 +321,36 @@ def test_hash_to_g2_batch_ragged_multi_wave(pkg, oracle, msg_len):
     assert bad == [], bad[:8]
 
 
+def test_hash_to_g2_one_million_messages_sampled(pkg, oracle):
+    """BASELINE configs[4] at its full size: msg_i = SHA-256(seed || "h" || i) for i < 2^20, message 0 replaced by the 32 zero bytes of
+    bls.rs:645, hashed in four chunks of 262 144. A fixed-stride sample of 64 outputs (every chunk, both ends) against the oracle, output 0 against the
+    reference's literal, and a size-independent property of the whole batch: the second half re-hashed after a permutation equals the permuted outputs."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+
+    workload = importlib.import_module("bls-verify-gadget_amd.workload")
+    n, chunk = 1 << 20, 1 << 18
+    dev = torch.device("cuda:0")
+    msgs = workload.messages(0x5EED, 0, n, tag=b"h")
+    msgs[0] = 0
+    d = torch.from_numpy(msgs).to(dev)
+    out = torch.empty((n, 24), dtype=torch.int64, device=dev)
+    for c0 in range(0, n, chunk):
+        pkg.hash_to_g2_batch(d[c0:c0 + chunk], out=out[c0:c0 + chunk])
+    torch.cuda.synchronize()
+    sample = sorted(set([0, 1, chunk - 1, chunk, n - 1] + list(range(7, n, n // 59))))
+    got = out[sample].cpu().numpy().view(np.uint64)
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        want = list(ex.map(lambda i: oracle.hash_to_g2(msgs[i].tobytes()), sample))
+    bad = [i for k, i in enumerate(sample) if not np.array_equal(want[k][1], got[k])]
+    assert bad == [], bad[:8]
+    assert want[0][0].hex() == LIT["hash_to_g2"]["compressed"] and bytes(msgs[0]).hex() == LIT["hash_to_g2"]["message"]  # bls.rs:645-651
+    perm = torch.randperm(chunk, device=dev, generator=torch.Generator(device=dev).manual_seed(7))
+    again = pkg.hash_to_g2_batch(d[n - chunk:][perm].contiguous())
+    torch.cuda.synchronize()
+    assert torch.equal(again, out[n - chunk:][perm])
+
+
 def test_sign_batch_ragged_multi_wave(pkg, oracle):
     """blsw_sign_batch over several waves (n = 200): sig = sk * H(m) through the four-digit psi ladder and pk = sk * g1 through the
     fixed-base windows (vsign.hpp), scalars with special digit patterns and random ones, against the oracle's signer."""
