@@ -8,10 +8,11 @@ template <int NT>
 __device__ __forceinline__ void expand_store(uint4* dst, const uint4& v) {
     if (NT == 2) {
         u32x4 vv = {v.x, v.y, v.z, v.w};
-        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(vv) : "memory");
+        // (two wait states after a store of more than 64 bits before a vector instruction may overwrite its data: the compiler does not look into asm)
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(vv) : "memory");
     } else if (NT == 3) {
         u32x4 vv = {v.x, v.y, v.z, v.w};
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(vv) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst), "v"(vv) : "memory");
     } else if (NT == 1) {
         __builtin_nontemporal_store(v.x, &dst->x);
         __builtin_nontemporal_store(v.y, &dst->y);

@@ -850,6 +850,10 @@ def test_expansion_geometries_bit_exact(pkg, oracle, msg_len):
             assert torch.equal(got[k], ref[k]), "expand_variant %d, step %d" % (variant, k)
             assert torch.equal(res[k], ref_res[k])
         del got
+    for store in (1, 2, 3):  # nontemporal / sc1 / sc0 sc1 stores of the default geometry
+        got, res = run(expand_store=store)
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), "expand_store %d" % store
+        del got
     canon_ref, _ = run(output_form=1)
     canon, _ = run(output_form=1, expand_variant=10)
     assert torch.equal(canon[0], canon_ref[0]) and not torch.equal(canon_ref[0], ref[0])
