@@ -183,7 +183,7 @@ def allgather_leg(args, pkg, sharding, dist, dev, inputs, lay, world):
     # consumer mode: groups of chains run ahead into the staging, a step is expanded into its ring tensor when the gather has
     # released that tensor's previous user
     group = max(1, min(args.allgather_group, steps // 2))
-    eng = pkg.WitnessEngine(n, 32, max_steps=group, device=dev, n_buffers=max(2, min(3, (steps + group - 1) // group)), consumer_mode=1, group_ramp=1)
+    eng = pkg.WitnessEngine(n, 32, max_steps=group, device=dev, n_buffers=max(2, min(3, (steps + group - 1) // group)), consumer_mode=1)
     outs = [eng.new_witness_tensor() for _ in range(ring)]
     results = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(ring)]
     chunk = max(1, min(args.allgather_chunk, n))
@@ -254,7 +254,7 @@ def allgather_leg_compact(args, pkg, sharding, dist, dev, inputs, lay, world):
     steps = min(args.allgather_steps, args.steps)
     group = max(1, min(args.allgather_group, steps // 2))
     ring = 4  # compact buffers; consumer mode: a step leaves for its buffer when the gather has released the buffer's previous user
-    eng = pkg.WitnessEngine(n, 32, max_steps=group, device=dev, n_buffers=max(2, min(3, (steps + group - 1) // group)), consumer_mode=1, group_ramp=1)
+    eng = pkg.WitnessEngine(n, 32, max_steps=group, device=dev, n_buffers=max(2, min(3, (steps + group - 1) // group)), consumer_mode=1)
     cbufs = eng.new_compact_buffer(ring)
     results = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(ring)]
     wit = eng.new_witness_tensor()

@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256) void k_place_rows(const Fp* __restrict__ rows,
 __global__ __launch_bounds__(256) void k_digest(const uint64_t* __restrict__ w, uint64_t stride, uint64_t n_words, uint64_t* __restrict__ digest) {
     const uint64_t inst = blockIdx.y;
     const u32x4* src = reinterpret_cast<const u32x4*>(w + inst * stride * 6);
-    const uint32_t n_pieces = (uint32_t)(n_words / 2);  // n_witness * 6 is even
+    const uint64_t n_pieces = n_words / 2;  // n_witness * 6 is even; 64-bit: a 4 096-pair vector has 8.4 x 10^9 pieces (the key is (q + 1) * KEY mod 2^32)
     uint32_t key = 0;
     uint64_t d0 = 0;
     uint32_t lo = 0, hi = 0;
@@ -341,12 +341,12 @@ __global__ __launch_bounds__(256) void k_digest(const uint64_t* __restrict__ w, 
     };
     // a workgroup walks chunks blockIdx.x, blockIdx.x + gridDim.x, ... of its instance (the host caps gridDim.x: a 4.19 GB vector of the
     // N+1-pair circuit would otherwise end in 64 k atomic triples on the same three addresses)
-    const uint32_t n_chunks = (n_pieces + BLSW_DIGEST_ITERS * 256 - 1) / (BLSW_DIGEST_ITERS * 256);
+    const uint32_t n_chunks = (uint32_t)((n_pieces + BLSW_DIGEST_ITERS * 256 - 1) / (BLSW_DIGEST_ITERS * 256));
 #pragma unroll 1
     for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
-        const uint32_t q0 = chunk * (BLSW_DIGEST_ITERS * 256) + threadIdx.x;
-        key = (q0 + 1) * BLSW_DIGEST_KEY;
-        if (chunk * (BLSW_DIGEST_ITERS * 256) + BLSW_DIGEST_ITERS * 256 <= n_pieces) {  // whole chunk in range
+        const uint64_t q0 = (uint64_t)chunk * (BLSW_DIGEST_ITERS * 256) + threadIdx.x;
+        key = ((uint32_t)q0 + 1) * BLSW_DIGEST_KEY;
+        if ((uint64_t)chunk * (BLSW_DIGEST_ITERS * 256) + BLSW_DIGEST_ITERS * 256 <= n_pieces) {  // whole chunk in range
 #pragma unroll 1
             for (int it = 0; it < BLSW_DIGEST_ITERS; it += 4) {
                 u32x4 v[4];
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256) void k_digest(const uint64_t* __restrict__ w, 
                 for (int k = 0; k < 4; k++) piece(v[k]);
             }
         } else {
-            uint32_t q = q0;
+            uint64_t q = q0;
 #pragma unroll 1
             for (int it = 0; it < BLSW_DIGEST_ITERS; it++, q += 256) {
                 if (q < n_pieces) piece(src[q]);

@@ -159,14 +159,14 @@ class CompactGatherPipeline:
             self._consume(*prev)
 
 
-def stream_shard(pkg, n_shard=8192, batch=1024, ring=2, rank=0, world=8, buffers=6, seed=0x5EED, device=None, group=None, ramp=True):
+def stream_shard(pkg, n_shard=8192, batch=1024, ring=2, rank=0, world=8, buffers=6, seed=0x5EED, device=None, group=None, ramp=False):
     """One rank's shard of a sharded batch (BASELINE configs[2]: 65 536 instances over 8 GPUs = 8 192 per rank) streamed in
     micro-batches of `batch` instances through a ring of `ring` witness tensors: every tensor is drained by a consumer (the digest
     kernel blsw_witness_digest, standing in for a per-GPU prover or the gather of a micro-batch) before the engine may overwrite it.
     group > 0: consumer-mode engine with groups of `group` steps (chains run ahead into the staging, a step is expanded into its
     ring tensor when the consumer has released that tensor's previous user); group = 0: free-running engine with groups of `ring`.
-    ramp: the consumer-mode engine starts with groups of 2, 4, 8, ... steps (options.group_ramp): nothing can be consumed before the first
-    group's chains end, and a small group (cofactor chain on three lanes) ends first.
+    ramp: the consumer-mode engine starts with groups of 2, 4, 8, ... steps (options.group_ramp); measured useless (a group's chain latency is one
+    wave's latency, 59 ms for 2 x 1024 instances and 63 ms for 4 x 1024: profiles/r04_consumer_probe.txt), off by default.
     Inputs are minted on the GPU before the timed region. -> dict (instances_per_s, digests [n_shard, 2] uint64, ...)."""
     import importlib
     import time
