@@ -23,9 +23,11 @@ def main():
              (32768, None, True), (32768, None, False), (32768, None, True), (32768, 8, True), (32768, 10, True)]
     if len(sys.argv) > 1:
         plans = [tuple(json.loads(a)) for a in sys.argv[1:]]
-    for shard, group, ramp in plans:
-        cs = sharding.stream_shard(pkg, shard, n, 2, 0, 1, device=dev, group=group, ramp=ramp)
-        print(json.dumps({"shard": shard, "group": cs["group_steps"], "ramp": cs["group_ramp"], "instances_per_s": round(cs["instances_per_s"]), "seconds": round(cs["seconds"], 4),
+    for plan in plans:
+        shard, group, ramp = plan[:3]
+        ring = plan[3] if len(plan) > 3 else 2
+        cs = sharding.stream_shard(pkg, shard, n, ring, 0, 1, device=dev, group=group, ramp=ramp)
+        print(json.dumps({"shard": shard, "ring": ring, "group": cs["group_steps"], "ramp": cs["group_ramp"], "instances_per_s": round(cs["instances_per_s"]), "seconds": round(cs["seconds"], 4),
                           "results_ok": cs["results_ok"]}), flush=True)
         del cs
         torch.cuda.empty_cache()
