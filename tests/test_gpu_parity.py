@@ -1353,6 +1353,26 @@ def test_sharded_stream_rehearsal(pkg, oracle):
     assert out["sampled"] >= 82
 
 
+def test_config2_every_shard_of_the_65536_on_one_gpu(pkg, oracle):
+    """BASELINE configs[2] at its full size, rank by rank on the one GPU at hand: the 65 536 instances of SURVEY 8d config 3 as the eight contiguous shards
+    of 8 192 that eight ranks would own (sharding.shard_range), each streamed through a ring of two tensors with the digest kernel as the consumer. All
+    65 536 result booleans against the tamper rule, a fixed-stride sample of every shard (168 instances in all) against the oracle's witness vectors, and
+    a size-independent property of the whole: the shards' digest sets are pairwise different (every rank processed ITS block of the global batch)."""
+    import torch
+
+    rehearsal = importlib.import_module("tools.shard_rehearsal")
+    sums = []
+    for rank in range(8):
+        out = rehearsal.run_shard(pkg, n_shard=8192, batch=1024, ring=2, rank=rank, world=8)
+        assert out["results_ok"] and out["steps"] == 8 and out["first_instance"] == rank * 8192, rank
+        bad = rehearsal.check_sample(pkg, oracle, out, frac=1.0 / 400, threads=8)
+        assert bad == [] and out["sampled"] >= 20, (rank, bad)
+        sums.append(tuple(int(v) for v in out["digests"].sum(axis=0, dtype=np.uint64)))
+        del out
+        torch.cuda.empty_cache()
+    assert len(set(sums)) == 8
+
+
 def test_c_caller_on_the_gpu(pkg, oracle):
     """tests/c_caller (plain C against include/blsw.h): decode -> engine create / submit / flush / wait_step -> digest for the
     reference's gadget case (constraints.rs:337-343); result and witness digest against the oracle."""
