@@ -29,7 +29,7 @@ class blsw_layout_t(ctypes.Structure):
 
 
 class blsw_engine_options_t(ctypes.Structure):
-    _fields_ = [("device", ctypes.c_int32)] + [(n, ctypes.c_uint32) for n in "n_keys pairing_mode g2_mode expand_variant expand_store prio_mode place_lds consumer_mode output_form chain_variant n_pairs cofactor_mode params_mode group_ramp".split()]
+    _fields_ = [("device", ctypes.c_int32)] + [(n, ctypes.c_uint32) for n in "n_keys pairing_mode g2_mode expand_variant expand_store prio_mode place_lds consumer_mode output_form chain_variant n_pairs cofactor_mode params_mode group_ramp latency_mode".split()]
 
 
 class blsw_matrices_info_t(ctypes.Structure):
@@ -185,7 +185,7 @@ def engine_options(**overrides):
         o.pairing_mode = 1
     if env.get("BLSW_G2", "")[:1] == "t" and o.pairing_mode == 0:
         o.g2_mode = 1
-    for var, field in (("BLSW_CHAIN_VARIANT", "chain_variant"), ("BLSW_COFACTOR_MODE", "cofactor_mode"), ("BLSW_EXPAND_VARIANT", "expand_variant"), ("BLSW_EXPAND_NT", "expand_store"), ("BLSW_PRIO_MODE", "prio_mode"), ("BLSW_PLACE_LDS", "place_lds"), ("BLSW_GROUP_RAMP", "group_ramp")):
+    for var, field in (("BLSW_CHAIN_VARIANT", "chain_variant"), ("BLSW_COFACTOR_MODE", "cofactor_mode"), ("BLSW_EXPAND_VARIANT", "expand_variant"), ("BLSW_EXPAND_NT", "expand_store"), ("BLSW_PRIO_MODE", "prio_mode"), ("BLSW_PLACE_LDS", "place_lds"), ("BLSW_GROUP_RAMP", "group_ramp"), ("BLSW_LATENCY_MODE", "latency_mode")):
         if env.get(var):
             setattr(o, field, int(env[var]))
     names = {"pairing_mode": {"team": 0, "lane": 1}, "g2_mode": {"lane": 0, "team": 1}, "params_mode": PARAMS_MODES}

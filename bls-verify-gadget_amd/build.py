@@ -13,12 +13,14 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libblsw.so")
 OBJ = os.path.join(HERE, "build_obj")
 # the shipped translation units, listed: a stray or experimental .hip file in csrc/ is an error, not silently linked
-SOURCES = ["engine.hip", "k_bench.hip", "k_cofactor.hip", "k_g1.hip", "k_g2.hip", "k_map.hip", "k_miller_par.hip", "k_pairing_lane.hip", "k_prepare.hip", "k_sha.hip",
+SOURCES = ["engine.hip", "k_bench.hip", "k_cofactor.hip", "k_cofv.hip", "k_g1.hip", "k_g2.hip", "k_map.hip", "k_miller_par.hip", "k_pairing_lane.hip", "k_prepare.hip", "k_sha.hip",
            "k_sign.hip", "k_stream.hip", "k_team.hip", "k_values.hip"]
 HOST_SOURCES = ["r1cs.cpp"]  # host-only C++: compiled by g++, linked into the same library
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith((".hpp", ".h")))
 # the one-instance-per-lane chain units are compiled a second time with their programs inlined (kernels *_inl: kcommon.hpp)
 DUAL = ["k_sha.hip", "k_g1.hip", "k_g2.hip", "k_map.hip", "k_cofactor.hip", "k_prepare.hip"]
+# the units whose chains have a latency compilation: one chain on the four lanes of a quad (kernels *_q: kcommon.hpp, fp.hpp)
+QUAD = ["k_map.hip", "k_cofv.hip", "k_prepare.hip", "k_g2.hip"]
 HIP_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas"]
 
@@ -64,7 +66,7 @@ def build_tag(defines=()):
     ROCm release), the flags, the defines and the list of doubly compiled units. "std" names the shipped configuration's logs
     (resource_table); the objects carry the hash."""
     hipcc, cxx = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), os.environ.get("CXX", "g++")
-    key = "\n".join([hipcc, _tool_version(hipcc), cxx, _tool_version(cxx), " ".join(HIP_FLAGS), " ".join(HOST_FLAGS), " ".join(defines), " ".join(DUAL)])
+    key = "\n".join([hipcc, _tool_version(hipcc), cxx, _tool_version(cxx), " ".join(HIP_FLAGS), " ".join(HOST_FLAGS), " ".join(defines), " ".join(DUAL), " ".join(QUAD)])
     return hashlib.sha1(key.encode()).hexdigest()[:8]
 
 
@@ -83,9 +85,10 @@ def build(force=False, verbose=False, out=None, defines=()):
     hdr_time = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
     hdr_time = max(hdr_time, os.path.getmtime(os.path.join(HERE, "..", "include", "blsw.h")))
     jobs, objs = [], []
-    units = [(src, ()) for src in HOST_SOURCES + SOURCES] + [(src, ("-DBLSW_KVARIANT_INL",)) for src in DUAL]
+    units = [(src, ()) for src in HOST_SOURCES + SOURCES] + [(src, ("-DBLSW_KVARIANT_INL",)) for src in DUAL] + [(src, ("-DBLSW_KVARIANT_QUAD",)) for src in QUAD]
     for src, extra in units:
-        obj = os.path.join(OBJ, "%s%s.%s.o" % (os.path.splitext(src)[0], "_inl" if extra else "", tag))
+        suffix = "_inl" if "-DBLSW_KVARIANT_INL" in extra else ("_q" if extra else "")
+        obj = os.path.join(OBJ, "%s%s.%s.o" % (os.path.splitext(src)[0], suffix, tag))
         objs.append(obj)
         path = os.path.join(CSRC, src)
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), hdr_time):

@@ -316,14 +316,23 @@ static int launch_group(blsw_engine* e) {
     g.LS = e->LS;
     g.ws = carve(b.base, g.N, e->L, e->staged, e->modes, (uint64_t)steps * e->n);
     g.chain_prio = e->opt.prio_mode == 0;
-    const unsigned g1 = (unsigned)((g.N + 63) / 64), g2 = (unsigned)((2 * g.N + 63) / 64);
+    const unsigned g1 = (unsigned)((g.N + 63) / 64);
     const unsigned gt = (unsigned)((g.N + BLSW_TEAMS_PER_WAVE - 1) / BLSW_TEAMS_PER_WAVE);
-    // which compilation of the chain kernels: the engine's (options.chain_variant), except that with the default variant a SMALL group (at most 8 192
-    // lanes) that starts a pipeline (the first two after creation / a flush) takes the inlined one — little runs beside it whose registers it could
-    // starve, and its latency is what a consumer waits for before the first tensors exist (8 192-instance consumer-mode shard: +3-5 %,
-    // profiles/r04_consumer_probe.txt block 4; a steady stream of large groups loses 3 % with it, hence the conditions)
-    const bool cold_small = e->opt.chain_variant == 0 && e->staged && e->ramp_pos < 2 && g.N <= BLSW_COFACTOR_CHUNKED_MAX_LANES;
+    // Which kernels. A SMALL group (at most BLSW_LATENCY_MAX_LANES lanes) that finds the engine's chains idle starts a pipeline: nothing of this engine
+    // runs beside it, and its latency — one wave's instruction stream, whatever the group's size — is what a consumer waits for before the first
+    // tensors exist. Such a group takes the latency kernels (options.latency_mode 0): map / prepare / G2 allocation on quads and the cofactor chain
+    // values first (kcommon.hpp: Latency). "Idle" is the state of the other group buffers' chains, not a count of groups since the last flush.
+    bool idle = true;
+    for (int k = 0; k < e->nbuf; k++)
+        if (k != e->cur && e->buf[k].used && hipEventQuery(e->buf[k].ev_chains) != hipSuccess) idle = false;
+    const bool small = e->staged && g.ws.cofv != nullptr;
+    const uint32_t lm = e->opt.latency_mode;
+    Latency lat = {false, false};
+    if (small && (lm >= 2 || (lm == 0 && idle))) lat = {lm != 3, lm != 4};
+    // with the latency kernels off, such a group takes the inlined compilation of the chain kernels (options.chain_variant 0)
+    const bool cold_small = e->opt.chain_variant == 0 && small && idle;
     const ChainKernels ck = chain_kernels(e->chains_inlined || cold_small);
+    const bool chunked = e->cofactor_mode == 2 || (e->cofactor_mode == 0 && g.N <= BLSW_COFACTOR_CHUNKED_MAX_LANES);
     hipStream_t st = b.st[0];
     // inputs of every step are ready once its submitting stream reached the point of the submit
     for (uint32_t s = 0; s < steps; s++) hipStreamWaitEvent(st, b.ev_in[s], 0);
@@ -344,13 +353,12 @@ static int launch_group(blsw_engine* e) {
         Group gs = g;
         gs.N = (uint64_t)steps * e->n;
         gs.K = 1;
-        const unsigned s1 = (unsigned)((gs.N + 63) / 64);
         hipLaunchKernelGGL(k_sha_values, dim3(g1), dim3(64), 0, st, g);
-        hipLaunchKernelGGL(ck.map, dim3(g2), dim3(64), 0, st, g);
-        launch_cofactor(ck, e->cofactor_mode == 2 || (e->cofactor_mode == 0 && g.N <= BLSW_COFACTOR_CHUNKED_MAX_LANES), g, st);
-        hipLaunchKernelGGL(ck.prepare, dim3(g1), dim3(64), 0, st, g, 0);
-        hipLaunchKernelGGL(ck.g2_alloc, dim3(s1), dim3(64), 0, b.st[1], gs);
-        hipLaunchKernelGGL(ck.prepare, dim3(s1), dim3(64), 0, b.st[1], gs, 1);
+        launch_map(ck, lat, g, st);
+        launch_cofactor(ck, lat, chunked, g, st);
+        launch_prepare(ck, lat, g, 0, st);
+        launch_g2_alloc(ck, lat, gs, b.st[1]);
+        launch_prepare(ck, lat, gs, 1, b.st[1]);
         hipLaunchKernelGGL(ck.g1, dim3(g1), dim3(64), 0, b.st[1], g);
         hipEventRecord(b.ev_aux, b.st[1]);
         hipStreamWaitEvent(st, b.ev_aux, 0);
@@ -379,12 +387,12 @@ static int launch_group(blsw_engine* e) {
     } else {
         // main, first part: the hash-to-G2 critical path
         hipLaunchKernelGGL(k_sha_values, dim3(g1), dim3(64), 0, st, g);
-        hipLaunchKernelGGL(ck.map, dim3(g2), dim3(64), 0, st, g);
-        launch_cofactor(ck, e->cofactor_mode == 2 || (e->cofactor_mode == 0 && g.N <= BLSW_COFACTOR_CHUNKED_MAX_LANES), g, st);
-        hipLaunchKernelGGL(ck.prepare, dim3(g1), dim3(64), 0, st, g, 0);
+        launch_map(ck, lat, g, st);
+        launch_cofactor(ck, lat, chunked, g, st);
+        launch_prepare(ck, lat, g, 0, st);
         // aux: prepare_g2(sig) and the group allocations (53 ms alone beside the 86 ms of the main stream's first part)
         hipStream_t sb = b.st[1];
-        hipLaunchKernelGGL(ck.prepare, dim3(g1), dim3(64), 0, sb, g, 1);
+        launch_prepare(ck, lat, g, 1, sb);
         if (e->L.n_keys) {  // aggregate_verify: one lane per (instance, key) allocates, then mapped_aggregate + pk != 0 + prepare_g1 per instance
             hipLaunchKernelGGL(ck.agg_keys, dim3((unsigned)((g.N * e->L.n_keys + 63) / 64)), dim3(64), 0, sb, g, g.ws.keyproj);
             hipLaunchKernelGGL(ck.agg_sum, dim3(g1), dim3(64), 0, sb, g, (const Fp*)g.ws.keyproj);
@@ -393,7 +401,7 @@ static int launch_group(blsw_engine* e) {
         if (e->modes.g2_team)
             hipLaunchKernelGGL(k_g2_alloc_team, dim3(gt), dim3(64), 0, b.st[1], g);
         else
-            hipLaunchKernelGGL(ck.g2_alloc, dim3(g1), dim3(64), 0, b.st[1], g);
+            launch_g2_alloc(ck, lat, g, b.st[1]);
     }
     if (K == 1) {
         hipEventRecord(b.ev_aux, b.st[1]);
@@ -451,6 +459,7 @@ int blsw_engine_options_default(blsw_engine_options_t* o) {
     o->cofactor_mode = 0;
     o->params_mode = 0;
     o->group_ramp = 0;
+    o->latency_mode = 0;
     return BLSW_OK;
 }
 
@@ -466,9 +475,16 @@ int blsw_engine_workspace_bytes_ex(uint64_t n, uint32_t msg_len, uint32_t max_st
     // the same workspace serves every kernel variant: the largest carve of the three mode combinations
     uint64_t need = 0;
     const Modes all[3] = {{true, false}, {true, true}, {false, false}};
+    // a launch group may be any number of pending batches up to max_steps, and groups of at most BLSW_LATENCY_MAX_LANES lanes carry the
+    // scratch of the latency kernels: the largest such group can need more than the largest group
+    const uint64_t small_steps = BLSW_LATENCY_MAX_LANES / (n * K) < max_steps ? BLSW_LATENCY_MAX_LANES / (n * K) : max_steps;
     for (const Modes& m : all) {
         uint64_t t = carve(nullptr, n * max_steps * K, L, staged, m, n * max_steps).total_bytes;
         need = t > need ? t : need;
+        if (small_steps) {
+            t = carve(nullptr, n * small_steps * K, L, staged, m, n * small_steps).total_bytes;
+            need = t > need ? t : need;
+        }
     }
     if (K > 1) need = align_up(need, 256) + miller_par_bytes(n * max_steps, K, BLSW_MILLER_CHUNK_DEFAULT);  // value stores of the pair-parallel Miller product
     *bytes = (uint64_t)n_buffers * align_up(need, 4096);
@@ -489,7 +505,7 @@ int blsw_engine_create_ex(blsw_engine_t** out, uint64_t n, uint32_t msg_len, uin
     // place while the chains run and could not honour a held output
     if (options->consumer_mode > 1 || (options->consumer_mode == 1 && max_steps == 1 && n_buffers == 1)) return BLSW_ERR_ARG;
     if (options->pairing_mode > 1 || options->g2_mode > 1 || (options->g2_mode == 1 && options->pairing_mode != 0) || options->expand_store > 3 ||
-        options->prio_mode > 2 || options->group_ramp > 1 || options->output_form > 1 || options->chain_variant > 2 || options->cofactor_mode > 2 || (options->expand_variant & 0xff) > 12 || (options->expand_variant >> 9) || options->n_keys > 65535 ||
+        options->prio_mode > 2 || options->group_ramp > 1 || options->latency_mode > 4 || options->output_form > 1 || options->chain_variant > 2 || options->cofactor_mode > 2 || (options->expand_variant & 0xff) > 12 || (options->expand_variant >> 9) || options->n_keys > 65535 ||
         (options->n_keys && options->g2_mode) || options->n_pairs > 4096)
         return BLSW_ERR_ARG;
     // N+1-pair product (options.n_pairs = K > 1): a staged engine with the default kernel modes; its expansion launch has one row of
@@ -942,19 +958,20 @@ int blsw_aggregate_verify_batch(const uint64_t* d_pks_xy, const uint8_t* d_bitma
     DeviceGuard guard(stream_device(st));  // the device that owns `stream`
     StepDesc h = {nullptr, d_sig_xy, d_msg, d_witness, witness_stride, d_result, d_pks_xy, d_bitmap, d_count};
     if (int rc = put_desc(d_desc, h, st)) return rc;
-    const unsigned g1 = (unsigned)((n + 63) / 64), g2 = (unsigned)((2 * n + 63) / 64), gk = (unsigned)((n * n_keys + 63) / 64);
+    const unsigned g1 = (unsigned)((n + 63) / 64), gk = (unsigned)((n * n_keys + 63) / 64);
     hipLaunchKernelGGL(ck.agg_keys, dim3(gk), dim3(64), 0, st, g, keyproj);
     hipLaunchKernelGGL(ck.agg_sum, dim3(g1), dim3(64), 0, st, g, (const Fp*)keyproj);
-    hipLaunchKernelGGL(ck.g2_alloc, dim3(g1), dim3(64), 0, st, g);
-    hipLaunchKernelGGL(ck.prepare, dim3(g1), dim3(64), 0, st, g, 1);
+    const Latency lat = {g.ws.cofv != nullptr, g.ws.cofv != nullptr};  // a small direct call is latency-bound: quads, values-first cofactor chain
+    launch_g2_alloc(ck, lat, g, st);
+    launch_prepare(ck, lat, g, 1, st);
     hipLaunchKernelGGL(ck.sha, dim3(g1), dim3(64), 0, st, g, d_witness ? 1 : 0, 1);
     if (d_witness) {
         ExpandArgs xa = {g.ws.bits, g.ws.sha_words, 0, g.L.sha_bits, g.L.off_expand, d_witness, witness_stride, 1u, 0u, 0};
         launch_expand(BLSW_DEFAULT_EXPAND_VARIANT, 0, 0, st, xa, (unsigned)n);
     }
-    hipLaunchKernelGGL(ck.map, dim3(g2), dim3(64), 0, st, g);
-    launch_cofactor(ck, g.N <= BLSW_COFACTOR_CHUNKED_MAX_LANES, g, st);
-    hipLaunchKernelGGL(ck.prepare, dim3(g1), dim3(64), 0, st, g, 0);
+    launch_map(ck, lat, g, st);
+    launch_cofactor(ck, lat, g.N <= BLSW_COFACTOR_CHUNKED_MAX_LANES, g, st);
+    launch_prepare(ck, lat, g, 0, st);
     launch_pairing(g, DEFAULT_MODES, st);
     return hip_ok(hipGetLastError(), "launch");
 }
@@ -993,7 +1010,7 @@ int blsw_verify_multi_batch(const uint64_t* d_pks_xy, const uint8_t* d_msgs, uin
     DeviceGuard guard(dev);
     StepDesc h = {d_pks_xy, d_sig_xy, d_msgs, d_witness, witness_stride, d_result, nullptr, nullptr, nullptr};
     if (int rc = put_desc(d_desc, h, st)) return rc;
-    const unsigned p1 = (unsigned)((NP + 63) / 64), p2 = (unsigned)((2 * NP + 63) / 64), s1 = (unsigned)((n + 63) / 64);
+    const unsigned p1 = (unsigned)((NP + 63) / 64);
     // fork: the signature's allocation + prepare (one lane per instance: 57 ms of latency) and the keys' allocation run beside the
     // hash-to-G2 chains of the pairs; join in front of the Miller product. The two side streams and three events are created once
     // per host thread and device and kept (an event is re-recorded per call; a wait refers to the record that preceded it).
@@ -1021,8 +1038,9 @@ int blsw_verify_multi_batch(const uint64_t* d_pks_xy, const uint8_t* d_msgs, uin
         hipStreamWaitEvent(s_sig, ev_fork, 0);
         hipStreamWaitEvent(s_keys, ev_fork, 0);
     }
-    hipLaunchKernelGGL(ck.g2_alloc, dim3(s1), dim3(64), 0, s_sig, gs);
-    hipLaunchKernelGGL(ck.prepare, dim3(s1), dim3(64), 0, s_sig, gs, 1);
+    const Latency lat = {ws.cofv != nullptr, ws.cofv != nullptr};  // a small direct call is latency-bound: quads, values-first cofactor chain
+    launch_g2_alloc(ck, lat, gs, s_sig);
+    launch_prepare(ck, lat, gs, 1, s_sig);
     hipLaunchKernelGGL(ck.g1, dim3(p1), dim3(64), 0, s_keys, gp);
     // the SHA witness bits and their expansion (92 % of the output bytes) need only the messages: their own stream, beside the curve
     // chains; the chains start from the value-only hash_to_field
@@ -1039,9 +1057,9 @@ int blsw_verify_multi_batch(const uint64_t* d_pks_xy, const uint8_t* d_msgs, uin
         }
     }
     hipLaunchKernelGGL(k_sha_values, dim3(p1), dim3(64), 0, st, gp);
-    hipLaunchKernelGGL(ck.map, dim3(p2), dim3(64), 0, st, gp);
-    launch_cofactor(ck, gp.N <= BLSW_COFACTOR_CHUNKED_MAX_LANES, gp, st);
-    hipLaunchKernelGGL(ck.prepare, dim3(p1), dim3(64), 0, st, gp, 0);
+    launch_map(ck, lat, gp, st);
+    launch_cofactor(ck, lat, gp.N <= BLSW_COFACTOR_CHUNKED_MAX_LANES, gp, st);
+    launch_prepare(ck, lat, gp, 0, st);
     if (forked) {
         hipEventRecord(ev_join[0], s_sig);
         hipEventRecord(ev_join[1], s_keys);

@@ -482,6 +482,40 @@ BLSW_HD_NOINLINE Fp fp_inv(const Fp& a) {
     return r;
 }
 
+// ---------------------------------------------------------------- quads (latency compilation, -DBLSW_QUAD)
+// A translation unit compiled with BLSW_QUAD runs every chain on FOUR adjacent lanes: all four hold the same values and execute the same
+// program, and the independent Fp products of an Fp2 operation (three of a Karatsuba product, two of a square, two of a product by an Fp
+// element, the two squares of a norm) go to different lanes; the products come back to all four lanes through DPP quad broadcasts (twelve
+// v_mov_b32_dpp per element). The programs above (chains.hpp, cofactor_vf.hpp, ...) do not change: only the Fp2 primitives below and in
+// gadgets.hpp do. Used for small launch groups that start a pipeline, whose latency is one wave's instruction stream (engine.hip).
+#if defined(BLSW_QUAD) && defined(__HIP_DEVICE_COMPILE__)
+#define BLSW_QUAD_DEV 1
+BLSW_HD uint32_t quad_role() { return threadIdx.x & 3u; }
+template <int K>
+BLSW_HD Fp quad_bcast(const Fp& v) {  // lane K of the quad -> all four lanes
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < 12; i++) r.l[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)v.l[i], K * 0x55, 0xf, 0xf, true);
+    return r;
+}
+template <int K>
+BLSW_HD uint32_t quad_bcast_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, K * 0x55, 0xf, 0xf, true);
+}
+BLSW_HD Fp quad_sel2(uint32_t role, const Fp& a, const Fp& b) {  // even lanes a, odd lanes b
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < 12; i++) r.l[i] = (role & 1u) ? b.l[i] : a.l[i];
+    return r;
+}
+BLSW_HD Fp quad_sel3(uint32_t role, const Fp& a, const Fp& b, const Fp& c) {  // lane 0 (and 3) a, lane 1 b, lane 2 c
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < 12; i++) r.l[i] = role == 1u ? b.l[i] : (role == 2u ? c.l[i] : a.l[i]);
+    return r;
+}
+#endif
+
 // ---------------------------------------------------------------- Fp2 = Fp[u]/(u^2+1)
 BLSW_HD Fp2 fp2_zero() { return {fp_zero(), fp_zero()}; }
 BLSW_HD Fp2 fp2_one() { return {fp_one(), fp_zero()}; }
@@ -493,6 +527,41 @@ BLSW_HD Fp2 fp2_dbl(const Fp2& a) { return {fp_dbl(a.c0), fp_dbl(a.c1)}; }
 BLSW_HD Fp2 fp2_conj(const Fp2& a) { return {a.c0, fp_neg(a.c1)}; }
 BLSW_HD Fp2 fp2_mul_xi(const Fp2& a) { return {fp_sub(a.c0, a.c1), fp_add(a.c0, a.c1)}; }  // * (1+u)
 // value-only products (used where the circuit has a constant operand: linear combination, no witness)
+#ifdef BLSW_QUAD_DEV
+// one Fp product per lane: lane 0 a0 b0, lane 1 a1 b1, lane 2 (a0 + a1)(b0 + b1); `prod` = this lane's product (the witness of role < 3)
+BLSW_HD Fp2 fp2_mul_quad(const Fp2& a, const Fp2& b, Fp& prod) {
+    const uint32_t role = quad_role();
+    prod = fp_mul(quad_sel3(role, a.c0, a.c1, fp_add(a.c0, a.c1)), quad_sel3(role, b.c0, b.c1, fp_add(b.c0, b.c1)));
+    const Fp v0 = quad_bcast<0>(prod), v1 = quad_bcast<1>(prod), s = quad_bcast<2>(prod);
+    return {fp_sub(v0, v1), fp_sub(fp_sub(s, v0), v1)};
+}
+// lane 0 a0 a1, lane 1 (a0 - a1)(a0 + a1)
+BLSW_HD Fp2 fp2_sqr_quad(const Fp2& a, Fp& prod) {
+    const uint32_t role = quad_role();
+    prod = fp_mul(quad_sel2(role, a.c0, fp_sub(a.c0, a.c1)), quad_sel2(role, a.c1, fp_add(a.c0, a.c1)));
+    return {quad_bcast<1>(prod), fp_dbl(quad_bcast<0>(prod))};
+}
+BLSW_HD Fp2 fp2_mul_inl(const Fp2& a, const Fp2& b) {
+    Fp prod;
+    return fp2_mul_quad(a, b, prod);
+}
+BLSW_FN Fp2 fp2_mul(const Fp2& a, const Fp2& b) { return fp2_mul_inl(a, b); }
+BLSW_FN Fp2 fp2_sqr(const Fp2& a) {
+    Fp prod;
+    return fp2_sqr_quad(a, prod);
+}
+BLSW_FN Fp2 fp2_mul_fp(const Fp2& a, const Fp& b) {
+    const Fp prod = fp_mul(quad_sel2(quad_role(), a.c0, a.c1), b);
+    return {quad_bcast<0>(prod), quad_bcast<1>(prod)};
+}
+BLSW_HD Fp2 fp2_inv_inl(const Fp2& a) {
+    const uint32_t role = quad_role();
+    const Fp sq = fp_sqr(quad_sel2(role, a.c0, a.c1));
+    const Fp ni = fp_inv(fp_add(quad_bcast<0>(sq), quad_bcast<1>(sq)));
+    const Fp prod = fp_mul(quad_sel2(role, a.c0, a.c1), ni);
+    return {quad_bcast<0>(prod), fp_neg(quad_bcast<1>(prod))};
+}
+#else
 BLSW_HD Fp2 fp2_mul_inl(const Fp2& a, const Fp2& b) {
     Fp v0 = fp_mul(a.c0, b.c0), v1 = fp_mul(a.c1, b.c1);
     Fp s = fp_mul(fp_add(a.c0, a.c1), fp_add(b.c0, b.c1));
@@ -510,6 +579,7 @@ BLSW_HD Fp2 fp2_inv_inl(const Fp2& a) {
     Fp ni = fp_inv(n);
     return {fp_mul(a.c0, ni), fp_neg(fp_mul(a.c1, ni))};
 }
+#endif
 BLSW_FN Fp2 fp2_inv(const Fp2& a) { return fp2_inv_inl(a); }
 
 }  // namespace blsw

@@ -18,24 +18,39 @@ struct Emitter {
     uint32_t pos;          // element index of the next witness
     uint64_t stride = 12;  // distance, in u32, between consecutive elements: 12 = dense vector (instance-major);
                            // 12 * N = element-major staging shared by N instances (coalesced across lanes)
+    // element `at` of this instance := v (no cursor movement, no mode check)
+    BLSW_HD void store_at(uint32_t at, const Fp& v) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        // witnesses live in global memory (staging or an output tensor): say so — a generic pointer makes these FLAT stores, which count on
+        // lgkmcnt as well and hold up every later wait for an LDS operation (the team kernels) until their addresses are resolved
+        blsw_global_u32x4* d = (blsw_global_u32x4*)(base + (size_t)at * stride);
+        d[0] = blsw_u32x4{v.l[0], v.l[1], v.l[2], v.l[3]};
+        d[1] = blsw_u32x4{v.l[4], v.l[5], v.l[6], v.l[7]};
+        d[2] = blsw_u32x4{v.l[8], v.l[9], v.l[10], v.l[11]};
+#else
+        uint32_t* d = base + (size_t)at * stride;
+        for (int i = 0; i < 12; i++) d[i] = v.l[i];
+#endif
+    }
     BLSW_HD void put(const Fp& v) {
         if (base == nullptr) {  // value-only mode (hash_to_g2 batch): no store, cursor still advances
             pos++;
             return;
         }
-#if defined(__HIP_DEVICE_COMPILE__)
-        // witnesses live in global memory (staging or an output tensor): say so — a generic pointer makes these FLAT stores, which count on
-        // lgkmcnt as well and hold up every later wait for an LDS operation (the team kernels) until their addresses are resolved
-        blsw_global_u32x4* d = (blsw_global_u32x4*)(base + (size_t)pos * stride);
-        d[0] = blsw_u32x4{v.l[0], v.l[1], v.l[2], v.l[3]};
-        d[1] = blsw_u32x4{v.l[4], v.l[5], v.l[6], v.l[7]};
-        d[2] = blsw_u32x4{v.l[8], v.l[9], v.l[10], v.l[11]};
-#else
-        uint32_t* d = base + (size_t)pos * stride;
-        for (int i = 0; i < 12; i++) d[i] = v.l[i];
+#ifdef BLSW_QUAD_DEV
+        if (quad_role() == 0)  // the four lanes of a quad hold the same value: one of them stores it
 #endif
+            store_at(pos, v);
         pos++;
     }
+#ifdef BLSW_QUAD_DEV
+    // every lane of the quad with role < n stores ITS value at pos + role (the split products of an Fp2 operation); cursor += n
+    BLSW_HD void put_split(const Fp& mine, uint32_t n) {
+        const uint32_t role = quad_role();
+        if (base != nullptr && role < n) store_at(pos + role, mine);
+        pos += n;
+    }
+#endif
     BLSW_HD void put_bool(bool b) {
         Fp one = fp_one();
         Fp v;
@@ -70,6 +85,21 @@ BLSW_HD Fp fp_select_w(Emitter& e, bool cond, const Fp& t, const Fp& f) {
 }
 
 // ---- Fp2Var (QuadExtVar over FpVar)
+#ifdef BLSW_QUAD_DEV
+// the three (two) product witnesses are computed and stored by three (two) lanes of the quad (fp.hpp: fp2_mul_quad)
+BLSW_HD Fp2 fp2_mul_w(Emitter& e, const Fp2& a, const Fp2& b) {
+    Fp prod;
+    const Fp2 r = fp2_mul_quad(a, b, prod);
+    e.put_split(prod, 3);
+    return r;
+}
+BLSW_HD Fp2 fp2_sqr_w(Emitter& e, const Fp2& a) {
+    Fp prod;
+    const Fp2 r = fp2_sqr_quad(a, prod);
+    e.put_split(prod, 2);
+    return r;
+}
+#else
 BLSW_HD Fp2 fp2_mul_w(Emitter& e, const Fp2& a, const Fp2& b) {
     Fp v0 = fp_mul_w(e, a.c0, b.c0);
     Fp v1 = fp_mul_w(e, a.c1, b.c1);
@@ -81,6 +111,7 @@ BLSW_HD Fp2 fp2_sqr_w(Emitter& e, const Fp2& a) {
     Fp t = fp_mul_w(e, fp_sub(a.c0, a.c1), fp_add(a.c0, a.c1));
     return {t, fp_dbl(v2)};
 }
+#endif
 // QuadExtVar::inverse: witnesses inv.c0, inv.c1, then mul_equals' v1 = a.c1 * inv.c1
 BLSW_FN Fp2 fp2_inv_w(Emitter& e, const Fp2& a) {
     Fp2 inv = fp2_inv(a);
@@ -119,6 +150,30 @@ BLSW_HD void fp2_inv2_inl(const Fp2& a, const Fp2& b, Fp2& a_inv, Fp2& b_inv) {
     b_inv = fp2_mul_inl(a, pi);
 }
 BLSW_FN void fp2_inv2(const Fp2& a, const Fp2& b, Fp2& a_inv, Fp2& b_inv) { fp2_inv2_inl(a, b, a_inv, b_inv); }
+#ifdef BLSW_QUAD_DEV
+// the two component tests (an inversion each) on two lanes of the quad: lane 0 stores [ne0, m0], lane 1 [ne1, m1]
+BLSW_FN bool fp2_is_eq_w(Emitter& e, const Fp2& self, const Fp2& other) {
+    const uint32_t role = quad_role();
+    const Fp diff = fp_sub(quad_sel2(role, self.c0, self.c1), quad_sel2(role, other.c0, other.c1));
+    const bool ne = !fp_is_zero(diff);
+    const Fp m = fp_inv(diff);
+    if (e.base != nullptr && role < 2) {
+        const Fp one = fp_one();
+        Fp flag, mult;
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            flag.l[i] = ne ? one.l[i] : 0u;
+            mult.l[i] = ne ? m.l[i] : one.l[i];
+        }
+        e.store_at(e.pos + 2 * role, flag);
+        e.store_at(e.pos + 2 * role + 1, mult);
+    }
+    e.pos += 4;
+    const bool r = !quad_bcast_u32<0>(ne ? 1u : 0u) && !quad_bcast_u32<1>(ne ? 1u : 0u);
+    e.put_bool(r);
+    return r;
+}
+#else
 BLSW_FN bool fp2_is_eq_w(Emitter& e, const Fp2& self, const Fp2& other) {
     bool b0 = fp_is_eq_w(e, self.c0, other.c0);
     bool b1 = fp_is_eq_w(e, self.c1, other.c1);
@@ -126,6 +181,7 @@ BLSW_FN bool fp2_is_eq_w(Emitter& e, const Fp2& self, const Fp2& other) {
     e.put_bool(r);
     return r;
 }
+#endif
 // v.is_eq(Constant zero) / v.is_zero(): evaluated as zero.is_eq(v)
 BLSW_HD bool fp2_is_zero_w(Emitter& e, const Fp2& v) { return fp2_is_eq_w(e, fp2_zero(), v); }
 BLSW_HD Fp2 fp2_select_w(Emitter& e, bool cond, const Fp2& t, const Fp2& f) {

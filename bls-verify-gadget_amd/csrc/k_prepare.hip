@@ -2,11 +2,12 @@
 // Two compilations (build.py, kcommon.hpp: BLSW_K). Grouped-engine compilation of THIS unit: programs inlined into the kernel and
 // two waves per SIMD (<= 256 registers) — measured +4 % on the 20-step job, neutral in the steady state (profiles/r03_ab_chain_builds.txt);
 // -DBLSW_OUTLINE_PREPARE restores the out-of-line build for A/B runs. Direct-mode compilation (*_inl): inlined, the whole register file.
-#if defined(BLSW_KVARIANT_INL) || !defined(BLSW_OUTLINE_PREPARE)
+// Latency compilation (*_q, -DBLSW_KVARIANT_QUAD): inlined, one chain on the four lanes of a quad (fp.hpp: quads).
+#if defined(BLSW_KVARIANT_INL) || defined(BLSW_KVARIANT_QUAD) || !defined(BLSW_OUTLINE_PREPARE)
 #define BLSW_INLINE_CHAINS 1
 #endif
 #include "kcommon.hpp"
-#if !defined(BLSW_KVARIANT_INL) && !defined(BLSW_OUTLINE_PREPARE)
+#if !defined(BLSW_KVARIANT_INL) && !defined(BLSW_KVARIANT_QUAD) && !defined(BLSW_OUTLINE_PREPARE)
 #define BLSW_CHAIN_ATTR BLSW_ATTR_W2
 #else
 #define BLSW_CHAIN_ATTR
@@ -17,7 +18,7 @@ namespace blsw {
 // which = 0: prepare_g2(H(m)) ; which = 1: prepare_g2(sig)
 __global__ __launch_bounds__(64) BLSW_CHAIN_ATTR void BLSW_K(k_prepare)(Group g, int which) {
     if (g.chain_prio) __builtin_amdgcn_s_setprio(3);  // latency-critical chain: win VALU issue arbitration against the streaming placement waves
-    uint64_t I = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t I = item_index();  // latency compilation (k_prepare_q): four lanes per item
     if (I >= g.N) return;
     LaneId id = lane_id(g, I);
     const uint64_t N = g.N;

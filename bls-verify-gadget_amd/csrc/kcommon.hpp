@@ -5,10 +5,24 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef BLSW_KVARIANT_QUAD  // the latency compilation of a chain unit: four lanes per item (fp.hpp: quads)
+#define BLSW_QUAD 1
+#endif
 #include "chains.hpp"
+#include "cofactor_vf.hpp"
 #include "layout.h"
 
 namespace blsw {
+
+#ifdef BLSW_KVARIANT_QUAD
+#define BLSW_LPI 4u  // lanes per item (instance, pair, chunk) of this compilation's kernels
+#else
+#define BLSW_LPI 1u
+#endif
+// index of this thread's item, and whether it is the lane of its item that writes the item's outputs (values are identical on the lanes of a quad)
+__device__ __forceinline__ uint64_t item_index() { return ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / BLSW_LPI; }
+__device__ __forceinline__ bool item_leader() { return BLSW_LPI == 1u || (threadIdx.x & (BLSW_LPI - 1u)) == 0u; }
+inline unsigned item_grid(uint64_t items, unsigned lpi) { return (unsigned)((items * lpi + 63) / 64); }
 
 // ---------------------------------------------------------------- workspace
 // All per-instance scratch is stored element-major: element e of instance I lives at index e*N + I, so that the
@@ -34,8 +48,11 @@ struct Workspace {
     uint32_t split_row;  // is_one), instance-major: the six-lane pairing kernel appends each instance's segment sequentially
     uint32_t pair_rows;  // (split_row = staging_rows, pair_rows = 0 when the single-lane pairing kernel is in use)
     uint64_t sha_words;
+    Fp* cofv;            // [BLSW_COFV_ELEMS][N] scratch of the values-first cofactor chain (cofactor_vf.hpp), or nullptr (N > BLSW_LATENCY_MAX_LANES)
     uint64_t total_bytes;
 };
+// launch groups of at most this many lanes may take the latency kernels (quads, values-first cofactor chain): their scratch is carved for them
+#define BLSW_LATENCY_MAX_LANES 8192
 inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
 BLSW_HD inline uint64_t bits_tile_words(uint64_t sha_words) { return sha_words * 64; }  // u32 per 64-instance tile
 // kernel variants, fixed per engine at creation (blsw_engine_options_t)
@@ -121,6 +138,7 @@ inline Workspace carve(void* base, uint64_t N, const blsw_layout_t& L, bool with
     w.coeff_sig = reinterpret_cast<Fp*>(take(272ull * n_sig * sizeof(Fp)));
     w.n_sig = n_sig;
     w.keyproj = L.n_keys ? reinterpret_cast<Fp*>(take(3ull * N * L.n_keys * sizeof(Fp))) : nullptr;
+    w.cofv = N <= BLSW_LATENCY_MAX_LANES ? reinterpret_cast<Fp*>(take((uint64_t)BLSW_COFV_ELEMS * N * sizeof(Fp))) : nullptr;
     w.staging_rows = L.n_witness - L.sha_bits;
     if (L.n_pairs > 1 && with_staging) {  // N+1-pair product in the grouped engine: pair tiles, instance tiles, instance-major rows
         const MultiStaging ms = staging_layout_multi(L);
@@ -277,7 +295,9 @@ __device__ __forceinline__ Proj<OpsFp2> ld_proj2(const Fp* p, uint64_t n) {
 struct CoeffStrided {
     Fp* p;
     uint64_t n;
-    __device__ __forceinline__ void st(uint32_t idx, const Fp& v) const { st_fp(p + (uint64_t)idx * n, v); }
+    __device__ __forceinline__ void st(uint32_t idx, const Fp& v) const {
+        if (item_leader()) st_fp(p + (uint64_t)idx * n, v);
+    }
     __device__ __forceinline__ Fp ld(uint32_t idx) const { return ld_fp(p + (uint64_t)idx * n); }
 };
 
@@ -309,11 +329,16 @@ struct ExpandArgs {
 //   k_map_inl  (-DBLSW_KVARIANT_INL) the programs inlined into the kernel: the whole 512-register file, 0.1-0.7 KB of stack instead of
 //              1.2-3.9 KB (no argument / callee-saved traffic through scratch): 1.2-3.5x shorter under HBM load (k_map 32.8 -> 9.2 ms,
 //              k_g1 22 -> 8.5 ms in blsw_verify_multi_batch) — what the direct-mode entries want (few waves, latency-bound)
-#ifdef BLSW_KVARIANT_INL
+//   k_map_q    (-DBLSW_KVARIANT_QUAD) inlined, and every chain on the four lanes of a quad with the independent Fp products of an Fp2 operation
+//              on different lanes (fp.hpp, gadgets.hpp): the latency compilation, for small launch groups that start a pipeline
+#if defined(BLSW_KVARIANT_QUAD)
+#define BLSW_K(name) name##_q
+#elif defined(BLSW_KVARIANT_INL)
 #define BLSW_K(name) name##_inl
 #else
 #define BLSW_K(name) name
 #endif
+
 #ifndef BLSW_PLACE_ITERS
 #define BLSW_PLACE_ITERS 8
 #endif
@@ -347,6 +372,17 @@ __global__ void k_cofactor_chunk(Group g);
 __global__ void k_cofactor_chunk_inl(Group g);
 __global__ void k_cofactor_join(Group g);
 __global__ void k_cofactor_join_inl(Group g);
+__global__ void k_map_q(Group g);
+__global__ void k_prepare_q(Group g, int which);
+__global__ void k_g2_alloc_q(Group g);
+// values-first cofactor chain (cofactor_vf.hpp; k_cofv.hip): serial value phases (one lane or one quad per item), parallel witness phases, join
+__global__ void k_cofv_chain(Group g);
+__global__ void k_cofv_chain_q(Group g);
+__global__ void k_cofv_acc(Group g);
+__global__ void k_cofv_acc_q(Group g);
+__global__ void k_cofv_dbl_w(Group g);
+__global__ void k_cofv_add_w(Group g);
+__global__ void k_cofv_join(Group g);
 __global__ void k_map_values(Group g);
 __global__ void k_cofactor_values(Group g);
 __global__ void k_prepare(Group g, int which);
@@ -405,19 +441,56 @@ struct ChainKernels {
     void (*cofactor_chunk)(Group);  // the cofactor segment with its three chunks on three lanes, and the join (cofactor_par.hpp)
     void (*cofactor_join)(Group);
 };
-// clear_cofactor2 of N lanes on `st`: chunked (three lanes per (pk, msg) pair + the join) or as one chain per lane
-inline void launch_cofactor(const ChainKernels& ck, bool chunked, const Group& g, hipStream_t st) {
-    const unsigned g1 = (unsigned)((g.N + 63) / 64), g3 = (unsigned)((3 * g.N + 63) / 64);
-    if (chunked) {
+inline ChainKernels chain_kernels(bool inlined) {
+    if (inlined) return {k_sha_inl, k_g1_inl, k_agg_keys_inl, k_agg_sum_inl, k_g2_alloc_inl, k_map_inl, k_cofactor_inl, k_prepare_inl, k_cofactor_chunk_inl, k_cofactor_join_inl};
+    return {k_sha, k_g1, k_agg_keys, k_agg_sum, k_g2_alloc, k_map, k_cofactor, k_prepare, k_cofactor_chunk, k_cofactor_join};
+}
+// Latency forms of a launch group's chains (small groups: Workspace::cofv exists): `quad` = the *_q compilation of map / prepare / G2 allocation and
+// of the serial phases of the values-first cofactor chain (four lanes per item); `vf` = clear_cofactor2 values first (cofactor_vf.hpp)
+struct Latency {
+    bool quad, vf;
+};
+// clear_cofactor2 of N lanes on `st`: values first (five launches), chunked (three lanes per (pk, msg) pair + the join) or as one chain per lane
+inline void launch_cofactor(const ChainKernels& ck, Latency lat, bool chunked, const Group& g, hipStream_t st) {
+    const unsigned g1 = item_grid(g.N, 1), g3 = item_grid(3 * g.N, 1);
+    if (lat.vf && g.ws.cofv) {
+        constexpr CofvPlan plan = cofv_plan();
+        const uint64_t adds = (uint64_t)plan.n_adds[0] + plan.n_adds[1] + plan.n_adds[2];
+        if (lat.quad)
+            hipLaunchKernelGGL(k_cofv_chain_q, dim3(item_grid(g.N, 4)), dim3(64), 0, st, g);
+        else
+            hipLaunchKernelGGL(k_cofv_chain, dim3(g1), dim3(64), 0, st, g);
+        hipLaunchKernelGGL(k_cofv_dbl_w, dim3(item_grid((uint64_t)BLSW_H_EFF_NBITS * g.N, 1)), dim3(64), 0, st, g);
+        if (lat.quad)
+            hipLaunchKernelGGL(k_cofv_acc_q, dim3(item_grid(3 * g.N, 4)), dim3(64), 0, st, g);
+        else
+            hipLaunchKernelGGL(k_cofv_acc, dim3(g3), dim3(64), 0, st, g);
+        hipLaunchKernelGGL(k_cofv_add_w, dim3(item_grid(adds * g.N, 1)), dim3(64), 0, st, g);
+        hipLaunchKernelGGL(k_cofv_join, dim3(g1), dim3(64), 0, st, g);
+    } else if (chunked) {
         hipLaunchKernelGGL(ck.cofactor_chunk, dim3(g3), dim3(64), 0, st, g);
         hipLaunchKernelGGL(ck.cofactor_join, dim3(g1), dim3(64), 0, st, g);
     } else {
         hipLaunchKernelGGL(ck.cofactor, dim3(g1), dim3(64), 0, st, g);
     }
 }
-inline ChainKernels chain_kernels(bool inlined) {
-    if (inlined) return {k_sha_inl, k_g1_inl, k_agg_keys_inl, k_agg_sum_inl, k_g2_alloc_inl, k_map_inl, k_cofactor_inl, k_prepare_inl, k_cofactor_chunk_inl, k_cofactor_join_inl};
-    return {k_sha, k_g1, k_agg_keys, k_agg_sum, k_g2_alloc, k_map, k_cofactor, k_prepare, k_cofactor_chunk, k_cofactor_join};
+inline void launch_map(const ChainKernels& ck, Latency lat, const Group& g, hipStream_t st) {
+    if (lat.quad)
+        hipLaunchKernelGGL(k_map_q, dim3(item_grid(2 * g.N, 4)), dim3(64), 0, st, g);
+    else
+        hipLaunchKernelGGL(ck.map, dim3(item_grid(2 * g.N, 1)), dim3(64), 0, st, g);
+}
+inline void launch_prepare(const ChainKernels& ck, Latency lat, const Group& g, int which, hipStream_t st) {
+    if (lat.quad)
+        hipLaunchKernelGGL(k_prepare_q, dim3(item_grid(g.N, 4)), dim3(64), 0, st, g, which);
+    else
+        hipLaunchKernelGGL(ck.prepare, dim3(item_grid(g.N, 1)), dim3(64), 0, st, g, which);
+}
+inline void launch_g2_alloc(const ChainKernels& ck, Latency lat, const Group& g, hipStream_t st) {
+    if (lat.quad)
+        hipLaunchKernelGGL(k_g2_alloc_q, dim3(item_grid(g.N, 4)), dim3(64), 0, st, g);
+    else
+        hipLaunchKernelGGL(ck.g2_alloc, dim3(item_grid(g.N, 1)), dim3(64), 0, st, g);
 }
 // host-side launch helpers that live next to their (templated) kernels
 void launch_expand(uint32_t variant, uint32_t store, unsigned lds, hipStream_t st, ExpandArgs a, unsigned n_y);

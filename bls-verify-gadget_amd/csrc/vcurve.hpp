@@ -12,11 +12,18 @@ namespace blsw {
 // here it is a Jacobian ladder over the 636 bits of h_eff with two inversions in all. Output as k_cofactor's: homogeneous (x, y, z).
 // The ladder is written out with inlined Fp2 operations (only the Fp product and the inversion are calls), so that the kernel
 // fits two waves per SIMD: the shared jac2_dbl / jac2_add_mixed are separate functions that take 248 VGPRs + 32 AGPRs each.
+#ifdef BLSW_QUAD_DEV
+BLSW_HD Fp2 v_sqr(const Fp2& a) {
+    Fp prod;
+    return fp2_sqr_quad(a, prod);
+}
+#else
 BLSW_HD Fp2 v_sqr(const Fp2& a) {
     Fp v = fp_mul(a.c0, a.c1);
     Fp t = fp_mul(fp_sub(a.c0, a.c1), fp_add(a.c0, a.c1));
     return {t, fp_dbl(v)};
 }
+#endif
 BLSW_HD Jac2 v_dbl(const Jac2& p) {  // dbl-2009-l, a = 0
     Fp2 A = v_sqr(p.x), B = v_sqr(p.y), C = v_sqr(B);
     Fp2 D = fp2_dbl(fp2_sub(fp2_sub(v_sqr(fp2_add(p.x, B)), A), C));

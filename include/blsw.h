@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define BLSW_ABI_VERSION 9
+#define BLSW_ABI_VERSION 10
 
 #define BLSW_OK 0
 #define BLSW_ERR_ARG 1
@@ -154,6 +154,12 @@ typedef struct {
                               after creation / a flush are 2, 4, 8, ... batches, up to max_steps: the first witness tensors exist after the chain
                               latency of a small group (its cofactor chain on three lanes), which is what a consumer-mode caller waits for
                               before it can consume anything. Same witnesses either way. */
+    uint32_t latency_mode; /* the latency kernels for launch groups of at most 8 192 lanes: the hash-to-G2 / prepare / G2-allocation chains of an item on the
+                              four lanes of a quad (the independent Fp products of every Fp2 operation on different lanes) and clear_cofactor2 "values
+                              first" (the 636 doublings and 304 additions as Jacobian value chains with four inversions in all, every step's witnesses
+                              derived by a lane of its own). 0 (default) = for such a group when it finds the engine's chains idle (it starts a pipeline:
+                              its latency is what a consumer waits for); 1 = never; 2 = for every such group; 3 / 4 = as 2 with only the values-first
+                              cofactor chain / only the quads (A/B runs). Same witnesses either way. */
 } blsw_engine_options_t;
 /* the defaults (pure: the library reads no environment variable; measurement scripts set the fields they want to vary) */
 int blsw_engine_options_default(blsw_engine_options_t* out);

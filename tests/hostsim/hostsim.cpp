@@ -11,6 +11,7 @@
 #include "../../bls-verify-gadget_amd/csrc/vsign.hpp"
 #include "../../bls-verify-gadget_amd/csrc/miller_par.hpp"
 #include "../../bls-verify-gadget_amd/csrc/cofactor_par.hpp"
+#include "../../bls-verify-gadget_amd/csrc/cofactor_vf.hpp"
 #include <array>
 
 using namespace blsw;
@@ -116,7 +117,7 @@ struct TeamHost {
     }
 };
 static int g_use_team = 0;
-static int g_cofactor_par = 0;  // 1: clear_cofactor2 through cofactor_par.hpp (chunks in the order 2, 0, 1, then the join)
+static int g_cofactor_par = 0;  // 1: clear_cofactor2 through cofactor_par.hpp (chunks in the order 2, 0, 1, then the join); 2: cofactor_vf.hpp
 static uint32_t g_miller_chunk = 2;  // pairs per chunk of the pair-parallel Miller product (mode 2)
 // G2 allocation with the scalar multiplication of the subgroup check on the team program (lanes 0..2 own x, y, z)
 static void g2_alloc_segment(uint32_t* base, const blsw_layout_t& L, const Fp2& sx, const Fp2& sy) {
@@ -178,6 +179,17 @@ struct ParkHost {
 static Proj<OpsFp2> run_cofactor(Emitter e_add, Emitter e, const Proj<OpsFp2>& q0, const Proj<OpsFp2>& q1) {
     if (!g_cofactor_par) return chain_cofactor(e_add, e, q0, q1);
     Fp rows[BLSW_COFACTOR_ROWS];
+    if (g_cofactor_par == 2) {  // cofactor_vf.hpp: values first, the parallel phases in reverse order of their lanes
+        constexpr CofvPlan vp = cofv_plan();
+        std::vector<Fp> scr(BLSW_COFV_ELEMS);
+        const CoeffLinear S{scr.data()}, R{rows};
+        cofv_chain(e_add, e, q0, q1, S, R);
+        for (int D = BLSW_H_EFF_NBITS - 1; D >= 0; D--) cofv_dbl_w(e, (uint32_t)D, S);
+        for (int c = 2; c >= 0; c--) cofv_acc_chain(c, S, R);
+        for (int c = 2; c >= 0; c--)
+            for (int j = (int)vp.n_adds[c] - 1; j >= 0; j--) cofv_add_w(e, c, (uint32_t)j, S);
+        return cofv_join(e, S, R);
+    }
     const int order[3] = {2, 0, 1};  // the chunks do not depend on each other
     for (int k = 0; k < 3; k++) chain_cofactor_chunk(e_add, e, q0, q1, order[k], CoeffLinear{rows});
     return chain_cofactor_join(e, CoeffLinear{rows});
@@ -463,9 +475,14 @@ int hostsim_cofactor_compare(const uint64_t* q0_xy, const uint64_t* q1_xy, uint6
     Proj<OpsFp2> a = chain_cofactor({reinterpret_cast<uint32_t*>(out_serial), 0}, {reinterpret_cast<uint32_t*>(out_serial), SEG_ADD}, q0, q1);
     Fp rows[BLSW_COFACTOR_ROWS];
     Emitter e_add = {reinterpret_cast<uint32_t*>(out_chunked), 0}, e = {reinterpret_cast<uint32_t*>(out_chunked), SEG_ADD};
-    const int order[3] = {1, 2, 0};
-    for (int k = 0; k < 3; k++) chain_cofactor_chunk(e_add, e, q0, q1, order[k], CoeffLinear{rows});
-    Proj<OpsFp2> b = chain_cofactor_join(e, CoeffLinear{rows});
+    Proj<OpsFp2> b;
+    if (g_cofactor_par == 2) {
+        b = run_cofactor(e_add, e, q0, q1);  // cofactor_vf.hpp
+    } else {
+        const int order[3] = {1, 2, 0};
+        for (int k = 0; k < 3; k++) chain_cofactor_chunk(e_add, e, q0, q1, order[k], CoeffLinear{rows});
+        b = chain_cofactor_join(e, CoeffLinear{rows});
+    }
     bool same = fp_eq(a.x.c0, b.x.c0) && fp_eq(a.x.c1, b.x.c1) && fp_eq(a.y.c0, b.y.c0) && fp_eq(a.y.c1, b.y.c1) && fp_eq(a.z.c0, b.z.c0) && fp_eq(a.z.c1, b.z.c1);
     return same && memcmp(out_serial, out_chunked, (size_t)(SEG_ADD + SEG_COFACTOR) * 48) == 0;
 }

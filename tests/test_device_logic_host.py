@@ -430,6 +430,43 @@ def test_cofactor_chunks_in_parallel_device_logic(oracle):
         lib.hostsim_cofactor_par(0)
 
 
+def test_cofactor_values_first_device_logic(oracle):
+    """cofactor_vf.hpp: the doubling chain and the addition chains of clear_cofactor2 as Jacobian VALUE programs (one inversion each, the
+    other 1 / Z by the backward recurrence), every doubling's / addition's witnesses derived independently at its planned place (the
+    parallel phases run in reverse lane order here) and the join: the whole witness vector stays bit-exact, for valid / tampered
+    instances, identity inputs and another message length; and for chosen (Q0, Q1) incl. sum = identity, Q1 = identity, Q0 = Q1."""
+    import ctypes
+
+    lib = hostsim_lib.load()
+    lib.hostsim_cofactor_par(2)
+    try:
+        pk, msg, sig, _ = synth.make_batch(oracle, 16)
+        assert _check(oracle, pk[3], msg[3].tobytes(), sig[3]) is True
+        assert _check(oracle, pk[15], msg[15].tobytes(), sig[15]) is False
+        _check(oracle, np.zeros(12, dtype=np.uint64), msg[0].tobytes(), np.zeros(24, dtype=np.uint64))
+        _check(oracle, pk[1], b"x" * 119, sig[1])
+        p_mod = int("1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab", 16)
+        _, a = oracle.hash_to_g2(b"cofactor-a")
+        _, b = oracle.hash_to_g2(b"cofactor-b")
+
+        def neg(xy):
+            out = xy.copy()
+            for k in (2, 3):
+                v = int.from_bytes(xy[6 * k:6 * k + 6].tobytes(), "little")
+                out[6 * k:6 * k + 6] = np.frombuffer(((p_mod - v) % p_mod).to_bytes(48, "little"), dtype=np.uint64)
+            return out
+
+        u64p = ctypes.POINTER(ctypes.c_uint64)
+        zero = np.zeros(24, dtype=np.uint64)
+        for q0, q1 in ((a, b), (a, neg(a)), (a, zero), (a, a), (zero, zero)):
+            s1 = np.zeros((36 + 8979, 6), dtype=np.uint64)
+            s2 = np.zeros((36 + 8979, 6), dtype=np.uint64)
+            ok = lib.hostsim_cofactor_compare(np.ascontiguousarray(q0).ctypes.data_as(u64p), np.ascontiguousarray(q1).ctypes.data_as(u64p), s1.ctypes.data_as(u64p), s2.ctypes.data_as(u64p))
+            assert ok == 1 and s1.any()
+    finally:
+        lib.hostsim_cofactor_par(0)
+
+
 def test_cofactor_chunks_when_the_sum_is_the_identity(oracle):
     """Q0 = -Q1 (not reachable by hashing): the circuit's affine chain then runs on (0, 0) with zero inverse hints. The chunked
     program must follow those values step by step (its Jacobian shortcut would compute a different, mathematically meaningful

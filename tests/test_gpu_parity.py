@@ -56,17 +56,19 @@ def test_batch_bit_exact(pkg, oracle):
     _compare(oracle, pk, msg, sig, got, w, range(n))
 
 
-@pytest.mark.parametrize("chain_variant,cofactor_mode", [(1, 1), (2, 1), (1, 2), (2, 2)])
-def test_kernel_variants_bit_exact(pkg, oracle, chain_variant, cofactor_mode):
-    """Every compilation of the chain kernels and both forms of the cofactor chain write the same bytes: out-of-line / inlined
-    (options.chain_variant) x one chain per lane / three chunks + join (options.cofactor_mode), a full wave and a ragged one, through a
-    grouped engine (two steps per group)."""
+def _grouped_engine_against_oracle(pkg, oracle, n=35, steps=2, identity_at=None, **options):
+    """n * steps instances (a full wave and a ragged one per step) through a grouped engine (two steps per group) with the given options;
+    every fourth instance on all elements against the oracle. identity_at: that instance gets the all-zero (identity) key and signature."""
     import torch
 
-    n, steps = 35, 2
     pk, msg, sig, expect = synth.make_batch(oracle, n * steps)
+    if identity_at is not None:
+        pk, sig, expect = pk.copy(), sig.copy(), expect.copy()
+        pk[identity_at] = 0
+        sig[identity_at] = 0
+        expect[identity_at] = oracle.witness(pk[identity_at], msg[identity_at].tobytes(), sig[identity_at])[2]  # the gadget's Boolean on defined values
     dev = torch.device("cuda:0")
-    eng = pkg.WitnessEngine(n, 32, max_steps=2, device=dev, n_buffers=2, chain_variant=chain_variant, cofactor_mode=cofactor_mode)
+    eng = pkg.WitnessEngine(n, 32, max_steps=2, device=dev, n_buffers=2, **options)
     outs, ress, keep = [], [], []
     for k in range(steps):
         sl = slice(k * n, (k + 1) * n)
@@ -80,8 +82,27 @@ def test_kernel_variants_bit_exact(pkg, oracle, chain_variant, cofactor_mode):
         sl = slice(k * n, (k + 1) * n)
         got = ress[k].cpu().numpy().astype(bool)
         assert np.array_equal(got, expect[sl])
-        _compare(oracle, pk[sl], msg[sl], sig[sl], got, outs[k].cpu().numpy().view(np.uint64), range(0, n, 4))
+        idx = sorted(set(range(0, n, 4)) | ({identity_at - k * n} if identity_at is not None and k * n <= identity_at < (k + 1) * n else set()))
+        _compare(oracle, pk[sl], msg[sl], sig[sl], got, outs[k].cpu().numpy().view(np.uint64), idx)
     eng.close()
+
+
+@pytest.mark.parametrize("chain_variant,cofactor_mode", [(1, 1), (2, 1), (1, 2), (2, 2)])
+def test_kernel_variants_bit_exact(pkg, oracle, chain_variant, cofactor_mode):
+    """Every compilation of the chain kernels and both forms of the cofactor chain write the same bytes: out-of-line / inlined
+    (options.chain_variant) x one chain per lane / three chunks + join (options.cofactor_mode), a full wave and a ragged one, through a
+    grouped engine (two steps per group); the latency kernels are switched off here (next test)."""
+    _grouped_engine_against_oracle(pkg, oracle, chain_variant=chain_variant, cofactor_mode=cofactor_mode, latency_mode=1)
+
+
+@pytest.mark.parametrize("latency_mode", [0, 2, 3, 4])
+def test_latency_kernels_bit_exact(pkg, oracle, latency_mode):
+    """options.latency_mode: the chains of a small launch group on quads (k_map_q, k_prepare_q, k_g2_alloc_q: the Fp products of every Fp2
+    operation on different lanes, DPP broadcasts) and clear_cofactor2 values first (cofactor_vf.hpp: Jacobian value chains, one lane per
+    doubling / addition for the witnesses) write the same bytes as the one-instance-per-lane chains: 0 = the default rule (the first group
+    finds the chains idle and takes them, the second does not), 2 = every group, 3 = values-first cofactor only, 4 = quads only. Three steps
+    (groups of two and one), ragged waves, one instance with the identity as key and signature."""
+    _grouped_engine_against_oracle(pkg, oracle, n=35, steps=3, identity_at=37, latency_mode=latency_mode)
 
 
 def test_reference_gadget_case(pkg, oracle):
