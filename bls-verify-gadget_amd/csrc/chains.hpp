@@ -381,51 +381,62 @@ struct CoeffLinear {  // plain array (host harness)
     BLSW_FN void st(uint32_t idx, const Fp& v) const { p[idx] = v; }
     BLSW_FN Fp ld(uint32_t idx) const { return p[idx]; }
 };
+// QuadExtVar::inverse with the inverse supplied (gadgets.hpp: fp2_inv_w): witnesses inv.c0, inv.c1, a.c1 * inv.c1
+BLSW_HD Fp2 fp2_inv_pre_w(Emitter& e, const Fp2& a, const Fp2& inv) {
+    e.put(inv.c0);
+    e.put(inv.c1);
+    fp_mul_w(e, a.c1, inv.c1);
+    return inv;
+}
+// one doubling / addition step of G2PreparedVar::from_group_var on the running affine point r, the inverse of the slope's
+// denominator supplied (`ry_inv` = 1 / r.y; `dx_inv` = 1 / (q.x - r.x)): 16 / 14 witnesses, the step's line coefficients to out[4 k ..]
+template <class C>
+BLSW_HD void prepare_dbl_step(Emitter& e, Fp2& rx, Fp2& ry, const Fp2& ry_inv, const C& out, uint32_t k) {
+    const Fp two_inv = K_TWO_INV();
+    Fp2 a = fp2_inv_pre_w(e, ry, ry_inv);
+    Fp2 b = fp2_sqr_w(e, rx);
+    b = fp2_add(fp2_mul_fp(b, two_inv), b);
+    Fp2 c = fp2_mul_w(e, a, b);
+    Fp2 x3 = fp2_sub(fp2_sqr_w(e, c), fp2_dbl(rx));
+    Fp2 cx = fp2_mul_w(e, c, rx);
+    Fp2 ee = fp2_sub(cx, ry);
+    Fp2 c_x3 = fp2_mul_w(e, c, x3);
+    Fp2 y3 = fp2_sub(ee, c_x3);
+    Fp2 f = fp2_neg(c);
+    rx = x3;
+    ry = y3;
+    out.st(4 * k + 0, ee.c0);
+    out.st(4 * k + 1, ee.c1);
+    out.st(4 * k + 2, f.c0);
+    out.st(4 * k + 3, f.c1);
+}
+template <class C>
+BLSW_HD void prepare_add_step(Emitter& e, const Fp2& qx, const Fp2& qy, Fp2& rx, Fp2& ry, const Fp2& dx_inv, const C& out, uint32_t k) {
+    Fp2 a = fp2_inv_pre_w(e, fp2_sub(qx, rx), dx_inv);
+    Fp2 b = fp2_sub(qy, ry);
+    Fp2 c = fp2_mul_w(e, a, b);
+    Fp2 x3 = fp2_sub(fp2_sqr_w(e, c), fp2_add(rx, qx));
+    Fp2 ee = fp2_mul_w(e, fp2_sub(rx, x3), c);
+    Fp2 y3 = fp2_sub(ee, ry);
+    Fp2 cr = fp2_mul_w(e, c, rx);
+    Fp2 g = fp2_sub(cr, ry);
+    Fp2 f = fp2_neg(c);
+    rx = x3;
+    ry = y3;
+    out.st(4 * k + 0, g.c0);
+    out.st(4 * k + 1, g.c1);
+    out.st(4 * k + 2, f.c0);
+    out.st(4 * k + 3, f.c1);
+}
 template <class C>
 BLSW_FN void chain_prepare_g2(Emitter e, const Proj<OpsFp2>& q_, const C& out) {
     Aff2Inf q = g2_to_affine_w(e, q_);
-    const Fp two_inv = K_TWO_INV();
     Fp2 rx = q.x, ry = q.y;
     uint32_t k = 0;
 #pragma unroll 1
     for (int i = 62; i >= 0; i--) {
-        {  // double
-            Fp2 a = fp2_inv_w(e, ry);
-            Fp2 b = fp2_sqr_w(e, rx);
-            b = fp2_add(fp2_mul_fp(b, two_inv), b);
-            Fp2 c = fp2_mul_w(e, a, b);
-            Fp2 x3 = fp2_sub(fp2_sqr_w(e, c), fp2_dbl(rx));
-            Fp2 cx = fp2_mul_w(e, c, rx);
-            Fp2 ee = fp2_sub(cx, ry);
-            Fp2 c_x3 = fp2_mul_w(e, c, x3);
-            Fp2 y3 = fp2_sub(ee, c_x3);
-            Fp2 f = fp2_neg(c);
-            rx = x3;
-            ry = y3;
-            out.st(4 * k + 0, ee.c0);
-            out.st(4 * k + 1, ee.c1);
-            out.st(4 * k + 2, f.c0);
-            out.st(4 * k + 3, f.c1);
-            k++;
-        }
-        if ((BLSW_X_ABS >> i) & 1) {  // add
-            Fp2 a = fp2_inv_w(e, fp2_sub(q.x, rx));
-            Fp2 b = fp2_sub(q.y, ry);
-            Fp2 c = fp2_mul_w(e, a, b);
-            Fp2 x3 = fp2_sub(fp2_sqr_w(e, c), fp2_add(rx, q.x));
-            Fp2 ee = fp2_mul_w(e, fp2_sub(rx, x3), c);
-            Fp2 y3 = fp2_sub(ee, ry);
-            Fp2 cr = fp2_mul_w(e, c, rx);
-            Fp2 g = fp2_sub(cr, ry);
-            Fp2 f = fp2_neg(c);
-            rx = x3;
-            ry = y3;
-            out.st(4 * k + 0, g.c0);
-            out.st(4 * k + 1, g.c1);
-            out.st(4 * k + 2, f.c0);
-            out.st(4 * k + 3, f.c1);
-            k++;
-        }
+        prepare_dbl_step(e, rx, ry, fp2_inv(ry), out, k++);
+        if ((BLSW_X_ABS >> i) & 1) prepare_add_step(e, q.x, q.y, rx, ry, fp2_inv(fp2_sub(q.x, rx)), out, k++);
     }
 }
 

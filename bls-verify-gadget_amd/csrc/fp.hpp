@@ -502,16 +502,26 @@ template <int K>
 BLSW_HD uint32_t quad_bcast_u32(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, K * 0x55, 0xf, 0xf, true);
 }
+// selects on VALUES (a conditional on two lvalues is an lvalue: the compiler would select addresses, and the operands could not leave memory)
 BLSW_HD Fp quad_sel2(uint32_t role, const Fp& a, const Fp& b) {  // even lanes a, odd lanes b
+    const bool odd = (role & 1u) != 0;
     Fp r;
 #pragma unroll
-    for (int i = 0; i < 12; i++) r.l[i] = (role & 1u) ? b.l[i] : a.l[i];
+    for (int i = 0; i < 12; i++) {
+        const uint32_t x = a.l[i], y = b.l[i];
+        r.l[i] = odd ? y : x;
+    }
     return r;
 }
 BLSW_HD Fp quad_sel3(uint32_t role, const Fp& a, const Fp& b, const Fp& c) {  // lane 0 (and 3) a, lane 1 b, lane 2 c
+    const bool is1 = role == 1u, is2 = role == 2u;
     Fp r;
 #pragma unroll
-    for (int i = 0; i < 12; i++) r.l[i] = role == 1u ? b.l[i] : (role == 2u ? c.l[i] : a.l[i]);
+    for (int i = 0; i < 12; i++) {
+        const uint32_t x = a.l[i], y = b.l[i], z = c.l[i];
+        const uint32_t t = is2 ? z : x;
+        r.l[i] = is1 ? y : t;
+    }
     return r;
 }
 #endif

@@ -5,15 +5,11 @@
 //   k_cofv_acc     phase 3, one lane per chunk: the chunk's additions as a mixed Jacobian chain, 1 / Z as values
 //   k_cofv_add_w   phase 4, one lane per addition: its eight witnesses
 //   k_cofv_join    phase 5, one lane per pair: folds the chunks (the statements of k_cofactor_join)
-// Two compilations (build.py): this one (programs inlined, two waves per SIMD) and the latency compilation (-DBLSW_KVARIANT_QUAD:
+// Two compilations (build.py): this one (programs inlined; the parallel phases at two waves per SIMD) and the latency compilation (-DBLSW_KVARIANT_QUAD:
 // k_cofv_chain_q, k_cofv_acc_q — the two serial phases on the four lanes of a quad, fp.hpp).
 #define BLSW_INLINE_CHAINS 1
 #include "kcommon.hpp"
-#ifdef BLSW_KVARIANT_QUAD
-#define BLSW_CHAIN_ATTR
-#else
-#define BLSW_CHAIN_ATTR BLSW_ATTR_W2
-#endif
+#define BLSW_CHAIN_ATTR  // the serial phases and the join: the whole register file (at 256 registers the join spills 2 000 into its additions)
 
 namespace blsw {
 
@@ -39,7 +35,7 @@ __global__ __launch_bounds__(64) BLSW_CHAIN_ATTR void BLSW_K(k_cofv_acc)(Group g
 #ifndef BLSW_KVARIANT_QUAD
 // thread t -> (doubling D = t / N, pair I = t % N): the lanes of a wave share D (N is a multiple of 64, or the tail wave mixes two), so its ten
 // witness rows are whole 3 KiB rows of the wave's staging tile and its scratch reads are contiguous
-__global__ __launch_bounds__(64) BLSW_CHAIN_ATTR void k_cofv_dbl_w(Group g) {
+__global__ __launch_bounds__(64) BLSW_ATTR_W2 void k_cofv_dbl_w(Group g) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, N = g.N;
     if (t >= (uint64_t)BLSW_H_EFF_NBITS * N) return;
     const uint32_t D = (uint32_t)(t / N);
@@ -49,7 +45,7 @@ __global__ __launch_bounds__(64) BLSW_CHAIN_ATTR void k_cofv_dbl_w(Group g) {
 }
 
 // thread t -> (addition a = t / N over the three chunks' additions in order, pair I = t % N)
-__global__ __launch_bounds__(64) BLSW_CHAIN_ATTR void k_cofv_add_w(Group g) {
+__global__ __launch_bounds__(64) BLSW_ATTR_W2 void k_cofv_add_w(Group g) {
     constexpr CofvPlan plan = cofv_plan();
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, N = g.N;
     const uint32_t total = plan.n_adds[0] + plan.n_adds[1] + plan.n_adds[2];

@@ -15,16 +15,11 @@
 
 namespace blsw {
 
-// which = 0: prepare_g2(H(m)) ; which = 1: prepare_g2(sig)
-__global__ __launch_bounds__(64) BLSW_CHAIN_ATTR void BLSW_K(k_prepare)(Group g, int which) {
-    if (g.chain_prio) __builtin_amdgcn_s_setprio(3);  // latency-critical chain: win VALU issue arbitration against the streaming placement waves
-    const uint64_t I = item_index();  // latency compilation (k_prepare_q): four lanes per item
-    if (I >= g.N) return;
-    LaneId id = lane_id(g, I);
-    const uint64_t N = g.N;
+// the point a prepare chain starts from: which = 0: H(m) from the workspace; which = 1: the signature (the identity as (0, 1, 0))
+__device__ __forceinline__ Proj<OpsFp2> prepare_point(const Group& g, const LaneId& id, uint64_t I, int which) {
     Proj<OpsFp2> q;
     if (which == 0) {
-        q = ld_proj2(g.ws.h + I, N);
+        q = ld_proj2(g.ws.h + I, g.N);
     } else {
         const Fp* p = reinterpret_cast<const Fp*>(g.desc[id.s].sig + (uint64_t)id.i * 24);
         Fp2 sx = {ld_fp(p), ld_fp(p + 1)}, sy = {ld_fp(p + 2), ld_fp(p + 3)};
@@ -33,8 +28,41 @@ __global__ __launch_bounds__(64) BLSW_CHAIN_ATTR void BLSW_K(k_prepare)(Group g,
         q.y = inf ? fp2_one() : sy;
         q.z = inf ? fp2_zero() : fp2_one();
     }
-    CoeffStrided out = which == 0 ? CoeffStrided{g.ws.coeff_h + I, N} : CoeffStrided{g.ws.coeff_sig + I, g.ws.n_sig};
-    chain_prepare_g2(which == 0 ? EMITJ(g, id, off_prep_h, stride_prep_h) : EMIT(g, id, off_prep_sig), q, out);
+    return q;
 }
+#define BLSW_PREPARE_EMIT(g, id, which) ((which) == 0 ? EMITJ(g, id, off_prep_h, stride_prep_h) : EMIT(g, id, off_prep_sig))
+#define BLSW_PREPARE_OUT(g, I, which) ((which) == 0 ? CoeffStrided{(g).ws.coeff_h + (I), (g).N} : CoeffStrided{(g).ws.coeff_sig + (I), (g).ws.n_sig})
+#define BLSW_PREPARE_SCR(g, I, which) ((which) == 0 ? CoeffStrided{(g).ws.prepv_h + (I), (g).N} : CoeffStrided{(g).ws.prepv_sig + (I), (g).ws.n_sig})
+
+// which = 0: prepare_g2(H(m)) ; which = 1: prepare_g2(sig)
+__global__ __launch_bounds__(64) BLSW_CHAIN_ATTR void BLSW_K(k_prepare)(Group g, int which) {
+    if (g.chain_prio) __builtin_amdgcn_s_setprio(3);  // latency-critical chain: win VALU issue arbitration against the streaming placement waves
+    const uint64_t I = item_index();  // latency compilation (k_prepare_q): four lanes per item
+    if (I >= g.N) return;
+    LaneId id = lane_id(g, I);
+    chain_prepare_g2(BLSW_PREPARE_EMIT(g, id, which), prepare_point(g, id, I, which), BLSW_PREPARE_OUT(g, I, which));
+}
+
+#ifndef BLSW_KVARIANT_INL
+// values first (prepare_vf.hpp), phase 1: to_affine (witnesses) and the chain of points as Jacobian values, one lane (or one quad) per point
+__global__ __launch_bounds__(64) BLSW_CHAIN_ATTR void BLSW_K(k_prepv_chain)(Group g, int which) {
+    if (g.chain_prio) __builtin_amdgcn_s_setprio(3);
+    const uint64_t I = item_index();
+    if (I >= g.N) return;
+    LaneId id = lane_id(g, I);
+    prepv_chain(BLSW_PREPARE_EMIT(g, id, which), prepare_point(g, id, I, which), BLSW_PREPARE_SCR(g, I, which));
+}
+#endif
+#if !defined(BLSW_KVARIANT_INL) && !defined(BLSW_KVARIANT_QUAD)
+// phase 2: thread t -> (step k = t / N, point I = t % N): the step's witnesses and line coefficients
+__global__ __launch_bounds__(64) BLSW_CHAIN_ATTR void k_prepv_step_w(Group g, int which) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, N = g.N;
+    if (t >= (uint64_t)BLSW_PREPV_STEPS * N) return;
+    const uint32_t k = (uint32_t)(t / N);
+    const uint64_t I = t - (uint64_t)k * N;
+    LaneId id = lane_id(g, I);
+    prepv_step_w(BLSW_PREPARE_EMIT(g, id, which), k, BLSW_PREPARE_SCR(g, I, which), BLSW_PREPARE_OUT(g, I, which));
+}
+#endif
 
 }  // namespace blsw

@@ -10,6 +10,7 @@
 #endif
 #include "chains.hpp"
 #include "cofactor_vf.hpp"
+#include "prepare_vf.hpp"
 #include "layout.h"
 
 namespace blsw {
@@ -49,6 +50,8 @@ struct Workspace {
     uint32_t pair_rows;  // (split_row = staging_rows, pair_rows = 0 when the single-lane pairing kernel is in use)
     uint64_t sha_words;
     Fp* cofv;            // [BLSW_COFV_ELEMS][N] scratch of the values-first cofactor chain (cofactor_vf.hpp), or nullptr (N > BLSW_LATENCY_MAX_LANES)
+    Fp* prepv_h;         // [BLSW_PREPV_ELEMS][N] / [BLSW_PREPV_ELEMS][n_sig] scratch of the values-first prepare chains (prepare_vf.hpp), or nullptr
+    Fp* prepv_sig;
     uint64_t total_bytes;
 };
 // launch groups of at most this many lanes may take the latency kernels (quads, values-first cofactor chain): their scratch is carved for them
@@ -138,7 +141,10 @@ inline Workspace carve(void* base, uint64_t N, const blsw_layout_t& L, bool with
     w.coeff_sig = reinterpret_cast<Fp*>(take(272ull * n_sig * sizeof(Fp)));
     w.n_sig = n_sig;
     w.keyproj = L.n_keys ? reinterpret_cast<Fp*>(take(3ull * N * L.n_keys * sizeof(Fp))) : nullptr;
-    w.cofv = N <= BLSW_LATENCY_MAX_LANES ? reinterpret_cast<Fp*>(take((uint64_t)BLSW_COFV_ELEMS * N * sizeof(Fp))) : nullptr;
+    const bool small = N <= BLSW_LATENCY_MAX_LANES;  // (not a test of a carved pointer: with base == nullptr the carve only measures)
+    w.cofv = small ? reinterpret_cast<Fp*>(take((uint64_t)BLSW_COFV_ELEMS * N * sizeof(Fp))) : nullptr;
+    w.prepv_h = small ? reinterpret_cast<Fp*>(take((uint64_t)BLSW_PREPV_ELEMS * N * sizeof(Fp))) : nullptr;
+    w.prepv_sig = small ? reinterpret_cast<Fp*>(take((uint64_t)BLSW_PREPV_ELEMS * n_sig * sizeof(Fp))) : nullptr;
     w.staging_rows = L.n_witness - L.sha_bits;
     if (L.n_pairs > 1 && with_staging) {  // N+1-pair product in the grouped engine: pair tiles, instance tiles, instance-major rows
         const MultiStaging ms = staging_layout_multi(L);
@@ -375,6 +381,10 @@ __global__ void k_cofactor_join_inl(Group g);
 __global__ void k_map_q(Group g);
 __global__ void k_prepare_q(Group g, int which);
 __global__ void k_g2_alloc_q(Group g);
+// values-first prepare chains (prepare_vf.hpp; k_prepare.hip): the serial value phase per point, then one lane per step
+__global__ void k_prepv_chain(Group g, int which);
+__global__ void k_prepv_chain_q(Group g, int which);
+__global__ void k_prepv_step_w(Group g, int which);
 // values-first cofactor chain (cofactor_vf.hpp; k_cofv.hip): serial value phases (one lane or one quad per item), parallel witness phases, join
 __global__ void k_cofv_chain(Group g);
 __global__ void k_cofv_chain_q(Group g);
@@ -481,7 +491,13 @@ inline void launch_map(const ChainKernels& ck, Latency lat, const Group& g, hipS
         hipLaunchKernelGGL(ck.map, dim3(item_grid(2 * g.N, 1)), dim3(64), 0, st, g);
 }
 inline void launch_prepare(const ChainKernels& ck, Latency lat, const Group& g, int which, hipStream_t st) {
-    if (lat.quad)
+    if (lat.vf && g.ws.prepv_h) {
+        if (lat.quad)
+            hipLaunchKernelGGL(k_prepv_chain_q, dim3(item_grid(g.N, 4)), dim3(64), 0, st, g, which);
+        else
+            hipLaunchKernelGGL(k_prepv_chain, dim3(item_grid(g.N, 1)), dim3(64), 0, st, g, which);
+        hipLaunchKernelGGL(k_prepv_step_w, dim3(item_grid((uint64_t)BLSW_PREPV_STEPS * g.N, 1)), dim3(64), 0, st, g, which);
+    } else if (lat.quad)
         hipLaunchKernelGGL(k_prepare_q, dim3(item_grid(g.N, 4)), dim3(64), 0, st, g, which);
     else
         hipLaunchKernelGGL(ck.prepare, dim3(item_grid(g.N, 1)), dim3(64), 0, st, g, which);

@@ -12,6 +12,7 @@
 #include "../../bls-verify-gadget_amd/csrc/miller_par.hpp"
 #include "../../bls-verify-gadget_amd/csrc/cofactor_par.hpp"
 #include "../../bls-verify-gadget_amd/csrc/cofactor_vf.hpp"
+#include "../../bls-verify-gadget_amd/csrc/prepare_vf.hpp"
 #include <array>
 
 using namespace blsw;
@@ -171,6 +172,16 @@ static bool pairing_segment(uint32_t* base, const blsw_layout_t& L, const Fp& ax
     return r;
 }
 
+static int g_prepare_vf = 0;  // 1: prepare_g2 through prepare_vf.hpp (value chain, then the steps in reverse order)
+static void run_prepare(Emitter e, const Proj<OpsFp2>& q, const CoeffLinear& out) {
+    if (!g_prepare_vf) {
+        chain_prepare_g2(e, q, out);
+        return;
+    }
+    std::vector<Fp> scr(BLSW_PREPV_ELEMS);
+    prepv_chain(e, q, CoeffLinear{scr.data()});
+    for (int k = BLSW_PREPV_STEPS - 1; k >= 0; k--) prepv_step_w(e, (uint32_t)k, CoeffLinear{scr.data()}, out);
+}
 struct ParkHost {
     Jac2* p;
     void st(int slot, const Jac2& v) const { p[slot] = v; }
@@ -197,6 +208,7 @@ static Proj<OpsFp2> run_cofactor(Emitter e_add, Emitter e, const Proj<OpsFp2>& q
 extern "C" {
 void hostsim_use_team(int on) { g_use_team = on; }
 void hostsim_cofactor_par(int on) { g_cofactor_par = on; }
+void hostsim_prepare_vf(int on) { g_prepare_vf = on; }
 void hostsim_miller_chunk(uint32_t b) { g_miller_chunk = b ? b : 1; }
 int hostsim_layout(uint32_t msg_len, blsw_layout_t* L) {
     make_layout(msg_len, L);
@@ -248,10 +260,10 @@ int hostsim_witness_params(const uint64_t* pk_xy, const uint8_t* msg, uint32_t m
     Proj<OpsFp2> q1 = chain_map_to_curve({base, L.off_map1}, u1);
     Proj<OpsFp2> h = run_cofactor({base, L.off_add}, {base, L.off_cofactor}, q0, q1);
     std::vector<Fp> ch(68 * 4), cs(68 * 4);
-    chain_prepare_g2({base, L.off_prep_h}, h, CoeffLinear{ch.data()});
+    run_prepare({base, L.off_prep_h}, h, CoeffLinear{ch.data()});
     bool sinf = fp2_is_zero(sx) && fp2_is_zero(sy);
     Proj<OpsFp2> sp = {sinf ? fp2_zero() : sx, sinf ? fp2_one() : sy, sinf ? fp2_zero() : fp2_one()};
-    chain_prepare_g2({base, L.off_prep_sig}, sp, CoeffLinear{cs.data()});
+    run_prepare({base, L.off_prep_sig}, sp, CoeffLinear{cs.data()});
     bool res = pairing_segment(base, L, g1.ax, g1.ay, cs.data(), ch.data());
     return res ? 1 : 0;
 }
@@ -294,14 +306,14 @@ int hostsim_witness_multi(const uint64_t* pks_xy, const uint8_t* msgs, uint32_t 
         Proj<OpsFp2> q0 = chain_map_to_curve({base, L.off_map0 + ho}, u0);
         Proj<OpsFp2> q1 = chain_map_to_curve({base, L.off_map1 + ho}, u1);
         Proj<OpsFp2> h = run_cofactor({base, L.off_add + ho}, {base, L.off_cofactor + ho}, q0, q1);
-        chain_prepare_g2({base, L.off_prep_h + j * L.stride_prep_h}, h, CoeffLinear{ch[j].data()});
+        run_prepare({base, L.off_prep_h + j * L.stride_prep_h}, h, CoeffLinear{ch[j].data()});
     }
     Fp2 sx = {load_fp(sig_xy), load_fp(sig_xy + 6)}, sy = {load_fp(sig_xy + 12), load_fp(sig_xy + 18)};
     g2_alloc_segment(base, L, sx, sy);
     std::vector<Fp> cs(68 * 4);
     bool sinf = fp2_is_zero(sx) && fp2_is_zero(sy);
     Proj<OpsFp2> sp = {sinf ? fp2_zero() : sx, sinf ? fp2_one() : sy, sinf ? fp2_zero() : fp2_one()};
-    chain_prepare_g2({base, L.off_prep_sig}, sp, CoeffLinear{cs.data()});
+    run_prepare({base, L.off_prep_sig}, sp, CoeffLinear{cs.data()});
     if (g_use_team == 2) {  // miller_par.hpp: the four phases of the pair-parallel Miller product, tasks run one after the other
         HostPairs hp = {&ch, &pk};
         const uint32_t B = g_miller_chunk, C = miller_chunks(K, B), S = BLSW_MILLER_STEPS;
@@ -374,7 +386,7 @@ int hostsim_witness_aggregate(const uint64_t* pks_xy, const uint8_t* bitmap, uin
     chain_prepare_g2({base, L.off_prep_h}, hh, CoeffLinear{ch.data()});
     bool sinf = fp2_is_zero(sx) && fp2_is_zero(sy);
     Proj<OpsFp2> sp = {sinf ? fp2_zero() : sx, sinf ? fp2_one() : sy, sinf ? fp2_zero() : fp2_one()};
-    chain_prepare_g2({base, L.off_prep_sig}, sp, CoeffLinear{cs.data()});
+    run_prepare({base, L.off_prep_sig}, sp, CoeffLinear{cs.data()});
     Fp12 fm = chain_miller({base, L.off_miller}, g1.ax, g1.ay, CoeffLinear{cs.data()}, CoeffLinear{ch.data()});
     bool res = chain_final_exp_is_one({base, L.off_final_exp}, {base, L.off_is_one}, fm);
     return res ? 1 : 0;

@@ -467,6 +467,24 @@ def test_cofactor_values_first_device_logic(oracle):
         lib.hostsim_cofactor_par(0)
 
 
+def test_prepare_values_first_device_logic(oracle):
+    """prepare_vf.hpp: the 63 doublings + 5 additions of G2PreparedVar::from_group_var as one Jacobian value chain (one inversion, the other
+    1 / Z by the backward recurrence) and every step's witnesses / line coefficients derived independently (steps in reverse order here): the
+    whole witness vector — the pairing consumes the coefficients — stays bit-exact, incl. identity inputs, the N+1-pair circuit and the team program."""
+    lib = hostsim_lib.load()
+    lib.hostsim_prepare_vf(1)
+    try:
+        pk, msg, sig, _ = synth.make_batch(oracle, 16)
+        assert _check(oracle, pk[3], msg[3].tobytes(), sig[3]) is True
+        assert _check(oracle, pk[15], msg[15].tobytes(), sig[15]) is False
+        _check(oracle, np.zeros(12, dtype=np.uint64), msg[0].tobytes(), np.zeros(24, dtype=np.uint64))
+        lib.hostsim_use_team(1)
+        _check(oracle, pk[1], b"x" * 3, sig[1])
+    finally:
+        lib.hostsim_use_team(0)
+        lib.hostsim_prepare_vf(0)
+
+
 def test_cofactor_chunks_when_the_sum_is_the_identity(oracle):
     """Q0 = -Q1 (not reachable by hashing): the circuit's affine chain then runs on (0, 0) with zero inverse hints. The chunked
     program must follow those values step by step (its Jacobian shortcut would compute a different, mathematically meaningful
