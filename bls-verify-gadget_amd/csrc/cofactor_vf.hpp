@@ -9,8 +9,8 @@
 //     1 / Z_i = 2 Y_i / Z_{i+1}, and the slope of doubling i is 3 X_i^2 / Z_{i+1} (3 x^2 / 2 y with x = X / Z^2, y = Y / Z^3);
 //   * the additions of a chunk are a chain of mixed Jacobian additions (madd-2007-bl, Z3 = 2 Z1 H) with the affine 2^i P as the second
 //     operand: again one inversion per chunk, 1 / Z1_j = 2 H_j / Z1_{j+1}, and the slope of addition j is r_j / Z1_{j+1}.
-// So: two short serial value programs (phase 1: the doubling chain of an instance; phase 3: the addition chain of a chunk) and two
-// embarrassingly parallel witness programs (phase 2: one lane per doubling; phase 4: one lane per addition) that recompute the affine
+// So: two short serial value programs (phase 1: the doubling chain of an instance; phase 3: the addition chain of a chunk) and
+// embarrassingly parallel programs (phase 2a: the affine 2^D P, 2b: one lane per doubling; phase 4: one lane per addition) that recompute the affine
 // operands, multiply out the slope and emit exactly the witnesses of curve.hpp's nz_double_pre_inl / nz_add_unchecked_pre_inl at the
 // step's place in the segment (cofv_plan: a compile-time walk over the bits of h_eff). Phase 5 folds the chunks (the statements of
 // cofactor_par.hpp's join with the tail doublings already emitted).
@@ -83,7 +83,7 @@ static_assert(cofv_plan().total == 8979, "cofactor segment: the plan must count 
 static_assert(cofv_plan().n_adds[0] < BLSW_COFV_MAX_ADDS && cofv_plan().n_adds[1] < BLSW_COFV_MAX_ADDS && cofv_plan().n_adds[2] < BLSW_COFV_MAX_ADDS, "cofv: additions per chunk");
 
 // scratch of one instance, in field elements; S::st(elem, Fp) / S::ld(elem) (element-major rows on the device, an array on the host)
-//   XY(D)   Jacobian (X, Y) of 2^D P after phase 1; phase 2 overwrites it with the affine point
+//   XY(D)   Jacobian (X, Y) of 2^D P (phase 1);  AF(D) the affine point (phase 2a)
 //   ZI(D)   1 / Z_D, D = 0 .. 636 (ZI(0) = 1)
 //   AC(c,j) addition j of chunk c: X1, Y1 (the accumulator before it), r, H; AZ(c,j) = 1 / Z1 before addition j (AZ(c, 0) = 1)
 #define BLSW_COFV_XY(D) (4u * (uint32_t)(D))
@@ -91,7 +91,9 @@ static_assert(cofv_plan().n_adds[0] < BLSW_COFV_MAX_ADDS && cofv_plan().n_adds[1
 #define BLSW_COFV_ACC0 (4u * BLSW_H_EFF_NBITS + 2u * (BLSW_H_EFF_NBITS + 1))
 #define BLSW_COFV_AC(c, j) (BLSW_COFV_ACC0 + (uint32_t)(c) * 10u * (BLSW_COFV_MAX_ADDS + 1) + 10u * (uint32_t)(j))
 #define BLSW_COFV_AZ(c, j) (BLSW_COFV_AC(c, j) + 8u)
-#define BLSW_COFV_ELEMS (BLSW_COFV_ACC0 + 3u * 10u * (BLSW_COFV_MAX_ADDS + 1))
+#define BLSW_COFV_AFF0 (BLSW_COFV_ACC0 + 3u * 10u * (BLSW_COFV_MAX_ADDS + 1))
+#define BLSW_COFV_AF(D) (BLSW_COFV_AFF0 + 4u * (uint32_t)(D))
+#define BLSW_COFV_ELEMS (BLSW_COFV_AFF0 + 4u * BLSW_H_EFF_NBITS)
 
 template <class S>
 BLSW_HD void cofv_st2(const S& s, uint32_t el, const Fp2& v) {
@@ -112,17 +114,10 @@ BLSW_FN void cofv_chain(Emitter e_add, Emitter e, const Proj<OpsFp2>& q0, const 
     rows.st(36, ra.infinity ? fp_one() : fp_zero());
     Fp2 X = ra.x, Y = ra.y, Z = fp2_one();
 #pragma unroll 1
-    for (int D = 0; D < BLSW_H_EFF_NBITS; D++) {  // dbl-2009-l, a = 0 (vcurve.hpp: v_dbl)
+    for (int D = 0; D < BLSW_H_EFF_NBITS; D++) {  // dbl-2009-l, a = 0 (vcurve.hpp: on a quad, four product rounds per step)
         cofv_st2(scr, BLSW_COFV_XY(D), X);
         cofv_st2(scr, BLSW_COFV_XY(D) + 2, Y);
-        const Fp2 A = v_sqr(X), B = v_sqr(Y), C = v_sqr(B);
-        const Fp2 Dd = fp2_dbl(fp2_sub(fp2_sub(v_sqr(fp2_add(X, B)), A), C));
-        const Fp2 E = fp2_add(fp2_dbl(A), A);
-        const Fp2 x3 = fp2_sub(v_sqr(E), fp2_dbl(Dd));
-        const Fp2 y3 = fp2_sub(fp2_mul_inl(E, fp2_sub(Dd, x3)), fp2_dbl(fp2_dbl(fp2_dbl(C))));
-        Z = fp2_dbl(fp2_mul_inl(Y, Z));
-        X = x3;
-        Y = y3;
+        v_dbl_inplace(X, Y, Z);
     }
     // 1 / Z_D backwards from the last: Z_{D+1} = 2 Y_D Z_D
     Fp2 zi = fp2_inv_inl(Z);
@@ -135,14 +130,21 @@ BLSW_FN void cofv_chain(Emitter e_add, Emitter e, const Proj<OpsFp2>& q0, const 
     cofv_st2(scr, BLSW_COFV_ZI(0), fp2_one());
 }
 
-// ---- phase 2 (one lane per doubling D of an instance): the ten witnesses of nz_double_pre_inl on 2^D P; leaves the affine point in XY(D)
+// ---- phase 2a (one lane per doubling index D of an instance): the affine 2^D P — what the addition chains wait for
+template <class S>
+BLSW_FN void cofv_affine(uint32_t D, const S& scr) {
+    const Fp2 X = cofv_ld2(scr, BLSW_COFV_XY(D)), Y = cofv_ld2(scr, BLSW_COFV_XY(D) + 2), zi = cofv_ld2(scr, BLSW_COFV_ZI(D));
+    const Fp2 zi2 = v_sqr(zi);
+    cofv_st2(scr, BLSW_COFV_AF(D), fp2_mul_inl(X, zi2));
+    cofv_st2(scr, BLSW_COFV_AF(D) + 2, fp2_mul_inl(Y, fp2_mul_inl(zi2, zi)));
+}
+// ---- phase 2b (one lane per doubling D of an instance): the ten witnesses of nz_double_pre_inl on 2^D P. Nothing waits for it but the
+// placement of the segment: the engine runs it beside the addition chains
 template <class S>
 BLSW_FN void cofv_dbl_w(Emitter e, uint32_t D, const S& scr) {
     constexpr CofvPlan plan = cofv_plan();
-    const Fp2 X = cofv_ld2(scr, BLSW_COFV_XY(D)), Y = cofv_ld2(scr, BLSW_COFV_XY(D) + 2);
-    const Fp2 zi = cofv_ld2(scr, BLSW_COFV_ZI(D)), zn = cofv_ld2(scr, BLSW_COFV_ZI(D + 1));
-    const Fp2 zi2 = v_sqr(zi);
-    const Aff2 p = {fp2_mul_inl(X, zi2), fp2_mul_inl(Y, fp2_mul_inl(zi2, zi))};
+    const Fp2 X = cofv_ld2(scr, BLSW_COFV_XY(D)), zn = cofv_ld2(scr, BLSW_COFV_ZI(D + 1));
+    const Aff2 p = {cofv_ld2(scr, BLSW_COFV_AF(D)), cofv_ld2(scr, BLSW_COFV_AF(D) + 2)};
     const Fp2 A = v_sqr(X);
     const Fp2 lambda = fp2_mul_inl(fp2_add(fp2_dbl(A), A), zn);
     e.pos += plan.pos_dbl[D];
@@ -153,8 +155,6 @@ BLSW_FN void cofv_dbl_w(Emitter e, uint32_t D, const S& scr) {
     const Fp2 l2 = fp2_sqr_w(e, lambda);
     const Fp2 x3 = fp2_sub(l2, fp2_dbl(p.x));
     (void)fp2_mul_w(e, lambda, fp2_sub(p.x, x3));
-    cofv_st2(scr, BLSW_COFV_XY(D), p.x);
-    cofv_st2(scr, BLSW_COFV_XY(D) + 2, p.y);
 }
 
 // ---- phase 3 (one lane, or one quad, per chunk of an instance): the additions of the chunk's loop as a mixed Jacobian chain.
@@ -163,13 +163,13 @@ template <class S, class ST>
 BLSW_FN void cofv_acc_chain(int c, const S& scr, const ST& rows) {
     constexpr CofvPlan plan = cofv_plan();
     const int off = 255 * c;
-    const Fp2 x0 = cofv_ld2(scr, BLSW_COFV_XY(off)), y0 = cofv_ld2(scr, BLSW_COFV_XY(off) + 2);
+    const Fp2 x0 = cofv_ld2(scr, BLSW_COFV_AF(off)), y0 = cofv_ld2(scr, BLSW_COFV_AF(off) + 2);
     Fp2 X1 = x0, Y1 = y0, Z1 = fp2_one();
     const uint32_t na = plan.n_adds[c];
 #pragma unroll 1
     for (uint32_t j = 0; j < na; j++) {  // madd-2007-bl with Z3 = 2 Z1 H
         const uint32_t D = plan.add_bit[c][j];
-        const Fp2 x2 = cofv_ld2(scr, BLSW_COFV_XY(D)), y2 = cofv_ld2(scr, BLSW_COFV_XY(D) + 2);
+        const Fp2 x2 = cofv_ld2(scr, BLSW_COFV_AF(D)), y2 = cofv_ld2(scr, BLSW_COFV_AF(D) + 2);
         const Fp2 z1z1 = v_sqr(Z1);
         const Fp2 u2 = fp2_mul_inl(x2, z1z1);
         const Fp2 s2 = fp2_mul_inl(fp2_mul_inl(y2, Z1), z1z1);
@@ -214,7 +214,7 @@ BLSW_FN void cofv_add_w(Emitter e, int c, uint32_t j, const S& scr) {
     const Fp2 zi = cofv_ld2(scr, BLSW_COFV_AZ(c, j)), zn = cofv_ld2(scr, BLSW_COFV_AZ(c, j + 1));
     const Fp2 zi2 = v_sqr(zi);
     const Aff2 p = {fp2_mul_inl(X1, zi2), fp2_mul_inl(Y1, fp2_mul_inl(zi2, zi))};
-    const Fp2 qx = cofv_ld2(scr, BLSW_COFV_XY(D));
+    const Fp2 qx = cofv_ld2(scr, BLSW_COFV_AF(D));
     const Fp2 lambda = fp2_mul_inl(rr, zn);
     e.pos += plan.pos_add[c][j];
     e.put(lambda.c0);
@@ -226,7 +226,7 @@ BLSW_FN void cofv_add_w(Emitter e, int c, uint32_t j, const S& scr) {
 }
 
 // ---- phase 5 (one lane per instance): chain_cofactor_join's statements; the tail doublings of chunks 0 and 1 were emitted by phase 2,
-// their operands are the affine points phase 2 left in XY
+// their operands are the affine points of phase 2a
 template <class S, class LD>
 BLSW_FN Proj<OpsFp2> cofv_join(Emitter e, const S& scr, const LD& load) {
     constexpr CofactorPlan plan = cofactor_plan();
@@ -259,7 +259,7 @@ BLSW_FN Proj<OpsFp2> cofv_join(Emitter e, const S& scr, const LD& load) {
 #pragma unroll 1
         for (int i = split; i < n; i++) {
             if (bit_of(HE, off + i)) {
-                Proj<OpsFp2> m = {cofv_ld2(scr, BLSW_COFV_XY(off + i)), cofv_ld2(scr, BLSW_COFV_XY(off + i) + 2), fp2_one()};
+                Proj<OpsFp2> m = {cofv_ld2(scr, BLSW_COFV_AF(off + i)), cofv_ld2(scr, BLSW_COFV_AF(off + i) + 2), fp2_one()};
                 mul_result = proj_add_zstate_w(e, mul_result, mr_state, m, 2);
                 mr_state = 0;
             }

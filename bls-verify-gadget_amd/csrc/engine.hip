@@ -76,6 +76,7 @@ struct GroupBuf {
     hipStream_t st[2] = {nullptr, nullptr};  // main, aux (a second aux stream for prepare(sig) / the key chains beside the G2 allocation measured slower:
                                              // profiles/r03_ab_chain_builds.txt section 7)
     hipEvent_t ev_start = nullptr, ev_aux = nullptr, ev_sha = nullptr, ev_chains = nullptr, ev_done = nullptr;
+    hipEvent_t ev_cof_aff = nullptr, ev_cof_acc = nullptr, ev_side = nullptr;  // values-first cofactor chain: its witness phases run on the aux stream
     hipEvent_t* ev_in = nullptr;    // [max_steps] inputs of step s valid (recorded on the submitting stream)
     hipEvent_t* ev_x = nullptr;     // [max_steps] expansion of step s issued and finished
     hipEvent_t* ev_step = nullptr;  // [max_steps] step s complete (witness tensor + results)
@@ -126,7 +127,7 @@ static void engine_free(blsw_engine* e) {
         if (b.d_desc) hipFree(b.d_desc);
         for (int i = 0; i < 2; i++)
             if (b.st[i]) hipStreamDestroy(b.st[i]);
-        hipEvent_t single[] = {b.ev_start, b.ev_aux, b.ev_sha, b.ev_chains, b.ev_done};
+        hipEvent_t single[] = {b.ev_start, b.ev_aux, b.ev_sha, b.ev_chains, b.ev_done, b.ev_cof_aff, b.ev_cof_acc, b.ev_side};
         for (hipEvent_t ev : single)
             if (ev) hipEventDestroy(ev);
         hipEvent_t* arrays[] = {b.ev_in, b.ev_x, b.ev_step};
@@ -333,6 +334,9 @@ static int launch_group(blsw_engine* e) {
     const bool cold_small = e->opt.chain_variant == 0 && small && idle;
     const ChainKernels ck = chain_kernels(e->chains_inlined || cold_small);
     const bool chunked = e->cofactor_mode == 2 || (e->cofactor_mode == 0 && g.N <= BLSW_COFACTOR_CHUNKED_MAX_LANES);
+    // values-first cofactor chain: its per-doubling / per-addition witness phases go to the aux stream, behind the aux chains (enqueued below)
+    const CofactorSide cof_side = {b.st[1], b.ev_cof_aff, b.ev_cof_acc};
+    const bool cof_deferred = lat.vf && g.ws.cofv != nullptr;
     hipStream_t st = b.st[0];
     // inputs of every step are ready once its submitting stream reached the point of the submit
     for (uint32_t s = 0; s < steps; s++) hipStreamWaitEvent(st, b.ev_in[s], 0);
@@ -355,13 +359,14 @@ static int launch_group(blsw_engine* e) {
         gs.K = 1;
         hipLaunchKernelGGL(k_sha_values, dim3(g1), dim3(64), 0, st, g);
         launch_map(ck, lat, g, st);
-        launch_cofactor(ck, lat, chunked, g, st);
+        launch_cofactor(ck, lat, chunked, g, st, &cof_side);
         launch_prepare(ck, lat, g, 0, st);
         launch_g2_alloc(ck, lat, gs, b.st[1]);
         launch_prepare(ck, lat, gs, 1, b.st[1]);
         hipLaunchKernelGGL(ck.g1, dim3(g1), dim3(64), 0, b.st[1], g);
         hipEventRecord(b.ev_aux, b.st[1]);
         hipStreamWaitEvent(st, b.ev_aux, 0);
+        if (cof_deferred) launch_cofactor_witness(g, cof_side);
         if (K < BLSW_MILLER_PAR_MIN_PAIRS) {
             hipLaunchKernelGGL(k_pairing_team_multi, dim3((unsigned)((gs.N + BLSW_TEAMS_PER_WAVE - 1) / BLSW_TEAMS_PER_WAVE)), dim3(64), 0, st, gs, K, g.N);
         } else {
@@ -388,7 +393,7 @@ static int launch_group(blsw_engine* e) {
         // main, first part: the hash-to-G2 critical path
         hipLaunchKernelGGL(k_sha_values, dim3(g1), dim3(64), 0, st, g);
         launch_map(ck, lat, g, st);
-        launch_cofactor(ck, lat, chunked, g, st);
+        launch_cofactor(ck, lat, chunked, g, st, &cof_side);
         launch_prepare(ck, lat, g, 0, st);
         // aux: prepare_g2(sig) and the group allocations (53 ms alone beside the 86 ms of the main stream's first part)
         hipStream_t sb = b.st[1];
@@ -405,9 +410,14 @@ static int launch_group(blsw_engine* e) {
     }
     if (K == 1) {
         hipEventRecord(b.ev_aux, b.st[1]);
+        if (cof_deferred) launch_cofactor_witness(g, cof_side);
         // main, second part: the pairing
         hipStreamWaitEvent(st, b.ev_aux, 0);
         launch_pairing(g, e->modes, st);
+    }
+    if (cof_deferred) {  // the group's chains are done when the deferred witness phases are
+        hipEventRecord(b.ev_side, b.st[1]);
+        hipStreamWaitEvent(st, b.ev_side, 0);
     }
     hipStreamWaitEvent(st, b.ev_sha, 0);
     hipEventRecord(b.ev_chains, st);
@@ -583,7 +593,7 @@ int blsw_engine_create_ex(blsw_engine_t** out, uint64_t n, uint32_t msg_len, uin
         chk(hipMalloc(reinterpret_cast<void**>(&b.d_desc), sizeof(StepDesc) * max_steps), "desc alloc");
         chk(hipStreamCreateWithPriority(&b.st[0], hipStreamNonBlocking, main_prio), "stream create");
         chk(hipStreamCreateWithPriority(&b.st[1], hipStreamNonBlocking, aux_prio), "stream create");
-        hipEvent_t* single[] = {&b.ev_start, &b.ev_aux, &b.ev_sha, &b.ev_chains, &b.ev_done};
+        hipEvent_t* single[] = {&b.ev_start, &b.ev_aux, &b.ev_sha, &b.ev_chains, &b.ev_done, &b.ev_cof_aff, &b.ev_cof_acc, &b.ev_side};
         for (hipEvent_t* ev : single) chk(hipEventCreateWithFlags(ev, hipEventDisableTiming), "event create");
         b.ev_in = new hipEvent_t[max_steps]();
         b.ev_x = new hipEvent_t[max_steps]();

@@ -1,7 +1,8 @@
 // libblsw.so, one translation unit per kernel family (see kcommon.hpp, build.py).
 // clear_cofactor2 "values first" (cofactor_vf.hpp): the latency form of the cofactor segment, for small launch groups.
 //   k_cofv_chain   phase 1, one lane per (pk, msg) pair: Q0 + Q1, to_affine (witnesses), the 636 Jacobian doublings and 1 / Z_D as values
-//   k_cofv_dbl_w   phase 2, one lane per doubling: its ten witnesses; the affine 2^D P
+//   k_cofv_aff     phase 2a, one lane per doubling index: the affine 2^D P
+//   k_cofv_dbl_w   phase 2b, one lane per doubling: its ten witnesses (off the critical path: the engine runs it beside phase 3)
 //   k_cofv_acc     phase 3, one lane per chunk: the chunk's additions as a mixed Jacobian chain, 1 / Z as values
 //   k_cofv_add_w   phase 4, one lane per addition: its eight witnesses
 //   k_cofv_join    phase 5, one lane per pair: folds the chunks (the statements of k_cofactor_join)
@@ -35,6 +36,13 @@ __global__ __launch_bounds__(64) BLSW_CHAIN_ATTR void BLSW_K(k_cofv_acc)(Group g
 #ifndef BLSW_KVARIANT_QUAD
 // thread t -> (doubling D = t / N, pair I = t % N): the lanes of a wave share D (N is a multiple of 64, or the tail wave mixes two), so its ten
 // witness rows are whole 3 KiB rows of the wave's staging tile and its scratch reads are contiguous
+__global__ __launch_bounds__(64) BLSW_ATTR_W2 void k_cofv_aff(Group g) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, N = g.N;
+    if (t >= (uint64_t)BLSW_H_EFF_NBITS * N) return;
+    const uint32_t D = (uint32_t)(t / N);
+    const uint64_t I = t - (uint64_t)D * N;
+    cofv_affine(D, CoeffStrided{g.ws.cofv + I, N});
+}
 __global__ __launch_bounds__(64) BLSW_ATTR_W2 void k_cofv_dbl_w(Group g) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, N = g.N;
     if (t >= (uint64_t)BLSW_H_EFF_NBITS * N) return;

@@ -390,6 +390,7 @@ __global__ void k_cofv_chain(Group g);
 __global__ void k_cofv_chain_q(Group g);
 __global__ void k_cofv_acc(Group g);
 __global__ void k_cofv_acc_q(Group g);
+__global__ void k_cofv_aff(Group g);
 __global__ void k_cofv_dbl_w(Group g);
 __global__ void k_cofv_add_w(Group g);
 __global__ void k_cofv_join(Group g);
@@ -460,22 +461,38 @@ inline ChainKernels chain_kernels(bool inlined) {
 struct Latency {
     bool quad, vf;
 };
-// clear_cofactor2 of N lanes on `st`: values first (five launches), chunked (three lanes per (pk, msg) pair + the join) or as one chain per lane
-inline void launch_cofactor(const ChainKernels& ck, Latency lat, bool chunked, const Group& g, hipStream_t st) {
+// clear_cofactor2 of N lanes on `st`: values first, chunked (three lanes per (pk, msg) pair + the join) or as one chain per lane.
+// Values first with a side stream: the two parallel witness phases (one lane per doubling / addition: nothing but the segment's placement waits for
+// them) are left to launch_cofactor_witness on `side`, after ev_aff / ev_acc which this function records; side == nullptr: everything on `st`.
+struct CofactorSide {
+    hipStream_t side;
+    hipEvent_t ev_aff, ev_acc;
+};
+inline uint64_t cofv_total_adds() {
+    constexpr CofvPlan plan = cofv_plan();
+    return (uint64_t)plan.n_adds[0] + plan.n_adds[1] + plan.n_adds[2];
+}
+inline void launch_cofactor(const ChainKernels& ck, Latency lat, bool chunked, const Group& g, hipStream_t st, const CofactorSide* side = nullptr) {
     const unsigned g1 = item_grid(g.N, 1), g3 = item_grid(3 * g.N, 1);
     if (lat.vf && g.ws.cofv) {
-        constexpr CofvPlan plan = cofv_plan();
-        const uint64_t adds = (uint64_t)plan.n_adds[0] + plan.n_adds[1] + plan.n_adds[2];
+        const unsigned gd = item_grid((uint64_t)BLSW_H_EFF_NBITS * g.N, 1);
         if (lat.quad)
             hipLaunchKernelGGL(k_cofv_chain_q, dim3(item_grid(g.N, 4)), dim3(64), 0, st, g);
         else
             hipLaunchKernelGGL(k_cofv_chain, dim3(g1), dim3(64), 0, st, g);
-        hipLaunchKernelGGL(k_cofv_dbl_w, dim3(item_grid((uint64_t)BLSW_H_EFF_NBITS * g.N, 1)), dim3(64), 0, st, g);
+        hipLaunchKernelGGL(k_cofv_aff, dim3(gd), dim3(64), 0, st, g);
+        if (side)
+            hipEventRecord(side->ev_aff, st);
+        else
+            hipLaunchKernelGGL(k_cofv_dbl_w, dim3(gd), dim3(64), 0, st, g);
         if (lat.quad)
             hipLaunchKernelGGL(k_cofv_acc_q, dim3(item_grid(3 * g.N, 4)), dim3(64), 0, st, g);
         else
             hipLaunchKernelGGL(k_cofv_acc, dim3(g3), dim3(64), 0, st, g);
-        hipLaunchKernelGGL(k_cofv_add_w, dim3(item_grid(adds * g.N, 1)), dim3(64), 0, st, g);
+        if (side)
+            hipEventRecord(side->ev_acc, st);
+        else
+            hipLaunchKernelGGL(k_cofv_add_w, dim3(item_grid(cofv_total_adds() * g.N, 1)), dim3(64), 0, st, g);
         hipLaunchKernelGGL(k_cofv_join, dim3(g1), dim3(64), 0, st, g);
     } else if (chunked) {
         hipLaunchKernelGGL(ck.cofactor_chunk, dim3(g3), dim3(64), 0, st, g);
@@ -483,6 +500,13 @@ inline void launch_cofactor(const ChainKernels& ck, Latency lat, bool chunked, c
     } else {
         hipLaunchKernelGGL(ck.cofactor, dim3(g1), dim3(64), 0, st, g);
     }
+}
+// the deferred witness phases of a values-first cofactor chain (launch_cofactor with a side stream), enqueued on the side stream
+inline void launch_cofactor_witness(const Group& g, const CofactorSide& side) {
+    hipStreamWaitEvent(side.side, side.ev_aff, 0);
+    hipLaunchKernelGGL(k_cofv_dbl_w, dim3(item_grid((uint64_t)BLSW_H_EFF_NBITS * g.N, 1)), dim3(64), 0, side.side, g);
+    hipStreamWaitEvent(side.side, side.ev_acc, 0);
+    hipLaunchKernelGGL(k_cofv_add_w, dim3(item_grid(cofv_total_adds() * g.N, 1)), dim3(64), 0, side.side, g);
 }
 inline void launch_map(const ChainKernels& ck, Latency lat, const Group& g, hipStream_t st) {
     if (lat.quad)

@@ -59,14 +59,7 @@ BLSW_FN void prepv_chain(Emitter e, const Proj<OpsFp2>& q_, const S& scr) {
         cofv_st2(scr, BLSW_PREPV_ST(k) + 2, Y);
         cofv_st2(scr, BLSW_PREPV_ST(k) + 4, Z);
         if (!plan.is_add[k]) {  // dbl-2009-l, a = 0
-            const Fp2 A = v_sqr(X), B = v_sqr(Y), C = v_sqr(B);
-            const Fp2 D = fp2_dbl(fp2_sub(fp2_sub(v_sqr(fp2_add(X, B)), A), C));
-            const Fp2 E = fp2_add(fp2_dbl(A), A);
-            const Fp2 x3 = fp2_sub(v_sqr(E), fp2_dbl(D));
-            const Fp2 y3 = fp2_sub(fp2_mul_inl(E, fp2_sub(D, x3)), fp2_dbl(fp2_dbl(fp2_dbl(C))));
-            Z = fp2_dbl(fp2_mul_inl(Y, Z));
-            X = x3;
-            Y = y3;
+            v_dbl_inplace(X, Y, Z);
         } else {  // madd-2007-bl with Z3 = 2 Z1 H
             const Fp2 z1z1 = v_sqr(Z);
             const Fp2 H = fp2_sub(fp2_mul_inl(q.x, z1z1), X);

@@ -33,6 +33,67 @@ BLSW_HD Jac2 v_dbl(const Jac2& p) {  // dbl-2009-l, a = 0
     Fp2 z3 = fp2_dbl(fp2_mul_inl(p.y, p.z));
     return {x3, y3, z3};
 }
+// (X, Y, Z) <- 2 (X, Y, Z), the formulas of v_dbl, for the value chains of cofactor_vf.hpp / prepare_vf.hpp. On a quad the 16 Fp products of the
+// step (five Fp2 squares, two Fp2 products) are scheduled over the four lanes in FOUR rounds of one product per lane instead of one round per
+// Fp2 operation (seven): X^2 | Y^2;  B^2 | (X + B)^2;  E^2 | Y0 Z0, Y1 Z1;  the three Karatsuba products of E (D - X3) | (Y0 + Y1)(Z0 + Z1).
+BLSW_HD void v_dbl_inplace(Fp2& X, Fp2& Y, Fp2& Z) {
+#ifdef BLSW_QUAD_DEV
+    const uint32_t role = quad_role();
+    const bool hi = role >= 2u, odd = (role & 1u) != 0;
+    auto pick = [&](bool c, const Fp& t, const Fp& f) {  // on values (see quad_sel2)
+        Fp r;
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            const uint32_t x = t.l[i], y = f.l[i];
+            r.l[i] = c ? x : y;
+        }
+        return r;
+    };
+    // a pair of lanes squares v: the even lane v0 v1, the odd lane (v0 - v1)(v0 + v1)
+    auto sq_operands = [&](const Fp2& lo, const Fp2& hi_v, Fp& a, Fp& b) {
+        const Fp v0 = pick(hi, hi_v.c0, lo.c0), v1 = pick(hi, hi_v.c1, lo.c1);
+        a = pick(odd, fp_sub(v0, v1), v0);
+        b = pick(odd, fp_add(v0, v1), v1);
+    };
+    Fp a, b;
+    sq_operands(X, Y, a, b);  // round 1: A = X^2 on lanes 0, 1; B = Y^2 on lanes 2, 3
+    Fp p = fp_mul(a, b);
+    const Fp2 A = {quad_bcast<1>(p), fp_dbl(quad_bcast<0>(p))}, B = {quad_bcast<3>(p), fp_dbl(quad_bcast<2>(p))};
+    sq_operands(B, fp2_add(X, B), a, b);  // round 2: C = B^2; T = (X + B)^2
+    p = fp_mul(a, b);
+    const Fp2 C = {quad_bcast<1>(p), fp_dbl(quad_bcast<0>(p))}, T = {quad_bcast<3>(p), fp_dbl(quad_bcast<2>(p))};
+    const Fp2 D = fp2_dbl(fp2_sub(fp2_sub(T, A), C));
+    const Fp2 E = fp2_add(fp2_dbl(A), A);
+    // round 3: F = E^2 on lanes 0, 1; Y0 Z0 on lane 2, Y1 Z1 on lane 3
+    const Fp e_sum = fp_add(E.c0, E.c1);
+    a = pick(hi, pick(odd, Y.c1, Y.c0), pick(odd, fp_sub(E.c0, E.c1), E.c0));
+    b = pick(hi, pick(odd, Z.c1, Z.c0), pick(odd, e_sum, E.c1));
+    p = fp_mul(a, b);
+    const Fp2 F = {quad_bcast<1>(p), fp_dbl(quad_bcast<0>(p))};
+    const Fp yz0 = quad_bcast<2>(p), yz1 = quad_bcast<3>(p);
+    const Fp2 x3 = fp2_sub(F, fp2_dbl(D));
+    const Fp2 W = fp2_sub(D, x3);
+    // round 4: E W (Karatsuba) on lanes 0, 1, 2; (Y0 + Y1)(Z0 + Z1) on lane 3
+    a = pick(hi, pick(odd, fp_add(Y.c0, Y.c1), e_sum), pick(odd, E.c1, E.c0));
+    b = pick(hi, pick(odd, fp_add(Z.c0, Z.c1), fp_add(W.c0, W.c1)), pick(odd, W.c1, W.c0));
+    p = fp_mul(a, b);
+    const Fp m0 = quad_bcast<0>(p), m1 = quad_bcast<1>(p), ms = quad_bcast<2>(p), yzs = quad_bcast<3>(p);
+    const Fp2 EW = {fp_sub(m0, m1), fp_sub(fp_sub(ms, m0), m1)};
+    const Fp2 YZ = {fp_sub(yz0, yz1), fp_sub(fp_sub(yzs, yz0), yz1)};
+    X = x3;
+    Y = fp2_sub(EW, fp2_dbl(fp2_dbl(fp2_dbl(C))));
+    Z = fp2_dbl(YZ);
+#else
+    const Fp2 A = v_sqr(X), B = v_sqr(Y), C = v_sqr(B);
+    const Fp2 D = fp2_dbl(fp2_sub(fp2_sub(v_sqr(fp2_add(X, B)), A), C));
+    const Fp2 E = fp2_add(fp2_dbl(A), A);
+    const Fp2 x3 = fp2_sub(v_sqr(E), fp2_dbl(D));
+    const Fp2 y3 = fp2_sub(fp2_mul_inl(E, fp2_sub(D, x3)), fp2_dbl(fp2_dbl(fp2_dbl(C))));
+    Z = fp2_dbl(fp2_mul_inl(Y, Z));
+    X = x3;
+    Y = y3;
+#endif
+}
 BLSW_HD Jac1v v1_dbl(const Jac1v& p) {
     Fp A = fp_sqr(p.x), B = fp_sqr(p.y), C = fp_sqr(B);
     Fp D = fp_dbl(fp_sub(fp_sub(fp_sqr(fp_add(p.x, B)), A), C));

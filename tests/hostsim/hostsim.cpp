@@ -195,8 +195,9 @@ static Proj<OpsFp2> run_cofactor(Emitter e_add, Emitter e, const Proj<OpsFp2>& q
         std::vector<Fp> scr(BLSW_COFV_ELEMS);
         const CoeffLinear S{scr.data()}, R{rows};
         cofv_chain(e_add, e, q0, q1, S, R);
-        for (int D = BLSW_H_EFF_NBITS - 1; D >= 0; D--) cofv_dbl_w(e, (uint32_t)D, S);
+        for (int D = BLSW_H_EFF_NBITS - 1; D >= 0; D--) cofv_affine((uint32_t)D, S);
         for (int c = 2; c >= 0; c--) cofv_acc_chain(c, S, R);
+        for (int D = BLSW_H_EFF_NBITS - 1; D >= 0; D--) cofv_dbl_w(e, (uint32_t)D, S);  // beside the addition chains on the device
         for (int c = 2; c >= 0; c--)
             for (int j = (int)vp.n_adds[c] - 1; j >= 0; j--) cofv_add_w(e, c, (uint32_t)j, S);
         return cofv_join(e, S, R);
