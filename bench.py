@@ -72,6 +72,8 @@ def parse_args():
                     help="compact form: 1 = the gather of step k + 1 on a communication stream beside expansion + digest of step k; 0 = one stream; -1 = 1 when there "
                          "is something to overlap (world > 1): at world 1 the gather is a local copy and the second stream only adds contention (48.5 k vs 44.2 k instances/s)")
     ap.add_argument("--consumer-steady-shard", type=int, default=32768, help="a second, longer consumer-mode run (steady state: HBM-bound rather than chain-latency-bound; 0 = skip)")
+    ap.add_argument("--side-legs", type=int, default=1, help="N = 1: bounded legs for BASELINE configs[3] (one signature over 128 pairs), configs[4] (hash-to-G2, 1 M messages) and "
+                    "the compact wire form of configs[1], each with its own roofline and CPU baseline (0 = skip)")
     ap.add_argument("--allgather-form", choices=("compact", "full"), default="compact",
                     help="what travels in the all-gather leg: the compact wire form, expanded by every receiver, or the full witness tensors")
     return ap.parse_args()
@@ -169,6 +171,134 @@ def cpu_baseline(args, d_pk, d_msg, d_sig, n):
             "single_case_ms": single_ms, "single_case": "verify_valid_case_2ea479adf8c40300.json (= constraints.rs:337-343), one thread, mean of 5", "single_case_result_ok": single_ok,
             "sample": "first %d instances of the bench batch through the C++ restatement of the reference path (oracle/, %s), %d threads: %.2f s; "
                       "first %d instances on one thread: %.2f s" % (m, build, cores, all_dt, m1, one_dt)}
+
+
+def side_legs(args, pkg, workload, dev, fpmul_peak, opc):
+    """Bounded legs for the BASELINE configs the headline does not time (N = 1 only), each under this process's clock with a roofline of its own and
+    the oracle timed beside it (tools/bench_configs.py holds the longer sweeps):
+      multi_128       configs[3]: one signature over 128 (pk, msg) pairs, 129-pair Miller product, through the grouped engine (16 instances per step,
+                      groups of 4, three in flight, ring of two 67 GB tensors, free running) — HBM-bound: output bytes / time against 8 TB/s
+      hash_to_g2_1M   configs[4]: SSWU + cofactor clearing for 1 M messages (value-only kernels) — VALU-bound: executed Fp products against the measured rate
+      compact_form    configs[1] with the steps leaving in the compact wire form (2.6 MB per instance, what a sharded run ships) — VALU-bound
+    """
+    import numpy as np
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+
+    from tests import oracle_lib  # the CPU restatement: baselines of these legs only
+
+    oracle = oracle_lib.load()
+    cores = host_cores()
+    legs = {}
+
+    def timed(fn):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    # ---- configs[4]: hash-to-G2, 1 M messages in chunks of 262 144; message 0 is the 32-zero-byte message of bls.rs:645
+    try:
+        total_n, chunk = 1 << 20, 1 << 18
+        msgs = workload.messages(0x5EED, 0, chunk, tag=b"h")
+        msgs[0] = 0
+        d = torch.from_numpy(msgs).to(dev)
+        out = torch.empty((chunk, 24), dtype=torch.int64, device=dev)
+        pkg.hash_to_g2_batch(d, out=out)
+        dt = sum(timed(lambda: pkg.hash_to_g2_batch(d, out=out)) for _ in range(total_n // chunk))
+        first = out[0].cpu().numpy().view(np.uint64)
+        ok = bool(np.array_equal(first, oracle.hash_to_g2(bytes(32))[1]))
+        # executed Fp products per message of the value-only kernels (DESIGN.md section 3): two maps of ~2.3 k (joint-ladder exponentiation) + ~2.9 k (psi-based clearing)
+        fpmul_per_msg = 2 * 2300 + 2900
+        sample = msgs[1:1 + 4 * cores]
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=cores) as ex:
+            list(ex.map(lambda m: oracle.hash_to_g2(m.tobytes()), sample))
+        cdt = time.perf_counter() - t0
+        legs["hash_to_g2_1M"] = {"workload": "configs[4]: hash-to-G2 (SSWU + cofactor clearing, hasher.rs:727-740 values), 1 048 576 distinct 32-byte messages, affine outputs", "value": total_n / dt,
+                                 "unit": "messages/s", "seconds": dt, "first_output_is_bls_rs_645_point": ok,
+                                 "roofline": {"bound": "valu-fp-mul", "executed_fpmul_per_message": fpmul_per_msg, "achieved": total_n / dt * fpmul_per_msg, "peak": fpmul_peak,
+                                              "unit": "Fp products/s (peak = blsw_microbench 1, measured on this box)", "frac": total_n / dt * fpmul_per_msg / fpmul_peak},
+                                 "cpu_baseline": {"value": len(sample) / cdt, "unit": "messages/s", "cores": cores, "kind": "port",
+                                                  "sample": "%d messages through the oracle's hash_to_g2 on %d threads: %.2f s" % (len(sample), cores, cdt)}}
+        del d, out
+    except Exception as exc:  # noqa: BLE001 (reported in the JSON line)
+        legs["hash_to_g2_1M"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+    torch.cuda.empty_cache()
+
+    # ---- configs[1] leaving in compact wire form: groups of 16, three in flight, ring of four compact buffers, free running
+    try:
+        nb, steps = args.batch, 96
+        cpk, cmsg, csig, cexp = workload.make_batch(pkg, nb, seed=0x5EED, device=dev)
+        eng = pkg.WitnessEngine(nb, 32, max_steps=16, device=dev, n_buffers=3)
+        cbufs = eng.new_compact_buffer(4)
+        cres = [torch.empty(nb, dtype=torch.int32, device=dev) for _ in range(4)]
+
+        def run_compact(k_steps):
+            for k in range(k_steps):
+                eng.submit_compact(cpk, csig, cmsg, cbufs[k % 4], result=cres[k % 4])
+            eng.flush()
+
+        run_compact(48)
+        dt = timed(lambda: run_compact(steps))
+        executed = opc["fp_mul"] + opc["fp_inv"] * FPMUL_PER_INV_EXECUTED
+        cb = eng.compact_bytes() / nb
+        legs["compact_form"] = {"workload": "configs[1] instances leaving in compact wire form (bit-packed SHA witnesses + field witnesses, no expansion): %d steps of %d, groups of 16" % (steps, nb),
+                                "value": nb * steps / dt, "unit": "instances/s", "seconds": dt, "wire_bytes_per_instance": cb,
+                                "results_ok": bool(np.array_equal(cres[0].cpu().numpy().astype(bool), cexp)),
+                                "roofline": {"bound": "valu-fp-mul", "executed_fpmul_per_instance": executed, "achieved": nb * steps / dt * executed, "peak": fpmul_peak,
+                                             "unit": "Fp products/s (peak = blsw_microbench 1, measured on this box)", "frac": nb * steps / dt * executed / fpmul_peak,
+                                             "hbm_GBps_of_wire_bytes": nb * steps / dt * cb / 1e9},
+                                "cpu_baseline": "the headline's (same chains, the oracle does not build the wire form)"}
+        eng.close()
+        del eng, cbufs
+    except Exception as exc:  # noqa: BLE001
+        legs["compact_form"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+    torch.cuda.empty_cache()
+
+    # ---- configs[3]: one signature over 128 pairs; with distinct messages the signature of pair 0 stands in (result false, identical witness work)
+    try:
+        Kp, ne, st, co = 128, 16, 12, 4
+        msk = workload.secret_keys(0x5EED, 16)
+        mm = workload.messages(0x5EED, 1000, Kp, tag=b"mm")
+        mr = pkg.sign_batch(torch.from_numpy(np.frombuffer(b"".join(msk[j % 16].to_bytes(32, "little") for j in range(Kp)), dtype=np.uint8).reshape(Kp, 32).copy()).to(dev),
+                            torch.from_numpy(mm).to(dev), want_bytes=False)
+        epks = mr["pk_xy"].unsqueeze(0).repeat(ne, 1, 1).contiguous()
+        emsg = torch.from_numpy(mm).to(dev).unsqueeze(0).repeat(ne, 1, 1).contiguous()
+        esig = mr["sig_xy"][0:1].repeat(ne, 1).contiguous()
+        ress = [torch.empty(ne, dtype=torch.int32, device=dev) for _ in range(2)]
+        eng = pkg.WitnessEngine(ne, 32, max_steps=co, device=dev, n_buffers=3, n_pairs=Kp)
+        outs = [eng.new_witness_tensor() for _ in range(2)]
+
+        def run_multi(k_steps):
+            for k in range(k_steps):
+                eng.submit_multi(epks, emsg, esig, witness=outs[k % 2], result=ress[k % 2])
+            eng.flush()
+
+        run_multi(co)
+        eng.expand_stats()
+        dt = timed(lambda: run_multi(st))
+        out_bytes = eng.n_witness * 48
+        # one instance alone through the direct entry (latency: what BASELINE configs[3] is as a single job)
+        pkg.verify_multi(pkg.ParametersVar(), pkg.PublicKeyVar(epks[:1]), emsg[:1], pkg.SignatureVar(esig[:1]), want_witness=False)
+        one_dt = timed(lambda: pkg.verify_multi(pkg.ParametersVar(), pkg.PublicKeyVar(epks[:1]), emsg[:1], pkg.SignatureVar(esig[:1]), want_witness=False))
+        t0 = time.perf_counter()
+        n_w, o_res, _, _ = oracle.witness_multi(mr["pk_xy"].cpu().numpy().view(np.uint64), mm, mr["sig_xy"][0].cpu().numpy().view(np.uint64), want_vector=False)
+        cdt = time.perf_counter() - t0
+        legs["multi_128"] = {"workload": "configs[3]: one signature over 128 (pk, msg) pairs, 129-pair Miller product, grouped engine: %d instances per step, %d steps, groups of %d, ring of 2 tensors, free running" % (ne, st, co),
+                             "value": ne * st / dt, "unit": "instances/s", "pairs_per_s": Kp * ne * st / dt, "seconds": dt, "n_witness": eng.n_witness,
+                             "one_instance_alone_ms": one_dt * 1e3, "result_equals_oracle": bool(bool(ress[0][0].item()) == o_res and n_w == eng.n_witness),
+                             "roofline": {"bound": "hbm", "algorithmic_bytes_per_instance": out_bytes, "achieved": ne * st / dt * out_bytes / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                          "frac": ne * st / dt * out_bytes / 1e9 / HBM_PEAK_GBPS},
+                             "cpu_baseline": {"value": 1.0 / cdt, "unit": "instances/s", "cores": 1, "kind": "port",
+                                              "sample": "one 128-pair instance through the oracle's witness_multi on one thread: %.2f s" % cdt}}
+        eng.close()
+        del eng, outs
+    except Exception as exc:  # noqa: BLE001
+        legs["multi_128"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+    torch.cuda.empty_cache()
+    return legs
 
 
 def allgather_leg(args, pkg, sharding, dist, dev, inputs, lay, world):
@@ -397,6 +527,9 @@ def main():
     def step(k):
         eng.submit(d_pk, d_sig, d_msg, witness=outs[k % n_out], result=results[k % n_out])
 
+    # same-box yardstick: what this box's memory system gives a plain fill of one witness tensor in the expansion's store geometry (boxes of the pool
+    # differ by 20-30 %; the tensor is overwritten by the warm-up steps)
+    fill_bps = pkg.fill_rate(outs[0], reps=2)
     for k in range(args.warmup):
         step(k)
     eng.flush()
@@ -450,9 +583,10 @@ def main():
     if world == 1 and args.consumer_shard >= 2 * n:  # the real-use rate: a consumer reads every tensor before it is overwritten
         try:
             shard = args.consumer_shard // n * n
-            sharding.stream_shard(pkg, 2 * n, n, 2, 0, 1, device=dev)  # warm-up: code objects, scratch, allocator
+            stream_shard = importlib.import_module("tools.shard_rehearsal").stream_shard  # the measurement harness of the consumer legs (not product code)
+            stream_shard(pkg, 2 * n, n, 2, 0, 1, device=dev)  # warm-up: code objects, scratch, allocator
             torch.cuda.empty_cache()
-            cs = sharding.stream_shard(pkg, shard, n, 2, 0, 1, device=dev)
+            cs = stream_shard(pkg, shard, n, 2, 0, 1, device=dev)
             consumer = {"value": cs["instances_per_s"], "unit": "instances/s", "shard_instances": shard, "steps": cs["steps"], "ring": 2, "group_steps": cs["group_steps"],
                         "seconds": cs["seconds"], "results_ok": cs["results_ok"],
                         "digests_equal_free_running": bool((cs["digests"][:n].view("int64") == ref_digest.numpy()).all()) if cs["first_instance"] == 0 else None,
@@ -461,7 +595,7 @@ def main():
             del cs
             if args.consumer_steady_shard >= 4 * n:
                 torch.cuda.empty_cache()
-                cs = sharding.stream_shard(pkg, args.consumer_steady_shard // n * n, n, 2, 0, 1, device=dev)
+                cs = stream_shard(pkg, args.consumer_steady_shard // n * n, n, 2, 0, 1, device=dev)
                 consumer["steady"] = {"value": cs["instances_per_s"], "shard_instances": cs["n_shard"], "steps": cs["steps"], "group_steps": cs["group_steps"], "seconds": cs["seconds"],
                                       "results_ok": cs["results_ok"], "hbm_GBps_written_plus_read": cs["instances_per_s"] * 2 * lay["n_witness"] * 48 / 1e9}
                 del cs
@@ -525,9 +659,11 @@ def main():
         "data": "synthetic",
         "config": {"workload": "configs[1]: batch of 1024 independent BLS-verify instances per GPU per step (1024 distinct messages, 16 keys, every 16th tampered), 32-byte messages, full witness vectors written",
                    "instances_per_gpu_per_step": n, "batches_fused_per_launch_group": coalesce, "groups_in_flight": buffers, "output_ring": n_out, "n_witness": lay["n_witness"], "results_ok": ok, "witness_ok": witness_ok,
-                   "result_shards_gathered": gathered_ok},
+                   "result_shards_gathered": gathered_ok, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
         "roofline": {"bound": "hbm", "kernel": "k_sha_expand", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                     "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": expand_bytes, "avg_launch_ms": exp_avg_ms, "launches_timed": exp_count},
+                     "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": expand_bytes, "avg_launch_ms": exp_avg_ms, "launches_timed": exp_count,
+                     # the same-box yardstick: a plain fill of one witness tensor in the kernel's store geometry, measured before the timed region
+                     "fill_GBps": fill_bps / 1e9, "frac_of_fill": achieved / (fill_bps / 1e9) if fill_bps else None},
         "roofline_whole_path": {"bound": "hbm", "algorithmic_bytes_per_instance": bytes_per_instance,
                                 "achieved": value / world * bytes_per_instance / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                 "frac": value / world * bytes_per_instance / 1e9 / HBM_PEAK_GBPS},
@@ -555,6 +691,8 @@ def main():
         if ag_dt:
             out["value_with_allgather"] = n * world * ag_steps / ag_dt
         out["allgather"] = dict({"steps": ag_steps, "seconds": ag_dt}, **ag_info)
+    if world == 1 and args.side_legs:
+        out["side"] = side_legs(args, pkg, workload, dev, fpmul_peak, opc)
     if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only: the other ranks of a multi-GPU run would wait ~15 s in the final barrier
         out["cpu_baseline"] = cpu_baseline(args, d_pk, d_msg, d_sig, n)
     print(json.dumps(out))

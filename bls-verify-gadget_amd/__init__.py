@@ -116,6 +116,7 @@ def lib():
         L.blsw_aggregate_points_batch.argtypes = [u32, vp, u32, u64, vp, vp, vp, u64, vp]
         L.blsw_sign_batch.argtypes = [vp, vp, u32, u64, vp, vp, vp, vp, vp, vp, u64, vp]
         L.blsw_microbench.argtypes = [ctypes.c_int, u32, u32, ctypes.POINTER(ctypes.c_double)]
+        L.blsw_fill_rate.argtypes = [vp, u64, u32, ctypes.POINTER(ctypes.c_double)]
         _lib = L
     return _lib
 
@@ -124,7 +125,7 @@ EXPORTED_SYMBOLS = ["blsw_version", "blsw_layout", "blsw_engine_options_default"
                     "blsw_engine_create_ex", "blsw_engine_destroy", "blsw_engine_submit", "blsw_engine_submit_bytes", "blsw_engine_submit_multi", "blsw_engine_submit_multi_compact", "blsw_engine_submit_aggregate", "blsw_engine_flush", "blsw_engine_submitted", "blsw_engine_launched", "blsw_engine_materialised", "blsw_engine_wait_step",
                     "blsw_engine_output_consumed", "blsw_engine_compact_bytes", "blsw_engine_submit_compact", "blsw_engine_submit_aggregate_compact", "blsw_engine_expand_compact", "blsw_engine_expand_stats", "blsw_witness_digest", "blsw_hash_to_g2_workspace_bytes", "blsw_hash_to_g2_batch",
                     "blsw_decode_batch", "blsw_layout_aggregate", "blsw_aggregate_workspace_bytes", "blsw_aggregate_verify_batch", "blsw_layout_multi",
-                    "blsw_verify_multi_workspace_bytes", "blsw_verify_multi_batch", "blsw_matrices_info", "blsw_matrices_fill", "blsw_sign_batch", "blsw_microbench",
+                    "blsw_verify_multi_workspace_bytes", "blsw_verify_multi_batch", "blsw_matrices_info", "blsw_matrices_fill", "blsw_sign_batch", "blsw_microbench", "blsw_fill_rate",
                     "blsw_layout_params", "blsw_matrices_info_params", "blsw_matrices_fill_params", "blsw_aggregate_points_workspace_bytes", "blsw_aggregate_points_batch"]
 
 
@@ -745,6 +746,16 @@ def microbench(which, iters=4096, blocks=4096):
     rc = lib().blsw_microbench(which, iters, blocks, ctypes.byref(v))
     if rc:
         raise BlswError("blsw_microbench failed: %d" % rc)
+    return v.value
+
+
+def fill_rate(tensor, reps=2):
+    """blsw_fill_rate: bytes/s of a plain fill of `tensor` (a cuda tensor; overwritten) in the expansion's store geometry — the same-box HBM yardstick."""
+    _require_cuda()
+    v = ctypes.c_double(0)
+    rc = lib().blsw_fill_rate(ctypes.c_void_p(tensor.data_ptr()), ctypes.c_uint64(tensor.numel() * tensor.element_size()), reps, ctypes.byref(v))
+    if rc:
+        raise BlswError("blsw_fill_rate failed: %d" % rc)
     return v.value
 
 

@@ -1141,6 +1141,32 @@ int blsw_hash_to_g2_workspace_bytes(uint64_t n, uint32_t msg_len, uint64_t* byte
     return BLSW_OK;
 }
 
+// Plain fill of a caller buffer (e.g. a witness tensor before it is used) in the expansion's store geometry, `reps` times after one warm-up pass, on the
+// NULL stream of the current device; bytes per second of the timed passes. Synchronous. The buffer's contents are overwritten.
+int blsw_fill_rate(void* d_buf, uint64_t bytes, uint32_t reps, double* bytes_per_s) {
+    if (!d_buf || bytes < 16 || reps == 0 || !bytes_per_s || (reinterpret_cast<uintptr_t>(d_buf) & 15)) return BLSW_ERR_ARG;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = hip_ok(hipEventCreate(&e0), "event create");
+    if (!rc) rc = hip_ok(hipEventCreate(&e1), "event create");
+    const uint64_t n16 = bytes / 16;
+    const unsigned grid = (unsigned)((n16 + 3071) / 3072);
+    if (!rc) {
+        hipLaunchKernelGGL(k_bench_fill, dim3(grid), dim3(384), 0, 0, reinterpret_cast<uint4*>(d_buf), n16);
+        hipEventRecord(e0, 0);
+        for (uint32_t r = 0; r < reps; r++) hipLaunchKernelGGL(k_bench_fill, dim3(grid), dim3(384), 0, 0, reinterpret_cast<uint4*>(d_buf), n16);
+        hipEventRecord(e1, 0);
+        rc = hip_ok(hipEventSynchronize(e1), "event sync");
+    }
+    if (!rc) {
+        float ms = 0;
+        rc = hip_ok(hipEventElapsedTime(&ms, e0, e1), "event elapsed");
+        if (!rc) *bytes_per_s = (double)n16 * 16.0 * reps / (ms * 1e-3);
+    }
+    if (e0) hipEventDestroy(e0);
+    if (e1) hipEventDestroy(e1);
+    return rc;
+}
+
 // which = 0: v_mad_u64_u32 issue rate (multiply-adds/s); 1: fp_mul (Fp products/s); 2: fp_inv (inversions/s); 3: Fp products/s inside
 // witness-emitting Fp2 mul + sqr. Synchronous, on the current device.
 int blsw_microbench(int which, uint32_t iters, uint32_t blocks, double* ops_per_s) {

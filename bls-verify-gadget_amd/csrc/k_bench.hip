@@ -20,6 +20,16 @@ __global__ __launch_bounds__(256) void k_bench_mad(uint32_t iters, uint32_t* out
     uint64_t r = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
     if (r == 0x123456789abcdefull) out[0] = (uint32_t)r;  // keep the chains live
 }
+// plain fill in the expansion's shipped store geometry (384 threads x 8 pieces of 16 bytes, 6 KiB apart; k_stream.hip: k_sha_expand<384, 8, ...>):
+// what THIS box's memory system gives a pure write stream — the yardstick bench.py prints beside the expansion's rate (blsw_fill_rate)
+__global__ __launch_bounds__(384) void k_bench_fill(uint4* __restrict__ dst, uint64_t n16) {
+    const uint4 v = make_uint4(threadIdx.x, blockIdx.x, 3, 4);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const uint64_t p = ((uint64_t)blockIdx.x * 8 + k) * 384 + threadIdx.x;
+        if (p < n16) dst[p] = v;
+    }
+}
 __global__ __launch_bounds__(64) void k_bench_fpmul(uint32_t iters, uint32_t* out) {
     Fp a = fp_one(), b = fp_one();
     a.l[0] ^= threadIdx.x + 1;

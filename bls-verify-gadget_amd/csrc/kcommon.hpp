@@ -409,6 +409,7 @@ __global__ void k_decode_points(uint32_t group, const uint8_t* __restrict__ in, 
 __global__ void k_sum_points(uint32_t group, const Fp* __restrict__ xy, const int32_t* __restrict__ pst, uint32_t k, uint64_t n, uint8_t* out, int32_t* status);
 __global__ void k_sign(uint64_t n, Workspace ws, const uint8_t* __restrict__ sk32, uint8_t* sig96, uint64_t* sig_xy, uint8_t* pk48, uint64_t* pk_xy, int32_t* status);
 __global__ void k_bench_mad(uint32_t iters, uint32_t* out);
+__global__ void k_bench_fill(uint4* __restrict__ dst, uint64_t n16);
 __global__ void k_bench_fpmul(uint32_t iters, uint32_t* out);
 __global__ void k_bench_fpmul32(uint32_t iters, uint32_t* out);
 __global__ void k_bench_fpinv(uint32_t iters, uint32_t* out);

@@ -339,6 +339,10 @@ int blsw_sign_batch(const uint8_t* d_sk32_le, const uint8_t* d_msg, uint32_t msg
  * 2: Fp inversions (safegcd) per second; 3: Fp products per second inside witness-emitting Fp2 mul + sqr;
  * 4: Fp products per second of the 12 x 32-bit CIOS formulation (cross-check of the shipped 14 x 28-bit one). */
 int blsw_microbench(int which, uint32_t iters, uint32_t blocks, double* ops_per_s);
+/* Same-box yardstick of the HBM roofline: a plain fill of the caller's device buffer (16-byte aligned; overwritten) in the store geometry of the
+ * expansion kernel (384 threads x 8 pieces of 16 bytes), `reps` passes after one warm-up pass on the NULL stream of the current device; bytes per
+ * second. Boxes of one pool differ by 20-30 % in what they give a write stream: a reader of a bench line needs this next to the kernel's own rate. */
+int blsw_fill_rate(void* d_buf, uint64_t bytes, uint32_t reps, double* bytes_per_s);
 
 int blsw_version(void);
 

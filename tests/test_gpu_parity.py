@@ -1377,7 +1377,8 @@ def test_sharded_stream_rehearsal(pkg, oracle):
 def test_config2_every_shard_of_the_65536_on_one_gpu(pkg, oracle):
     """BASELINE configs[2] at its full size, rank by rank on the one GPU at hand: the 65 536 instances of SURVEY 8d config 3 as the eight contiguous shards
     of 8 192 that eight ranks would own (sharding.shard_range), each streamed through a ring of two tensors with the digest kernel as the consumer. All
-    65 536 result booleans against the tamper rule, a fixed-stride sample of every shard (168 instances in all) against the oracle's witness vectors, and
+    65 536 result booleans against the tamper rule, a fixed-stride 1 % sample of EVERY shard (82 per shard, 656 in all) against the
+    oracle's witness vectors on all host threads, and
     a size-independent property of the whole: the shards' digest sets are pairwise different (every rank processed ITS block of the global batch)."""
     import torch
 
@@ -1386,8 +1387,8 @@ def test_config2_every_shard_of_the_65536_on_one_gpu(pkg, oracle):
     for rank in range(8):
         out = rehearsal.run_shard(pkg, n_shard=8192, batch=1024, ring=2, rank=rank, world=8)
         assert out["results_ok"] and out["steps"] == 8 and out["first_instance"] == rank * 8192, rank
-        bad = rehearsal.check_sample(pkg, oracle, out, frac=1.0 / 400, threads=8)
-        assert bad == [] and out["sampled"] >= 20, (rank, bad)
+        bad = rehearsal.check_sample(pkg, oracle, out, frac=0.01, threads=max(8, len(os.sched_getaffinity(0))))
+        assert bad == [] and out["sampled"] >= 81, (rank, bad)
         sums.append(tuple(int(v) for v in out["digests"].sum(axis=0, dtype=np.uint64)))
         del out
         torch.cuda.empty_cache()

@@ -206,7 +206,7 @@ def main():
     consumer = torch.cuda.Stream(device=dev, priority=-1)
 
     def drive(eng, n_steps, ring_outs, submit, consume):
-        """submit(k, out) / consume(s, out, stream): steps through a ring with BUSY -> drain, as sharding.stream_shard does (the engine's step
+        """submit(k, out) / consume(s, out, stream): steps through a ring with BUSY -> drain, as tools/shard_rehearsal.py's stream_shard does (the engine's step
         numbers run on across calls: this call's steps are base .. base + n_steps - 1)"""
         base = eng.submitted()
         assert base == eng.materialised()

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Round 4 probe: the consumer-mode shard legs of bench.py (sharding.stream_shard) repeated in one process — run-to-run spread, the
+"""Round 4 probe: the consumer-mode shard legs of bench.py (tools/shard_rehearsal.py: stream_shard) repeated in one process — run-to-run spread, the
 group ramp on / off, group sizes. One line per run."""
 import importlib
 import json
@@ -14,7 +14,7 @@ def main():
     import torch
 
     pkg = importlib.import_module("bls-verify-gadget_amd")
-    sharding = importlib.import_module("bls-verify-gadget_amd.sharding")
+    sharding = importlib.import_module("tools.shard_rehearsal")
     dev = torch.device("cuda:0")
     n = 1024
     sharding.stream_shard(pkg, 2 * n, n, 2, 0, 1, device=dev)
