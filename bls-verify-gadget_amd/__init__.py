@@ -203,8 +203,10 @@ class WitnessEngine:
     """Thin wrapper of blsw_engine_*: submit batches, flush, read results. max_steps batches are fused per launch group.
     Streaming consumers use the step numbers returned by submit(): wait_step(seq) / output_consumed(tensor)."""
 
-    def __init__(self, n, msg_len=32, max_steps=1, device=None, n_buffers=None, **options):
-        """options: fields of blsw_engine_options_t; n_keys=K makes it an aggregate_verify engine (submit_aggregate)."""
+    def __init__(self, n, msg_len=32, max_steps=1, device=None, n_buffers=None, reserve_bytes=0, **options):
+        """options: fields of blsw_engine_options_t; n_keys=K makes it an aggregate_verify engine (submit_aggregate).
+        reserve_bytes: bytes the caller will allocate next to the workspace (its witness tensors): the capacity check, made with the byte count
+        blsw_engine_workspace_bytes_ex returns for THESE options and this n_buffers, covers them too (BlswError instead of an allocator exception)."""
         torch = _require_cuda()
         self.torch = torch
         self.n, self.msg_len, self.max_steps = int(n), int(msg_len), int(max_steps)
@@ -220,6 +222,7 @@ class WitnessEngine:
         rc = lib().blsw_engine_workspace_bytes_ex(self.n, self.msg_len, self.max_steps, self.n_buffers, ctypes.byref(opt), ctypes.byref(wb))
         if rc:
             raise BlswError("blsw_engine_workspace_bytes_ex failed: %d" % rc)
+        check_capacity(self.device, "WitnessEngine (n = %d, max_steps = %d, n_buffers = %d)" % (self.n, self.max_steps, self.n_buffers), wb.value, reserve_bytes)
         self.workspace = torch.empty(wb.value, dtype=torch.uint8, device=self.device)
         self._e = ctypes.c_void_p()
         rc = lib().blsw_engine_create_ex(ctypes.byref(self._e), self.n, self.msg_len, self.max_steps, self.n_buffers, ctypes.byref(opt), self.workspace.data_ptr(),
@@ -472,12 +475,10 @@ class BlsSignatureVerifyGadget:
 
     def __init__(self, n, msg_len=32, device=None, want_witness=True, max_steps=1, **options):
         """options: blsw_engine_options_t fields; params_mode="witness" builds the circuit for ParametersVar.new_witness()."""
+        reserve = 0
         if want_witness and not options.get("n_keys") and not options.get("n_pairs"):
-            torch = _require_cuda()
-            dev = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
-            check_capacity(dev, "BlsSignatureVerifyGadget (n = %d)" % n, engine_workspace_bytes(n, msg_len, max_steps, 3 if max_steps > 1 else 1),
-                           n * layout(msg_len, PARAMS_MODES.get(options.get("params_mode"), options.get("params_mode") or 0))["n_witness"] * 48)
-        self.engine = WitnessEngine(n, msg_len, max_steps=max_steps, device=device, **options)
+            reserve = n * layout(msg_len, PARAMS_MODES.get(options.get("params_mode"), options.get("params_mode") or 0))["n_witness"] * 48
+        self.engine = WitnessEngine(n, msg_len, max_steps=max_steps, device=device, reserve_bytes=reserve, **options)
         torch = self.engine.torch
         self.torch = torch
         self.n, self.msg_len, self.device = self.engine.n, self.engine.msg_len, self.engine.device

@@ -25,17 +25,35 @@ HIP_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wno-unused
 HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas"]
 
 
+_REASON = {"text": ""}
+
+
 def needs_build():
+    """True when libblsw.so is missing, older than a source / header, or tagged by other compilers or flags than the present ones. A library that
+    arrives WITHOUT its tag file (the tag is git-ignored like the library; a copy may carry only the .so) is accepted when it is newer than every
+    source: it is not silently rebuilt — a full -O3 build of 40 units — on the strength of a missing side file. The reason for a rebuild is kept
+    in build_reason() and logged once by build()."""
     if not os.path.exists(OUT):
-        return True
-    try:  # built by other compilers / flags than the present ones: rebuild (the tag is written next to the library)
-        if open(OUT + ".tag").read().strip() != build_tag():
-            return True
-    except OSError:
+        _REASON["text"] = "no library"
         return True
     t = os.path.getmtime(OUT)
     deps = [os.path.join(CSRC, f) for f in SOURCES + HOST_SOURCES + HEADERS] + [os.path.join(HERE, "..", "include", "blsw.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    newer = [d for d in deps if os.path.getmtime(d) > t]
+    if newer:
+        _REASON["text"] = "%s is newer than the library" % os.path.basename(newer[0])
+        return True
+    try:  # built by other compilers / flags than the present ones: rebuild (the tag is written next to the library)
+        have = open(OUT + ".tag").read().strip()
+    except OSError:
+        return False
+    if have != build_tag():
+        _REASON["text"] = "the library's tag %s is not this toolchain's %s (other compiler release or flags)" % (have, build_tag())
+        return True
+    return False
+
+
+def build_reason():
+    return _REASON["text"]
 
 
 def _compile(job):
@@ -50,6 +68,7 @@ def _compile(job):
 
 
 _TOOL_VERSION = {}
+_TAGS = {}
 
 
 def _tool_version(tool):
@@ -66,8 +85,12 @@ def build_tag(defines=()):
     ROCm release), the flags, the defines and the list of doubly compiled units. "std" names the shipped configuration's logs
     (resource_table); the objects carry the hash."""
     hipcc, cxx = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), os.environ.get("CXX", "g++")
+    memo = (hipcc, cxx, tuple(defines))
+    if memo in _TAGS:  # one pair of compiler processes per Python process, not per call
+        return _TAGS[memo]
     key = "\n".join([hipcc, _tool_version(hipcc), cxx, _tool_version(cxx), " ".join(HIP_FLAGS), " ".join(HOST_FLAGS), " ".join(defines), " ".join(DUAL), " ".join(QUAD)])
-    return hashlib.sha1(key.encode()).hexdigest()[:8]
+    _TAGS[memo] = hashlib.sha1(key.encode()).hexdigest()[:8]
+    return _TAGS[memo]
 
 
 def build(force=False, verbose=False, out=None, defines=()):
@@ -78,6 +101,8 @@ def build(force=False, verbose=False, out=None, defines=()):
         raise RuntimeError("csrc/ does not hold exactly the listed translation units (unlisted: %s)" % ", ".join(stray))
     if out is None and not force and not needs_build():
         return OUT
+    if out is None and not force and os.path.exists(OUT):
+        print("[blsw build] rebuilding libblsw.so: %s" % build_reason(), file=sys.stderr)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     out = os.path.abspath(out) if out else None
     os.makedirs(OBJ, exist_ok=True)

@@ -163,6 +163,11 @@ __global__ __launch_bounds__(384) void k_sha_expand_s(ExpandArgs a) {
 // are part of the statement (the compiler's hazard recogniser does not look into asm: without them the store used a stale base whenever the scheduler
 // had put the scalar add right in front of it — caught by test_expansion_geometries_bit_exact), and so are the two after it that a
 // store of more than 64 bits wants before a vector instruction may overwrite its data registers
+// The wait states in the inline assembly of this file (s_nop 4 between a scalar write of a store's base and the store, s_nop 1 after a 128-bit
+// store whose data registers are overwritten next) are counted by hand for ONE target. Another target must not silently inherit them.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "k_stream.hip: the hand-counted hazard wait states of expand_store / expand_store_s are valid for gfx950 only"
+#endif
 __device__ __forceinline__ void expand_store_s(uint64_t sbase, uint32_t voff, const u32x4& v) {
     asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
 }

@@ -119,7 +119,10 @@ typedef struct {
                               * chunk per 256-thread workgroup, 2 / 3 / 4 = 768 threads x 8 / 4 / 16 pieces in 4 KiB-aligned chunks, 5 = 384 x 16, 6 / 7 = one
                               * 8 / 16 KiB-aligned chunk per 512- / 1024-thread workgroup, 8 / 9 = 384 x 8 / 4 with the bit words in scalar registers
                               * (14 vector registers per lane), 10 / 11 / 12 = 384 x 8 / 16 / 32 with a light instruction stream (scalar bit window, scalar store base: 5 vector
-                              * instructions per store instead of ~20); | 0x100 = raised wave priority */
+                              * instructions per store instead of ~20); | 0x100 = raised wave priority.
+                              * Only 0 is the shipped path. 10 / 11 / 12 (and expand_store 2 / 3) are EXPERIMENTAL, non-default measurement variants: their inline
+                              * assembly carries hand-counted hazard wait states for gfx950 (the unit refuses to compile for another target) and only
+                              * test_expansion_geometries_bit_exact guards them */
     uint32_t expand_store; /* stores of the SHA expansion kernel: 0 plain (default), 1 nontemporal, 2 sc1, 3 sc0 sc1 (variant 0) */
     uint32_t prio_mode;    /* stream priorities: 0 chains high, 1 placement high (default), 2 equal */
     uint32_t place_lds;    /* optional occupancy limiter of the expansion kernel: bytes of dynamic LDS per workgroup */
