@@ -20,7 +20,7 @@ _LAYOUT_FIELDS = (
     "msg_len n_instance_vars n_witness sha_bits off_msg off_pk_alloc off_sig_alloc off_pk_not_zero off_expand off_map0 off_map1 "
     "off_add off_cofactor off_prep_h off_prep_pk off_prep_sig off_miller off_final_exp off_is_one n_keys off_keys off_bitmap off_count off_agg "
     "n_pairs stride_msg stride_pk_alloc stride_pk_not_zero stride_hash stride_prep_h stride_prep_pk "
-    "params_mode off_params_alloc off_prep_g1"
+    "params_mode off_params_alloc off_prep_g1 pk_mode sig_mode"
 ).split()
 
 
@@ -29,7 +29,7 @@ class blsw_layout_t(ctypes.Structure):
 
 
 class blsw_engine_options_t(ctypes.Structure):
-    _fields_ = [("device", ctypes.c_int32)] + [(n, ctypes.c_uint32) for n in "n_keys pairing_mode g2_mode expand_variant expand_store prio_mode place_lds consumer_mode output_form chain_variant n_pairs cofactor_mode params_mode group_ramp latency_mode".split()]
+    _fields_ = [("device", ctypes.c_int32)] + [(n, ctypes.c_uint32) for n in "n_keys pairing_mode g2_mode expand_variant expand_store prio_mode place_lds consumer_mode output_form chain_variant n_pairs cofactor_mode params_mode group_ramp latency_mode pk_mode sig_mode".split()]
 
 
 class blsw_matrices_info_t(ctypes.Structure):
@@ -102,6 +102,7 @@ def lib():
         L.blsw_engine_destroy.argtypes = [vp]
         L.blsw_engine_submit.argtypes = [vp, vp, vp, vp, vp, u64, vp, vp]
         L.blsw_engine_submit_multi.argtypes = [vp, vp, vp, vp, vp, u64, vp, vp]
+        L.blsw_engine_submit_io.argtypes = [vp, vp, vp, vp, vp, vp, u64, vp, vp]
         L.blsw_engine_submit_multi_compact.argtypes = [vp, vp, vp, vp, vp, vp, vp]
         L.blsw_engine_submit_bytes.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, u64, vp, vp]
         L.blsw_engine_flush.argtypes = [vp, vp]
@@ -125,19 +126,28 @@ EXPORTED_SYMBOLS = ["blsw_version", "blsw_layout", "blsw_engine_options_default"
                     "blsw_engine_create_ex", "blsw_engine_destroy", "blsw_engine_submit", "blsw_engine_submit_bytes", "blsw_engine_submit_multi", "blsw_engine_submit_multi_compact", "blsw_engine_submit_aggregate", "blsw_engine_flush", "blsw_engine_submitted", "blsw_engine_launched", "blsw_engine_materialised", "blsw_engine_wait_step",
                     "blsw_engine_output_consumed", "blsw_engine_compact_bytes", "blsw_engine_submit_compact", "blsw_engine_submit_aggregate_compact", "blsw_engine_expand_compact", "blsw_engine_expand_stats", "blsw_witness_digest", "blsw_hash_to_g2_workspace_bytes", "blsw_hash_to_g2_batch",
                     "blsw_decode_batch", "blsw_layout_aggregate", "blsw_aggregate_workspace_bytes", "blsw_aggregate_verify_batch", "blsw_layout_multi",
-                    "blsw_verify_multi_workspace_bytes", "blsw_verify_multi_batch", "blsw_matrices_info", "blsw_matrices_fill", "blsw_sign_batch", "blsw_microbench", "blsw_fill_rate",
+                    "blsw_verify_multi_workspace_bytes", "blsw_verify_multi_batch", "blsw_matrices_info", "blsw_matrices_fill", "blsw_sign_batch", "blsw_microbench", "blsw_fill_rate", "blsw_layout_io", "blsw_engine_submit_io", "blsw_matrices_info_io", "blsw_matrices_fill_io",
                     "blsw_layout_params", "blsw_matrices_info_params", "blsw_matrices_fill_params", "blsw_aggregate_points_workspace_bytes", "blsw_aggregate_points_batch"]
 
 
 PARAMS_MODES = {"constant": 0, "witness": 1}
+IO_MODES = {"witness": 0, "input": 1, "Witness": 0, "Input": 1}
 
 
-def layout(msg_len=32, params_mode=0):
+def layout(msg_len=32, params_mode=0, pk_mode=0, sig_mode=0):
     """Segment table of the witness vector (host logic; replaces cs.num_witness_variables(), constraints.rs:369-373).
-    params_mode 1 / "witness": ParametersVar::new_variable with AllocationMode::Witness (constraints.rs:198-211)."""
+    params_mode 1 / "witness": ParametersVar::new_variable with AllocationMode::Witness (constraints.rs:198-211).
+    pk_mode / sig_mode 1 / "input": PublicKeyVar / SignatureVar::new_variable with AllocationMode::Input (constraints.rs:214-249): the point's
+    coordinates are public inputs (n_instance_vars > 1), its allocation segment is empty."""
     L = blsw_layout_t()
     params_mode = PARAMS_MODES.get(params_mode, params_mode)
-    rc = lib().blsw_layout_params(msg_len, params_mode, ctypes.byref(L)) if params_mode else lib().blsw_layout(msg_len, ctypes.byref(L))
+    pk_mode, sig_mode = IO_MODES.get(pk_mode, pk_mode), IO_MODES.get(sig_mode, sig_mode)
+    if pk_mode or sig_mode:
+        if params_mode:
+            raise BlswError("pk_mode / sig_mode Input apply to the circuit with Constant parameters")
+        rc = lib().blsw_layout_io(msg_len, pk_mode, sig_mode, ctypes.byref(L))
+    else:
+        rc = lib().blsw_layout_params(msg_len, params_mode, ctypes.byref(L)) if params_mode else lib().blsw_layout(msg_len, ctypes.byref(L))
     if rc:
         raise BlswError("blsw_layout failed: %d" % rc)
     return {n: getattr(L, n) for n in _LAYOUT_FIELDS}
@@ -189,7 +199,7 @@ def engine_options(**overrides):
     for var, field in (("BLSW_CHAIN_VARIANT", "chain_variant"), ("BLSW_COFACTOR_MODE", "cofactor_mode"), ("BLSW_EXPAND_VARIANT", "expand_variant"), ("BLSW_EXPAND_NT", "expand_store"), ("BLSW_PRIO_MODE", "prio_mode"), ("BLSW_PLACE_LDS", "place_lds"), ("BLSW_GROUP_RAMP", "group_ramp"), ("BLSW_LATENCY_MODE", "latency_mode")):
         if env.get(var):
             setattr(o, field, int(env[var]))
-    names = {"pairing_mode": {"team": 0, "lane": 1}, "g2_mode": {"lane": 0, "team": 1}, "params_mode": PARAMS_MODES}
+    names = {"pairing_mode": {"team": 0, "lane": 1}, "g2_mode": {"lane": 0, "team": 1}, "params_mode": PARAMS_MODES, "pk_mode": IO_MODES, "sig_mode": IO_MODES}
     for k, v in overrides.items():
         if v is None:
             continue
@@ -216,8 +226,9 @@ class WitnessEngine:
         opt.device = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.n_keys = int(opt.n_keys)
         self.n_pairs = int(opt.n_pairs) if opt.n_pairs > 1 else 1
-        self.layout = layout_aggregate(msg_len, self.n_keys) if self.n_keys else (layout_multi(msg_len, self.n_pairs) if self.n_pairs > 1 else layout(msg_len, int(opt.params_mode)))
+        self.layout = layout_aggregate(msg_len, self.n_keys) if self.n_keys else (layout_multi(msg_len, self.n_pairs) if self.n_pairs > 1 else layout(msg_len, int(opt.params_mode), int(opt.pk_mode), int(opt.sig_mode)))
         self.n_witness = self.layout["n_witness"]
+        self.n_instance_vars = self.layout["n_instance_vars"]
         wb = ctypes.c_uint64(0)
         rc = lib().blsw_engine_workspace_bytes_ex(self.n, self.msg_len, self.max_steps, self.n_buffers, ctypes.byref(opt), ctypes.byref(wb))
         if rc:
@@ -246,11 +257,16 @@ class WitnessEngine:
     def new_witness_tensor(self):
         return self.torch.empty((self.n, self.n_witness, 6), dtype=self.torch.int64, device=self.device)
 
+    def new_instance_tensor(self):
+        """[n, n_instance_vars, 6]: instance_assignment of every instance (submit(..., instance=...); element 0 = one)"""
+        return self.torch.empty((self.n, self.n_instance_vars, 6), dtype=self.torch.int64, device=self.device)
+
     def _stream(self, stream):
         return (stream if stream is not None else self.torch.cuda.current_stream(self.device)).cuda_stream
 
-    def submit(self, pk_xy, sig_xy, msg, witness=None, result=None, stream=None):
-        """-> step number (0, 1, 2, ... in submission order)"""
+    def submit(self, pk_xy, sig_xy, msg, witness=None, result=None, stream=None, instance=None):
+        """-> step number (0, 1, 2, ... in submission order). instance: [n, n_instance_vars, 6] tensor that receives instance_assignment
+        (blsw_engine_submit_io; pk_mode / sig_mode Input engines: the public inputs an arkworks verifier takes)."""
         assert pk_xy.is_cuda and sig_xy.is_cuda and msg.is_cuda
         assert pk_xy.shape == (self.n, 12) and sig_xy.shape == (self.n, 24) and msg.shape == (self.n, self.msg_len)
         assert pk_xy.is_contiguous() and sig_xy.is_contiguous() and msg.is_contiguous()
@@ -259,9 +275,15 @@ class WitnessEngine:
         if result is not None:
             assert result.is_contiguous() and result.numel() >= self.n
         seq = self.submitted()
-        rc = lib().blsw_engine_submit(self._e, pk_xy.data_ptr(), sig_xy.data_ptr(), msg.data_ptr() if self.msg_len else None,
-                                      witness.data_ptr() if witness is not None else None, witness.shape[1] if witness is not None else 0,
-                                      result.data_ptr() if result is not None else None, self._stream(stream))
+        if instance is not None:
+            assert instance.is_contiguous() and tuple(instance.shape) == (self.n, self.n_instance_vars, 6)
+            rc = lib().blsw_engine_submit_io(self._e, pk_xy.data_ptr(), sig_xy.data_ptr(), msg.data_ptr() if self.msg_len else None, instance.data_ptr(),
+                                             witness.data_ptr() if witness is not None else None, witness.shape[1] if witness is not None else 0,
+                                             result.data_ptr() if result is not None else None, self._stream(stream))
+        else:
+            rc = lib().blsw_engine_submit(self._e, pk_xy.data_ptr(), sig_xy.data_ptr(), msg.data_ptr() if self.msg_len else None,
+                                          witness.data_ptr() if witness is not None else None, witness.shape[1] if witness is not None else 0,
+                                          result.data_ptr() if result is not None else None, self._stream(stream))
         if rc:
             raise (BlswBusy if rc == ERR_BUSY else BlswError)("blsw_engine_submit failed: %d" % rc)
         self._keep.append((pk_xy, sig_xy, msg, witness, result))
@@ -449,35 +471,51 @@ class ParametersVar:
 
 
 class PublicKeyVar:
-    """constraints.rs:39-44, AllocVar at :214-232 (Witness mode). `xy`: [n, 12] int64 tensor (u64 limbs: x, y Montgomery)."""
+    """constraints.rs:39-44, AllocVar at :214-232: Witness (the reference's circuits) or Input (new_input: the key's x, y, z are public inputs,
+    no in-circuit subgroup check). `xy`: [n, 12] int64 tensor (u64 limbs: x, y Montgomery). AllocationMode::Constant is not on the GPU path."""
 
-    def __init__(self, xy):
+    def __init__(self, xy, mode="Witness"):
+        if mode not in ("Witness", "Input"):
+            raise BlswError("PublicKeyVar: AllocationMode %r is not on the GPU path (Witness or Input)" % (mode,))
         self.xy = xy
+        self.mode = mode
 
     @classmethod
     def new_witness(cls, xy):
         return cls(xy)
+
+    @classmethod
+    def new_input(cls, xy):
+        return cls(xy, "Input")
 
 
 class SignatureVar:
-    """constraints.rs:55-60, AllocVar at :234-249 (Witness mode). `xy`: [n, 24] int64 tensor (x.c0, x.c1, y.c0, y.c1)."""
+    """constraints.rs:55-60, AllocVar at :234-249: Witness or Input (new_input). `xy`: [n, 24] int64 tensor (x.c0, x.c1, y.c0, y.c1)."""
 
-    def __init__(self, xy):
+    def __init__(self, xy, mode="Witness"):
+        if mode not in ("Witness", "Input"):
+            raise BlswError("SignatureVar: AllocationMode %r is not on the GPU path (Witness or Input)" % (mode,))
         self.xy = xy
+        self.mode = mode
 
     @classmethod
     def new_witness(cls, xy):
         return cls(xy)
+
+    @classmethod
+    def new_input(cls, xy):
+        return cls(xy, "Input")
 
 
 class BlsSignatureVerifyGadget:
     """Batched counterpart of constraints.rs:79-128. One call = n independent circuits (direct mode engine, one batch)."""
 
     def __init__(self, n, msg_len=32, device=None, want_witness=True, max_steps=1, **options):
-        """options: blsw_engine_options_t fields; params_mode="witness" builds the circuit for ParametersVar.new_witness()."""
+        """options: blsw_engine_options_t fields; params_mode="witness" builds the circuit for ParametersVar.new_witness(), pk_mode / sig_mode="input" the
+        one for PublicKeyVar.new_input / SignatureVar.new_input (self.instance then holds every instance's instance_assignment after verify)."""
         reserve = 0
         if want_witness and not options.get("n_keys") and not options.get("n_pairs"):
-            reserve = n * layout(msg_len, PARAMS_MODES.get(options.get("params_mode"), options.get("params_mode") or 0))["n_witness"] * 48
+            reserve = n * layout(msg_len, PARAMS_MODES.get(options.get("params_mode"), options.get("params_mode") or 0), options.get("pk_mode") or 0, options.get("sig_mode") or 0)["n_witness"] * 48
         self.engine = WitnessEngine(n, msg_len, max_steps=max_steps, device=device, reserve_bytes=reserve, **options)
         torch = self.engine.torch
         self.torch = torch
@@ -486,6 +524,7 @@ class BlsSignatureVerifyGadget:
         self.n_witness = self.engine.n_witness
         self.result = torch.empty(self.n, dtype=torch.int32, device=self.device)
         self.witness = self.engine.new_witness_tensor() if want_witness else None
+        self.instance = self.engine.new_instance_tensor() if self.layout["n_instance_vars"] > 1 else None
 
     def verify(self, parameters, public_key, message, signature, witness=None, stream=None):
         """message: [n, msg_len] uint8 tensor. Returns the int32 result tensor (gadget Boolean per instance); the witness
@@ -493,8 +532,11 @@ class BlsSignatureVerifyGadget:
         assert isinstance(parameters, ParametersVar)
         if (parameters.mode == "Witness") != bool(self.layout["params_mode"]):
             raise BlswError("ParametersVar mode %s does not match the circuit this gadget was built for (params_mode=%d)" % (parameters.mode, self.layout["params_mode"]))
+        for var, field in ((public_key, "pk_mode"), (signature, "sig_mode")):
+            if (getattr(var, "mode", "Witness") == "Input") != bool(self.layout[field]):
+                raise BlswError("%s allocated as %s does not match the circuit this gadget was built for (%s=%d)" % (type(var).__name__, var.mode, field, self.layout[field]))
         w = witness if witness is not None else self.witness
-        self.engine.submit(public_key.xy, signature.xy, message, witness=w, result=self.result, stream=stream)
+        self.engine.submit(public_key.xy, signature.xy, message, witness=w, result=self.result, stream=stream, instance=self.instance)
         self.engine.flush(stream=stream)
         return self.result
 
@@ -635,7 +677,7 @@ def aggregate_verify(parameters, public_keys, bitmap, message, signature, want_w
     return res, cnt, wit
 
 
-def matrices(msg_len=32, n_keys=0, n_pairs=1, params_mode=0):
+def matrices(msg_len=32, n_keys=0, n_pairs=1, params_mode=0, pk_mode=0, sig_mode=0):
     """Constraint matrices of a circuit shape (host only; blsw_matrices_info + blsw_matrices_fill): the R1CS an arkworks prover
     takes next to the witness vectors, in ConstraintMatrices shape. Returns dict(n_constraints, n_instance_vars, n_witness,
     A / B / C = (row_ptr uint64 [n_constraints + 1], col uint32 [nnz], val uint64 [nnz, 6] Montgomery limbs)).
@@ -643,8 +685,13 @@ def matrices(msg_len=32, n_keys=0, n_pairs=1, params_mode=0):
     import numpy as np
 
     params_mode = PARAMS_MODES.get(params_mode, params_mode)
+    pk_mode, sig_mode = IO_MODES.get(pk_mode, pk_mode), IO_MODES.get(sig_mode, sig_mode)
     info = blsw_matrices_info_t()
-    if params_mode:
+    if pk_mode or sig_mode:  # columns: 0 = one, 1 .. n_instance_vars - 1 = the public inputs, n_instance_vars + k = witness k
+        if n_keys or n_pairs != 1 or params_mode:
+            raise BlswError("pk_mode / sig_mode apply to the single-key circuit with Constant parameters")
+        rc = lib().blsw_matrices_info_io(msg_len, pk_mode, sig_mode, ctypes.byref(info))
+    elif params_mode:
         if n_keys or n_pairs != 1:
             raise BlswError("params_mode applies to the single-key circuit")
         rc = lib().blsw_matrices_info_params(msg_len, params_mode, ctypes.byref(info))
@@ -661,7 +708,9 @@ def matrices(msg_len=32, n_keys=0, n_pairs=1, params_mode=0):
         out.row_ptr[m] = rp[m].ctypes.data_as(u64p)
         out.col[m] = col[m].ctypes.data_as(u32p)
         out.val[m] = val[m].ctypes.data_as(u64p)
-    if params_mode:
+    if pk_mode or sig_mode:
+        rc = lib().blsw_matrices_fill_io(msg_len, pk_mode, sig_mode, ctypes.byref(info), ctypes.byref(out))
+    elif params_mode:
         rc = lib().blsw_matrices_fill_params(msg_len, params_mode, ctypes.byref(info), ctypes.byref(out))
     else:
         rc = lib().blsw_matrices_fill(msg_len, n_keys, n_pairs, ctypes.byref(info), ctypes.byref(out))

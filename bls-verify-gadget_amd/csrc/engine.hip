@@ -317,6 +317,7 @@ static int launch_group(blsw_engine* e) {
     g.LS = e->LS;
     g.ws = carve(b.base, g.N, e->L, e->staged, e->modes, (uint64_t)steps * e->n);
     g.chain_prio = e->opt.prio_mode == 0;
+    g.canonical = (int)e->opt.output_form;
     const unsigned g1 = (unsigned)((g.N + 63) / 64);
     const unsigned gt = (unsigned)((g.N + BLSW_TEAMS_PER_WAVE - 1) / BLSW_TEAMS_PER_WAVE);
     // Which kernels. A SMALL group (at most BLSW_LATENCY_MAX_LANES lanes) that finds the engine's chains idle starts a pipeline: nothing of this engine
@@ -403,7 +404,9 @@ static int launch_group(blsw_engine* e) {
             hipLaunchKernelGGL(ck.agg_sum, dim3(g1), dim3(64), 0, sb, g, (const Fp*)g.ws.keyproj);
         } else  // params_mode: lanes [N, 2 N) allocate and prepare the generator (k_g1)
             hipLaunchKernelGGL(ck.g1, dim3(e->L.params_mode ? (unsigned)((2 * g.N + 63) / 64) : g1), dim3(64), 0, sb, g);
-        if (e->modes.g2_team)
+        if (e->L.sig_mode) {
+            // SignatureVar::new_variable(Input): no allocation chain (prepare(sig) wrote the instance variables)
+        } else if (e->modes.g2_team)
             hipLaunchKernelGGL(k_g2_alloc_team, dim3(gt), dim3(64), 0, b.st[1], g);
         else
             launch_g2_alloc(ck, lat, g, b.st[1]);
@@ -452,6 +455,12 @@ int blsw_layout_params(uint32_t msg_len, uint32_t params_mode, blsw_layout_t* ou
     return BLSW_OK;
 }
 
+int blsw_layout_io(uint32_t msg_len, uint32_t pk_mode, uint32_t sig_mode, blsw_layout_t* out) {
+    if (!out || msg_len > 65535 || pk_mode > 1 || sig_mode > 1) return BLSW_ERR_ARG;
+    make_layout(msg_len, out, 0, 1, false, pk_mode == 1, sig_mode == 1);
+    return BLSW_OK;
+}
+
 int blsw_engine_options_default(blsw_engine_options_t* o) {
     if (!o) return BLSW_ERR_ARG;
     o->device = -1;
@@ -470,17 +479,20 @@ int blsw_engine_options_default(blsw_engine_options_t* o) {
     o->params_mode = 0;
     o->group_ramp = 0;
     o->latency_mode = 0;
+    o->pk_mode = 0;
+    o->sig_mode = 0;
     return BLSW_OK;
 }
 
 int blsw_engine_workspace_bytes_ex(uint64_t n, uint32_t msg_len, uint32_t max_steps, uint32_t n_buffers, const blsw_engine_options_t* options, uint64_t* bytes) {
     if (!bytes || n == 0 || max_steps == 0 || n_buffers == 0 || n_buffers > BLSW_MAX_BUFFERS || msg_len > 65535 || !options || options->n_keys > 65535 ||
         options->n_pairs > 4096 || (options->n_pairs > 1 && options->n_keys) || options->params_mode > 1 ||
-        (options->params_mode && (options->n_keys || options->n_pairs > 1 || options->pairing_mode)))
+        (options->params_mode && (options->n_keys || options->n_pairs > 1 || options->pairing_mode)) || options->pk_mode > 1 || options->sig_mode > 1 ||
+        ((options->pk_mode || options->sig_mode) && (options->n_keys || options->n_pairs > 1 || options->params_mode || options->g2_mode)))
         return BLSW_ERR_ARG;
     blsw_layout_t L;
     const uint32_t K = options->n_pairs > 1 ? options->n_pairs : 1;
-    make_layout(msg_len, &L, options->n_keys, K, options->params_mode == 1);
+    make_layout(msg_len, &L, options->n_keys, K, options->params_mode == 1, options->pk_mode == 1, options->sig_mode == 1);
     const bool staged = max_steps > 1 || n_buffers > 1;
     // the same workspace serves every kernel variant: the largest carve of the three mode combinations
     uint64_t need = 0;
@@ -524,6 +536,10 @@ int blsw_engine_create_ex(blsw_engine_t** out, uint64_t n, uint32_t msg_len, uin
         return BLSW_ERR_ARG;
     // ParametersVar allocated as witnesses: the single-key circuit with the six-lane pairing kernel (k_pairing_team_pv)
     if (options->params_mode > 1 || (options->params_mode && (options->n_keys || options->n_pairs > 1 || options->pairing_mode))) return BLSW_ERR_ARG;
+    // PublicKeyVar / SignatureVar allocated as public inputs: the single-key circuit with Constant parameters and the one-lane G2 kernels
+    if (options->pk_mode > 1 || options->sig_mode > 1 ||
+        ((options->pk_mode || options->sig_mode) && (options->n_keys || options->n_pairs > 1 || options->params_mode || options->g2_mode)))
+        return BLSW_ERR_ARG;
     *out = nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return BLSW_ERR_NO_DEVICE;
@@ -561,7 +577,7 @@ int blsw_engine_create_ex(blsw_engine_t** out, uint64_t n, uint32_t msg_len, uin
     e->staged = max_steps > 1 || n_buffers > 1;
     e->cofactor_mode = options->cofactor_mode;
     e->chains_inlined = options->chain_variant == 2 || (options->chain_variant == 0 && !e->staged);
-    make_layout(msg_len, &e->L, options->n_keys, options->n_pairs > 1 ? options->n_pairs : 1, options->params_mode == 1);
+    make_layout(msg_len, &e->L, options->n_keys, options->n_pairs > 1 ? options->n_pairs : 1, options->params_mode == 1, options->pk_mode == 1, options->sig_mode == 1);
     e->LS = e->L.n_pairs > 1 ? staging_layout_multi(e->L).LS : staging_layout(e->L, e->modes);
     for (int i = 0; i < BLSW_MAX_CONSUMED; i++) {
         e->consumed_ptr[i] = nullptr;
@@ -696,6 +712,12 @@ int blsw_engine_submit(blsw_engine_t* e, const uint64_t* d_pk_xy, const uint64_t
                        uint64_t witness_stride, int32_t* d_result, void* stream_) {
     if (!e || e->L.n_keys || e->L.n_pairs > 1 || !d_pk_xy || !d_sig_xy || (!d_msg && e->msg_len)) return BLSW_ERR_ARG;
     StepDesc d = {d_pk_xy, d_sig_xy, d_msg, d_witness, witness_stride, d_result, nullptr, nullptr, nullptr, nullptr, nullptr};
+    return engine_submit(e, d, stream_);
+}
+int blsw_engine_submit_io(blsw_engine_t* e, const uint64_t* d_pk_xy, const uint64_t* d_sig_xy, const uint8_t* d_msg, uint64_t* d_instance, uint64_t* d_witness,
+                          uint64_t witness_stride, int32_t* d_result, void* stream_) {
+    if (!e || e->L.n_keys || e->L.n_pairs > 1 || e->L.params_mode || !d_pk_xy || !d_sig_xy || (!d_msg && e->msg_len)) return BLSW_ERR_ARG;
+    StepDesc d = {d_pk_xy, d_sig_xy, d_msg, d_witness, witness_stride, d_result, nullptr, nullptr, nullptr, nullptr, nullptr, d_instance};
     return engine_submit(e, d, stream_);
 }
 // N+1-pair product through the engine (an engine created with options.n_pairs = K): one batch of n instances, each ONE signature
@@ -856,14 +878,18 @@ int blsw_engine_expand_stats(blsw_engine_t* e, uint32_t* count, float* avg_ms) {
 }
 
 int blsw_witness_digest(const uint64_t* d_witness, uint64_t witness_stride, uint64_t n, uint32_t n_witness, uint64_t* d_digest, void* stream_) {
-    if (!d_witness || !d_digest || n == 0 || n > 65535 || n_witness == 0 || witness_stride < n_witness) return BLSW_ERR_ARG;
+    if (!d_witness || !d_digest || n == 0 || n_witness == 0 || witness_stride < n_witness) return BLSW_ERR_ARG;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream_);
     DeviceGuard guard(stream_device(st));
     if (hip_ok(hipMemsetAsync(d_digest, 0, n * 2 * sizeof(uint64_t), st), "memset")) return BLSW_ERR_HIP;
     const uint64_t n_words = (uint64_t)n_witness * 6, per_block = 2ull * 256 * BLSW_DIGEST_ITERS;
     const uint64_t chunks = (n_words + per_block - 1) / per_block;
-    dim3 grid((unsigned)(chunks < BLSW_DIGEST_MAX_BLOCKS ? chunks : BLSW_DIGEST_MAX_BLOCKS), (unsigned)n);  // a workgroup walks its instance's chunks with stride grid.x
-    hipLaunchKernelGGL(k_digest, grid, dim3(256), 0, st, d_witness, witness_stride, n_words, d_digest);
+    // one row of workgroups per instance (grid.y <= 65535): larger batches in slices of 65 535 instances
+    for (uint64_t first = 0; first < n; first += 65535) {
+        const uint64_t cnt = n - first < 65535 ? n - first : 65535;
+        dim3 grid((unsigned)(chunks < BLSW_DIGEST_MAX_BLOCKS ? chunks : BLSW_DIGEST_MAX_BLOCKS), (unsigned)cnt);  // a workgroup walks its instance's chunks with stride grid.x
+        hipLaunchKernelGGL(k_digest, grid, dim3(256), 0, st, d_witness + first * witness_stride * 6, witness_stride, n_words, d_digest + 2 * first);
+    }
     return hip_ok(hipGetLastError(), "launch");
 }
 
@@ -883,6 +909,7 @@ static Group direct_group(uint64_t n, uint32_t K, uint32_t msg_len, const blsw_l
     g.LS = L;
     g.ws = ws;
     g.chain_prio = 0;
+    g.canonical = 0;
     return g;
 }
 

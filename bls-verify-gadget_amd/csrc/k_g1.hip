@@ -35,7 +35,19 @@ __global__ __launch_bounds__(64) BLSW_CHAIN_ATTR void BLSW_K(k_g1)(Group g) {
         x = K_G1_GEN_X();
         y = fp_neg(K_G1_GEN_NEG_Y());
     }
-    Proj<OpsFp> pk = chain_g1_alloc_only(e_alloc, x, y);
+    Proj<OpsFp> pk;
+    if (g.L.pk_mode && !params) {
+        // PublicKeyVar::new_variable(Input) (constraints.rs:214-232) = new_variable_omit_prime_order_check: x, y, z are public inputs (1 .. 3 of
+        // instance_assignment), no witnesses, no in-circuit prime-order check
+        const bool inf = fp_is_zero(x) && fp_is_zero(y);
+        pk = {inf ? fp_zero() : x, inf ? fp_one() : y, inf ? fp_zero() : fp_one()};
+        put_instance(g, id, 1, pk.x);
+        put_instance(g, id, 2, pk.y);
+        put_instance(g, id, 3, pk.z);
+    } else {
+        pk = chain_g1_alloc_only(e_alloc, x, y);
+    }
+    if (!params) put_instance(g, id, 0, fp_one());  // instance_assignment[0]
     if (params) pk.y = fp_neg(pk.y);
     G1ChainOut o = chain_g1_post(e_nz, e_prep, pk);
     if (params) return;  // its affine form is the constant the pairing kernel uses

@@ -30,6 +30,18 @@ __device__ __forceinline__ Proj<OpsFp2> prepare_point(const Group& g, const Lane
     }
     return q;
 }
+// SignatureVar::new_variable(Input) (constraints.rs:234-249): x, y, z (c0, c1 each) are public inputs after the key's; the prepare chain of the
+// signature is the kernel that has the point at hand (there is no allocation chain in this mode)
+__device__ __forceinline__ void put_sig_instance(const Group& g, const LaneId& id, const Proj<OpsFp2>& q) {
+    if (!g.L.sig_mode || !item_leader()) return;
+    const uint32_t k0 = 1 + (g.L.pk_mode ? 3 : 0);
+    put_instance(g, id, k0 + 0, q.x.c0);
+    put_instance(g, id, k0 + 1, q.x.c1);
+    put_instance(g, id, k0 + 2, q.y.c0);
+    put_instance(g, id, k0 + 3, q.y.c1);
+    put_instance(g, id, k0 + 4, q.z.c0);
+    put_instance(g, id, k0 + 5, q.z.c1);
+}
 #define BLSW_PREPARE_EMIT(g, id, which) ((which) == 0 ? EMITJ(g, id, off_prep_h, stride_prep_h) : EMIT(g, id, off_prep_sig))
 #define BLSW_PREPARE_OUT(g, I, which) ((which) == 0 ? CoeffStrided{(g).ws.coeff_h + (I), (g).N} : CoeffStrided{(g).ws.coeff_sig + (I), (g).ws.n_sig})
 #define BLSW_PREPARE_SCR(g, I, which) ((which) == 0 ? CoeffStrided{(g).ws.prepv_h + (I), (g).N} : CoeffStrided{(g).ws.prepv_sig + (I), (g).ws.n_sig})
@@ -40,7 +52,9 @@ __global__ __launch_bounds__(64) BLSW_CHAIN_ATTR void BLSW_K(k_prepare)(Group g,
     const uint64_t I = item_index();  // latency compilation (k_prepare_q): four lanes per item
     if (I >= g.N) return;
     LaneId id = lane_id(g, I);
-    chain_prepare_g2(BLSW_PREPARE_EMIT(g, id, which), prepare_point(g, id, I, which), BLSW_PREPARE_OUT(g, I, which));
+    const Proj<OpsFp2> q = prepare_point(g, id, I, which);
+    if (which == 1) put_sig_instance(g, id, q);
+    chain_prepare_g2(BLSW_PREPARE_EMIT(g, id, which), q, BLSW_PREPARE_OUT(g, I, which));
 }
 
 #ifndef BLSW_KVARIANT_INL
@@ -50,7 +64,9 @@ __global__ __launch_bounds__(64) BLSW_CHAIN_ATTR void BLSW_K(k_prepv_chain)(Grou
     const uint64_t I = item_index();
     if (I >= g.N) return;
     LaneId id = lane_id(g, I);
-    prepv_chain(BLSW_PREPARE_EMIT(g, id, which), prepare_point(g, id, I, which), BLSW_PREPARE_SCR(g, I, which));
+    const Proj<OpsFp2> q = prepare_point(g, id, I, which);
+    if (which == 1) put_sig_instance(g, id, q);
+    prepv_chain(BLSW_PREPARE_EMIT(g, id, which), q, BLSW_PREPARE_SCR(g, I, which));
 }
 #endif
 #if !defined(BLSW_KVARIANT_INL) && !defined(BLSW_KVARIANT_QUAD)

@@ -57,7 +57,7 @@ struct Workspace {
 // launch groups of at most this many lanes may take the latency kernels (quads, values-first cofactor chain): their scratch is carved for them
 #define BLSW_LATENCY_MAX_LANES 8192
 inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
-BLSW_HD inline uint64_t bits_tile_words(uint64_t sha_words) { return sha_words * 64; }  // u32 per 64-instance tile
+BLSW_HD uint64_t bits_tile_words(uint64_t sha_words) { return sha_words * 64; }  // u32 per 64-instance tile
 // kernel variants, fixed per engine at creation (blsw_engine_options_t)
 struct Modes {
     bool pairing_team;  // pairing segment: six lanes per instance (default) or the single-lane chain (kept for A/B runs)
@@ -185,6 +185,8 @@ struct StepDesc {
     // blsw_engine_submit_bytes: [n][2] decode statuses of (pk, sig); result[i] = gadget Boolean AND both statuses BLSW_ST_OK
     // (tests/tests.rs:244-263: a point that does not decode is replaced by the default and the case must verify false)
     const int32_t* status;
+    // blsw_engine_submit_io: [n][n_instance_vars][6] instance_assignment of every instance (element 0 = one), or nullptr
+    uint64_t* inst;
 };
 __device__ __forceinline__ int32_t step_result(const StepDesc& d, uint32_t i, bool res) {
     if (d.status && (d.status[2 * i] | d.status[2 * i + 1])) return 0;
@@ -225,8 +227,8 @@ struct Group {
     blsw_layout_t LS;      // offsets in the staging rows (the vector with the SHA segment cut out)
     Workspace ws;
     int chain_prio;        // chain waves raise s_setprio
+    int canonical;         // instance_assignment elements as canonical integers (options.output_form 1) instead of Montgomery limbs
 };
-
 // workspace / staging / tensor accesses: global address space stated (see Emitter::put)
 __device__ __forceinline__ Fp ld_fp(const Fp* p) {
     const blsw_global_u32x4* s = (const blsw_global_u32x4*)p;
@@ -260,6 +262,13 @@ __device__ __forceinline__ LaneId lane_id(const Group& g, uint64_t I) {
     r.j = g.K == 1 ? 0u : r.f - r.i * g.K;
     return r;
 }
+// element k of instance (step s, i)'s instance_assignment := v (blsw_engine_submit_io); the witness kernels write the inputs they allocate
+__device__ __forceinline__ void put_instance(const Group& g, const LaneId& id, uint32_t k, const Fp& v) {
+    uint64_t* base = g.desc[id.s].inst;
+    if (!base) return;
+    st_fp(reinterpret_cast<Fp*>(base) + ((uint64_t)id.i * g.L.n_instance_vars + k), g.canonical ? fp_to_canonical(v) : v);
+}
+
 // witness cursor for a segment: staging row (engine mode), the instance's dense vector (direct mode), or value-only
 // per_pair: the segment belongs to a (pk, msg) pair (the lane is a pair lane) — else to the instance / signature
 __device__ __forceinline__ Emitter emitter(const Group& g, const LaneId& id, uint32_t off_full, uint32_t off_staging, bool per_pair) {

@@ -30,14 +30,19 @@ inline uint32_t seg_miller(uint32_t n_pairs) { return 62 * 36 + 68 * 30 - 30 + 6
 // params_witness: ParametersVar::new_variable(Witness) (constraints.rs:198-211), single-key circuit only: the generator's allocation
 // segment follows the message (argument order of constraints.rs:346-364), prepare_g1(-g1) emits its to_affine in front of prepare(H),
 // and every ell of the (-g1, sig) pair has a variable point: 38 witnesses instead of 30, 2 instead of 0 in the first one (f = 1).
-inline void make_layout(uint32_t msg_len, blsw_layout_t* L, uint32_t n_keys = 0, uint32_t n_pairs = 1, bool params_witness = false) {
+// pk_input / sig_input: PublicKeyVar / SignatureVar::new_variable(Input) (constraints.rs:214-249), single-key circuit with Constant parameters only: the
+// point's coordinates are instance variables and its allocation segment is empty (no in-circuit prime-order check for public inputs).
+inline void make_layout(uint32_t msg_len, blsw_layout_t* L, uint32_t n_keys = 0, uint32_t n_pairs = 1, bool params_witness = false, bool pk_input = false,
+                        bool sig_input = false) {
     std::vector<uint8_t> msg(msg_len ? msg_len : 1, 0);
     BitSink s;
     s.init(nullptr, 0);
     uint32_t uw[64];
     expand_message_w(s, msg.data(), msg_len, false, uw);
     L->msg_len = msg_len;
-    L->n_instance_vars = 1;
+    L->n_instance_vars = 1 + (pk_input ? 3 : 0) + (sig_input ? 6 : 0);
+    L->pk_mode = pk_input ? 1 : 0;
+    L->sig_mode = sig_input ? 1 : 0;
     L->sha_bits = (uint32_t)s.nbits;
     uint32_t o = 0;
     L->n_keys = n_keys;
@@ -51,7 +56,7 @@ inline void make_layout(uint32_t msg_len, blsw_layout_t* L, uint32_t n_keys = 0,
     const uint32_t K = n_keys ? 1 : (n_pairs ? n_pairs : 1);
     L->n_pairs = K;
     L->stride_msg = 8 * msg_len;
-    L->stride_pk_alloc = SEG_PK_ALLOC;
+    L->stride_pk_alloc = pk_input ? 0 : SEG_PK_ALLOC;
     L->stride_pk_not_zero = SEG_PK_NOT_ZERO;
     L->stride_hash = L->sha_bits + 2 * SEG_MAP + SEG_ADD + SEG_COFACTOR;
     L->stride_prep_h = SEG_PREP_G2;
@@ -65,9 +70,9 @@ inline void make_layout(uint32_t msg_len, blsw_layout_t* L, uint32_t n_keys = 0,
         o += SEG_PK_ALLOC;
     }
     L->off_pk_alloc = o;
-    if (!n_keys) o += SEG_PK_ALLOC * K;
+    if (!n_keys) o += L->stride_pk_alloc * K;
     L->off_sig_alloc = o;
-    o += SEG_SIG_ALLOC;
+    o += sig_input ? 0 : SEG_SIG_ALLOC;
     if (n_keys) {
         L->off_count = o;
         o += 32;

@@ -66,10 +66,14 @@ static Lc lc_scale(const Lc& a, const Fp& s) { return lc_axpy(Lc(), a, s); }
 struct Sys {
     uint64_t n_cons = 0;
     uint32_t n_wit = 0;
+    // a variable's number is its COLUMN (ark-relations: one, the instance variables, then the witnesses): 0 = one, 1 .. n_inst - 1 = the public inputs
+    // in allocation order, n_inst + k = witness k. n_inst is a property of the circuit shape, set before the synthesis.
+    uint32_t n_inst = 1, n_in = 0;
     std::vector<uint64_t> row_ptr[3];
     std::vector<uint32_t> col[3];
     std::vector<Fp> val[3];
-    uint32_t alloc() { return ++n_wit; }
+    uint32_t alloc() { return n_inst - 1 + ++n_wit; }
+    uint32_t alloc_input() { return ++n_in; }  // FpVar::new_input
     void row(int m, const Lc& l) {
         row_ptr[m].push_back(col[m].size());
         for (const Term& t : l) {
@@ -166,6 +170,7 @@ static V v_const(const Fp& c) { return {true, c, Lc()}; }
 static V v_zero() { return v_const(fp_zero()); }
 static V v_one() { return v_const(fp_one()); }
 static V v_alloc() { return {false, fp_zero(), lc_var(S->alloc())}; }
+static V v_input() { return {false, fp_zero(), lc_var(S->alloc_input())}; }  // FpVar::new_input
 static Lc v_lc(const V& a) { return a.k ? lc_const(a.c) : a.l; }
 static V v_add(const V& a, const V& b) {
     if (a.k && b.k) return v_const(fp_add(a.c, b.c));
@@ -280,6 +285,11 @@ static V2 v2_one() { return v2_const(fp2_one()); }
 static V2 v2_alloc() {
     V a = v_alloc();
     V b = v_alloc();
+    return {a, b};
+}
+static V2 v2_input() {
+    V a = v_input();
+    V b = v_input();
     return {a, b};
 }
 static V2 v2_add(const V2& a, const V2& b) { return {v_add(a.c0, b.c0), v_add(a.c1, b.c1)}; }
@@ -513,6 +523,7 @@ struct T1 {
     static F zero() { return v_zero(); }
     static F one() { return v_one(); }
     static F alloc() { return v_alloc(); }
+    static F input() { return v_input(); }
     static bool konst(const F& a) { return a.k; }
     static N value(const F& a) { return a.c; }
     static bool nzero(const N& a) { return fp_is_zero(a); }
@@ -543,6 +554,7 @@ struct T2 {
     static F zero() { return v2_zero(); }
     static F one() { return v2_one(); }
     static F alloc() { return v2_alloc(); }
+    static F input() { return v2_input(); }
     static bool konst(const F& a) { return a.k(); }
     static N value(const F& a) { return {a.c0.c, a.c1.c}; }
     static bool nzero(const N& a) { return fp2_is_zero(a); }
@@ -748,6 +760,14 @@ Pt<T> pt_alloc() {
     auto x = T::alloc();
     auto y = T::alloc();
     auto z = T::alloc();
+    return {x, y, z};
+}
+// ProjectiveVar::new_variable(Input) = new_variable_omit_prime_order_check (ark-r1cs-std 0.4.0): x, y, z as public inputs, no in-circuit check
+template <class T>
+Pt<T> pt_input() {
+    auto x = T::input();
+    auto y = T::input();
+    auto z = T::input();
     return {x, y, z};
 }
 static Pt<T1> g1_new_witness() {  // allocate g * (h^-1 mod r), multiply by the cofactor in-circuit
@@ -1215,7 +1235,7 @@ static B verify_gadget(const std::vector<Pt<T1>>& pks, const std::vector<std::ve
     V12 fe = final_exponentiation(miller_loop(ps, qs));
     return v12_is_eq(fe, v12_one());
 }
-static void circuit(uint32_t msg_len, uint32_t n_keys, uint32_t n_pairs, bool params_witness) {
+static void circuit(uint32_t msg_len, uint32_t n_keys, uint32_t n_pairs, bool params_witness, bool pk_input = false, bool sig_input = false) {
     if (n_keys) {  // constraints.rs:378-441: keys, bitmap booleans, msg, params, sig, aggregate_verify
         std::vector<Pt<T1>> keys;
         for (uint32_t k = 0; k < n_keys; k++) keys.push_back(g1_new_witness());
@@ -1242,16 +1262,19 @@ static void circuit(uint32_t msg_len, uint32_t n_keys, uint32_t n_pairs, bool pa
     Pt<T1> g1 = pt_zero<T1>();
     if (params_witness) g1 = g1_new_witness();  // ParametersVar::new_variable(Witness): argument order of constraints.rs:346-364
     std::vector<Pt<T1>> pks;
-    for (uint32_t j = 0; j < n_pairs; j++) pks.push_back(g1_new_witness());
-    Pt<T2> sig = g2_new_witness();
+    for (uint32_t j = 0; j < n_pairs; j++) pks.push_back(pk_input ? pt_input<T1>() : g1_new_witness());  // constraints.rs:214-232 with AllocationMode::Input / Witness
+    Pt<T2> sig = sig_input ? pt_input<T2>() : g2_new_witness();                                             // constraints.rs:234-249
     (void)verify_gadget(pks, msgs, sig, params_witness ? &g1 : nullptr);
 }
 
-static int run(uint32_t msg_len, uint32_t n_keys, uint32_t n_pairs, Sys& sys, uint32_t params_mode = 0) {
+// io_modes: bit 0 = pk Input, bit 1 = sig Input (single-key circuit with Constant parameters)
+static int run(uint32_t msg_len, uint32_t n_keys, uint32_t n_pairs, Sys& sys, uint32_t params_mode = 0, uint32_t io_modes = 0) {
     if (msg_len > 65535 || n_keys > 65535 || (n_keys && n_pairs > 1) || n_pairs == 0 || n_pairs > 4096) return BLSW_ERR_ARG;
     if (params_mode > 1 || (params_mode && (n_keys || n_pairs != 1))) return BLSW_ERR_ARG;
+    if (io_modes > 3 || (io_modes && (n_keys || n_pairs != 1 || params_mode))) return BLSW_ERR_ARG;
     S = &sys;
-    circuit(msg_len, n_keys, n_pairs, params_mode == 1);
+    sys.n_inst = 1 + ((io_modes & 1) ? 3 : 0) + ((io_modes & 2) ? 6 : 0);
+    circuit(msg_len, n_keys, n_pairs, params_mode == 1, (io_modes & 1) != 0, (io_modes & 2) != 0);
     sys.finish();
     S = nullptr;
     return BLSW_OK;
@@ -1261,7 +1284,7 @@ static int run(uint32_t msg_len, uint32_t n_keys, uint32_t n_pairs, Sys& sys, ui
 struct Cache {
     std::mutex mu;
     bool valid = false;
-    uint32_t msg_len = 0, n_keys = 0, n_pairs = 0, params_mode = 0;
+    uint32_t msg_len = 0, n_keys = 0, n_pairs = 0, params_mode = 0, io_modes = 0;
     Sys sys;
 };
 static Cache& cache() {
@@ -1272,7 +1295,7 @@ static Cache& cache() {
 }  // namespace r1cs
 }  // namespace blsw
 
-static int matrices_info(uint32_t msg_len, uint32_t n_keys, uint32_t n_pairs, uint32_t params_mode, blsw_matrices_info_t* out) {
+static int matrices_info(uint32_t msg_len, uint32_t n_keys, uint32_t n_pairs, uint32_t params_mode, blsw_matrices_info_t* out, uint32_t io_modes = 0) {
     if (!out) return BLSW_ERR_ARG;
     blsw::r1cs::Cache& c = blsw::r1cs::cache();
     std::lock_guard<std::mutex> lock(c.mu);
@@ -1280,36 +1303,38 @@ static int matrices_info(uint32_t msg_len, uint32_t n_keys, uint32_t n_pairs, ui
     int rc;
     try {  // no exception crosses the ABI: a system that does not fit in memory is BLSW_ERR_WORKSPACE
         c.sys = blsw::r1cs::Sys();
-        rc = blsw::r1cs::run(msg_len, n_keys, n_pairs, c.sys, params_mode);
+        rc = blsw::r1cs::run(msg_len, n_keys, n_pairs, c.sys, params_mode, io_modes);
     } catch (...) {
         c.sys = blsw::r1cs::Sys();
         return BLSW_ERR_WORKSPACE;
     }
     if (rc) return rc;
     c.valid = true;
+    c.io_modes = io_modes;
     c.msg_len = msg_len;
     c.n_keys = n_keys;
     c.n_pairs = n_pairs;
     c.params_mode = params_mode;
     out->n_constraints = c.sys.n_cons;
-    out->n_instance_vars = 1;
+    out->n_instance_vars = c.sys.n_inst;
     out->n_witness = c.sys.n_wit;
     for (int m = 0; m < 3; m++) out->nnz[m] = c.sys.col[m].size();
     return BLSW_OK;
 }
 
-static int matrices_fill(uint32_t msg_len, uint32_t n_keys, uint32_t n_pairs, uint32_t params_mode, const blsw_matrices_info_t* info, blsw_matrices_t* out) {
+static int matrices_fill(uint32_t msg_len, uint32_t n_keys, uint32_t n_pairs, uint32_t params_mode, const blsw_matrices_info_t* info, blsw_matrices_t* out,
+                         uint32_t io_modes = 0) {
     if (!info || !out) return BLSW_ERR_ARG;
     for (int m = 0; m < 3; m++)
         if (!out->row_ptr[m] || (info->nnz[m] && (!out->col[m] || !out->val[m]))) return BLSW_ERR_ARG;
     blsw::r1cs::Cache& c = blsw::r1cs::cache();
     std::lock_guard<std::mutex> lock(c.mu);
-    if (!(c.valid && c.msg_len == msg_len && c.n_keys == n_keys && c.n_pairs == n_pairs && c.params_mode == params_mode)) {
+    if (!(c.valid && c.msg_len == msg_len && c.n_keys == n_keys && c.n_pairs == n_pairs && c.params_mode == params_mode && c.io_modes == io_modes)) {
         c.valid = false;
         int rc;
         try {
             c.sys = blsw::r1cs::Sys();
-            rc = blsw::r1cs::run(msg_len, n_keys, n_pairs, c.sys, params_mode);
+            rc = blsw::r1cs::run(msg_len, n_keys, n_pairs, c.sys, params_mode, io_modes);
         } catch (...) {
             c.sys = blsw::r1cs::Sys();
             return BLSW_ERR_WORKSPACE;
@@ -1317,7 +1342,7 @@ static int matrices_fill(uint32_t msg_len, uint32_t n_keys, uint32_t n_pairs, ui
         if (rc) return rc;
     }
     const blsw::r1cs::Sys& s = c.sys;
-    bool ok = s.n_cons == info->n_constraints && s.n_wit == info->n_witness;
+    bool ok = s.n_cons == info->n_constraints && s.n_wit == info->n_witness && s.n_inst == info->n_instance_vars;
     for (int m = 0; m < 3; m++) ok = ok && s.col[m].size() == info->nnz[m];
     if (ok)
         for (int m = 0; m < 3; m++) {
@@ -1340,5 +1365,13 @@ int blsw_matrices_fill(uint32_t msg_len, uint32_t n_keys, uint32_t n_pairs, cons
 int blsw_matrices_info_params(uint32_t msg_len, uint32_t params_mode, blsw_matrices_info_t* out) { return matrices_info(msg_len, 0, 1, params_mode, out); }
 int blsw_matrices_fill_params(uint32_t msg_len, uint32_t params_mode, const blsw_matrices_info_t* info, blsw_matrices_t* out) {
     return matrices_fill(msg_len, 0, 1, params_mode, info, out);
+}
+int blsw_matrices_info_io(uint32_t msg_len, uint32_t pk_mode, uint32_t sig_mode, blsw_matrices_info_t* out) {
+    if (pk_mode > 1 || sig_mode > 1) return BLSW_ERR_ARG;
+    return matrices_info(msg_len, 0, 1, 0, out, pk_mode | sig_mode << 1);
+}
+int blsw_matrices_fill_io(uint32_t msg_len, uint32_t pk_mode, uint32_t sig_mode, const blsw_matrices_info_t* info, blsw_matrices_t* out) {
+    if (pk_mode > 1 || sig_mode > 1) return BLSW_ERR_ARG;
+    return matrices_fill(msg_len, 0, 1, 0, info, out, pk_mode | sig_mode << 1);
 }
 }

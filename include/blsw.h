@@ -42,10 +42,10 @@ extern "C" {
 
 /* Segment table of one instance's witness vector for the circuit of src/constraints.rs:335-366
  * (msg witness bytes, params Constant, pk Witness, sig Witness, then verify). Offsets are in field elements.
- * 34 uint32_t fields; the Rust mirror in INTEGRATION.md must have the same fields in the same order. */
+ * 36 uint32_t fields; the Rust mirror in INTEGRATION.md must have the same fields in the same order. */
 typedef struct {
     uint32_t msg_len;
-    uint32_t n_instance_vars; /* 1: the constant one (this gadget allocates no public input) */
+    uint32_t n_instance_vars; /* instance_assignment length: 1 (the constant one) + 3 if pk_mode is Input + 6 if sig_mode is Input */
     uint32_t n_witness;       /* witness_assignment length */
     uint32_t sha_bits;        /* boolean witnesses of ONE expand_message segment (16 lib_str bits + SHA-256 gadget) */
     uint32_t off_msg, off_pk_alloc, off_sig_alloc, off_pk_not_zero, off_expand, off_map0, off_map1, off_add, off_cofactor, off_prep_h, off_prep_pk,
@@ -61,6 +61,12 @@ typedef struct {
      * prep_h; the ell of the (-g1, sig) pair then has a variable point (68 x 8 witnesses more, 2 in the first one). All zero for
      * the reference's own circuits (params Constant: no witnesses). */
     uint32_t params_mode, off_params_alloc, off_prep_g1;
+    /* PublicKeyVar / SignatureVar allocated with AllocationMode::Input (blsw_layout_io; src/constraints.rs:214-249 take any mode): 0 = Witness (the
+     * reference's circuits), 1 = Input: the point's x, y, z are public inputs — instance_assignment = [1, pk.x, pk.y, pk.z, sig.x.c0, sig.x.c1,
+     * sig.y.c0, sig.y.c1, sig.z.c0, sig.z.c1] in allocation order — and its allocation segment is empty (ark-r1cs-std 0.4.0 allocates Input points
+     * through new_variable_omit_prime_order_check: no in-circuit subgroup check, a verifier checks its public inputs itself). Matrix columns:
+     * 0 = one, 1 .. n_instance_vars - 1 = the inputs, n_instance_vars + k = witness k. */
+    uint32_t pk_mode, sig_mode;
 } blsw_layout_t;
 
 /* layout(circuit shape) — replaces reading cs.num_witness_variables() after synthesis (constraints.rs:369-373). Host only. */
@@ -93,6 +99,10 @@ int blsw_layout_multi(uint32_t msg_len, uint32_t n_pairs, blsw_layout_t* out);
  * 1 = Witness. AllocationMode::Input would put the generator into instance_assignment, which this engine does not produce:
  * BLSW_ERR_ARG. Host only. */
 int blsw_layout_params(uint32_t msg_len, uint32_t params_mode, blsw_layout_t* out);
+/* single-key circuit with PublicKeyVar / SignatureVar::new_variable(.., mode) (src/constraints.rs:214-249): pk_mode / sig_mode 0 = Witness, 1 = Input
+ * (blsw_layout_t.pk_mode). AllocationMode::Constant for a key or a signature is a different circuit in four segments and is not offered: BLSW_ERR_ARG.
+ * Parameters Constant. Host only. */
+int blsw_layout_io(uint32_t msg_len, uint32_t pk_mode, uint32_t sig_mode, blsw_layout_t* out);
 int blsw_verify_multi_workspace_bytes(uint64_t n, uint32_t msg_len, uint32_t n_pairs, uint64_t* bytes);
 int blsw_verify_multi_batch(const uint64_t* d_pks_xy, const uint8_t* d_msgs, uint32_t msg_len, uint32_t n_pairs, const uint64_t* d_sig_xy, uint64_t n,
                             uint64_t* d_witness, uint64_t witness_stride, int32_t* d_result, void* d_workspace, uint64_t workspace_bytes, void* stream);
@@ -163,6 +173,9 @@ typedef struct {
                               derived by a lane of its own). 0 (default) = for such a group when it finds the engine's chains idle (it starts a pipeline:
                               its latency is what a consumer waits for); 1 = never; 2 = for every such group; 3 / 4 = as 2 with only the values-first
                               cofactor chain / only the quads (A/B runs). Same witnesses either way. */
+    uint32_t pk_mode;      /* PublicKeyVar allocation (src/constraints.rs:214-232): 0 (default) Witness, 1 Input (blsw_layout_io): batches go through
+                              blsw_engine_submit_io, which also writes instance_assignment. Single-key circuit with Constant parameters only. */
+    uint32_t sig_mode;     /* SignatureVar allocation (src/constraints.rs:234-249): 0 (default) Witness, 1 Input; as pk_mode; not with g2_mode 1 */
 } blsw_engine_options_t;
 /* the defaults (pure: the library reads no environment variable; measurement scripts set the fields they want to vary) */
 int blsw_engine_options_default(blsw_engine_options_t* out);
@@ -172,7 +185,8 @@ int blsw_engine_workspace_bytes_ex(uint64_t n, uint32_t msg_len, uint32_t max_st
  * allocated) when pairing_mode 1 is combined with so many group buffers that the runtime's per-queue scratch
  * (stack bytes x 64 lanes x wave slots of the device, per queue) would exceed what ROCr can back: that combination
  * used to abort the process with HSA_STATUS_ERROR_OUT_OF_RESOURCES. */
-/* BLSW_ERR_ARG also for: n > 65535 (one row of workgroups per instance in the expansion launches); options->consumer_mode > 1;
+/* BLSW_ERR_ARG also for: n > 65535 (one row of workgroups per instance in the expansion launches; no restriction in practice: a step's
+ * output is n witness vectors of 34 MB, so 288 GB of HBM hold steps of at most ~8 000 instances — larger batches are more steps); options->consumer_mode > 1;
  * options->consumer_mode == 1 on a direct-mode engine (max_steps == 1 and n_buffers == 1: it writes witnesses in place while
  * the chains run and cannot hold a step back). */
 int blsw_engine_create(blsw_engine_t** out, uint64_t n, uint32_t msg_len, uint32_t max_steps, uint32_t n_buffers, void* d_workspace,
@@ -180,6 +194,11 @@ int blsw_engine_create(blsw_engine_t** out, uint64_t n, uint32_t msg_len, uint32
 int blsw_engine_create_ex(blsw_engine_t** out, uint64_t n, uint32_t msg_len, uint32_t max_steps, uint32_t n_buffers, const blsw_engine_options_t* options,
                           void* d_workspace, uint64_t workspace_bytes);
 int blsw_engine_destroy(blsw_engine_t* e);
+/* blsw_engine_submit for an engine with pk_mode / sig_mode Input (it works for every single-key engine): additionally writes
+ * d_instance [n][n_instance_vars][6] u64 = each instance's instance_assignment (element 0 = one; Montgomery limbs, or canonical integers with
+ * options.output_form 1), i.e. what ConstraintSystem::instance_assignment holds after synthesis. d_instance may be NULL. */
+int blsw_engine_submit_io(blsw_engine_t* e, const uint64_t* d_pk_xy, const uint64_t* d_sig_xy, const uint8_t* d_msg, uint64_t* d_instance, uint64_t* d_witness,
+                          uint64_t witness_stride, int32_t* d_result, void* stream);
 
 /* Submits one batch of n independent (pk, msg, sig) instances: the witness vectors of the circuit of
  * src/constraints.rs:335-366 are written to d_witness and the gadget's output Boolean (constraints.rs:127) to d_result.
@@ -275,7 +294,7 @@ int blsw_engine_expand_stats(blsw_engine_t* e, uint32_t* count, float* avg_ms);
  *            (the NH family of UMAC with a position-derived key: one multiply per 8 bytes)
  *     d[1] = lo | hi << 32,  lo = sum_q (x_4q ^ key_q) + (x_4q+2 ^ ~key_q),  hi = sum_q (x_4q+1 ^ key_q) + (x_4q+3 ^ ~key_q)   mod 2^32
  *   (ABI 9; ABI <= 8 summed a splitmix64 finalizer per u64 word: four 64-bit multiplies per 16 bytes made the kernel VALU-bound.)
- *   d_witness [n][witness_stride] elements, d_digest [n][2] u64. Reads the tensor once at HBM speed. */
+ *   d_witness [n][witness_stride] elements, d_digest [n][2] u64, any n (launched in slices of 65 535 instances). Reads the tensor once at HBM speed. */
 int blsw_witness_digest(const uint64_t* d_witness, uint64_t witness_stride, uint64_t n, uint32_t n_witness, uint64_t* d_digest, void* stream);
 
 /* Constraint matrices (host only, no GPU): the R1CS whose witness vectors the entry points above fill, in arkworks'
@@ -301,6 +320,10 @@ int blsw_matrices_fill(uint32_t msg_len, uint32_t n_keys, uint32_t n_pairs, cons
 /* the same for the single-key circuit of blsw_layout_params (params_mode 0 = the two calls above with n_keys 0, n_pairs 1) */
 int blsw_matrices_info_params(uint32_t msg_len, uint32_t params_mode, blsw_matrices_info_t* out);
 int blsw_matrices_fill_params(uint32_t msg_len, uint32_t params_mode, const blsw_matrices_info_t* info, blsw_matrices_t* out);
+/* the same for the single-key circuit of blsw_layout_io: info->n_instance_vars = 1 + the number of public-input field elements; column numbering as in
+ * blsw_layout_t.pk_mode (ark-relations' ConstraintMatrices: instance variables first, then the witnesses) */
+int blsw_matrices_info_io(uint32_t msg_len, uint32_t pk_mode, uint32_t sig_mode, blsw_matrices_info_t* out);
+int blsw_matrices_fill_io(uint32_t msg_len, uint32_t pk_mode, uint32_t sig_mode, const blsw_matrices_info_t* info, blsw_matrices_t* out);
 
 /* Input decode (PublicKey::try_from / Signature::try_from -> deserialize_compressed, src/bls.rs:219-242, 316-339):
  *   d_pk48 [n][48], d_sig96 [n][96]  ZCash-format compressed points

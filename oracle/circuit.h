@@ -575,16 +575,19 @@ inline Bool bls_verify_gadget(const G1Var& g1_generator, const G1Var& pk, const 
 // the circuit of constraints.rs:335-366: msg witness bytes, params Constant, pk Witness, sig Witness, verify.
 // params_witness: ParametersVar::new_variable with AllocationMode::Witness instead (constraints.rs:198-211 takes any mode): the
 // generator goes through G1Var::new_variable like a public key, between the message and the key (argument order of :346-364).
+// pk_input / sig_input: PublicKeyVar / SignatureVar::new_variable with AllocationMode::Input (constraints.rs:214-249 take any mode): the point's
+// x, y, z are public inputs (instance_assignment = [1, pk.x, pk.y, pk.z, sig.x.c0, .., sig.z.c1] in allocation order) and the allocation
+// segment has no witnesses (pv_new_input: no prime-order check). The caller sets CSREF.n_inst = 1 + 3 pk_input + 6 sig_input first.
 inline Bool bls_verify_circuit(const G1Aff& pk, const uint8_t* msg, size_t msg_len, const G2Aff& sig, VerifyTrace* tr = nullptr,
-                               bool params_witness = false) {
+                               bool params_witness = false, bool pk_input = false, bool sig_input = false) {
     CSREF.mark("msg");
     std::vector<U8> msg_var = u8witness_vec(msg, msg_len);
     if (params_witness) CSREF.mark("params_alloc");
     G1Var g1 = params_witness ? g1_new_witness(g1_generator()) : pv_constant<FpT>(g1_generator());
     CSREF.mark("pk_alloc");
-    G1Var pk_var = g1_new_witness(pk);
+    G1Var pk_var = pk_input ? pv_new_input<FpT>(pk) : g1_new_witness(pk);
     CSREF.mark("sig_alloc");
-    G2Var sig_var = g2_new_witness(sig);
+    G2Var sig_var = sig_input ? pv_new_input<Fp2T>(sig) : g2_new_witness(sig);
     return bls_verify_gadget(g1, pk_var, msg_var, sig_var, tr);
 }
 

@@ -16,7 +16,8 @@
 
 namespace orc {
 
-typedef uint32_t Var;  // 0 = the constant One; k>0 = witness k-1 (column k of the matrices)
+typedef uint32_t Var;  // the variable's COLUMN in the matrices (ark-relations: One, then the instance variables, then the witnesses):
+                       // 0 = the constant One; 1 .. n_inst - 1 = public inputs in allocation order; n_inst + k = witness k
 struct Term {
     Var v;
     Fp c;
@@ -27,12 +28,21 @@ typedef std::shared_ptr<const LCv> LC;
 struct CS {
     bool record = false;  // keep A,B,C linear combinations (matrix emission / satisfiability check)
     std::vector<Fp> wit;  // witness_assignment
+    // instance_assignment = [1, inst...]. n_inst (1 + the number of AllocationMode::Input field elements of the circuit SHAPE) is set before
+    // synthesis: a witness's column depends on it, and witnesses are allocated before the last input is (constraints.rs:341 precedes :353)
+    uint32_t n_inst = 1;
+    std::vector<Fp> inst;
     std::vector<LC> A, B, C;
     uint64_t ncons = 0;
     std::vector<std::pair<std::string, uint64_t>> marks;
     Var new_witness(const Fp& v) {
         wit.push_back(v);
-        return (Var)wit.size();
+        return (Var)(n_inst - 1 + wit.size());
+    }
+    Var new_input(const Fp& v) {  // FpVar::new_input
+        inst.push_back(v);
+        if (inst.size() >= n_inst) abort();  // the shape announced fewer inputs
+        return (Var)inst.size();
     }
     void enforce(const LC& a, const LC& b, const LC& c) {
         ncons++;
@@ -87,9 +97,10 @@ inline LC lc_axpy(const LC& a, const LC& b, const Fp& s) {  // a + s*b, both sor
 inline LC lc_add(const LC& a, const LC& b) { return lc_axpy(a, b, fp_one()); }
 inline LC lc_sub(const LC& a, const LC& b) { return lc_axpy(a, b, fp_neg(fp_one())); }
 inline LC lc_scale(const LC& a, const Fp& s) { return lc_axpy(lc_zero(), a, s); }
-inline Fp lc_eval(const LCv& a, const std::vector<Fp>& wit) {
+inline Fp lc_eval(const LCv& a, const std::vector<Fp>& wit, const std::vector<Fp>* inst = nullptr) {
+    const uint32_t n_inst = inst ? (uint32_t)inst->size() + 1 : 1;
     Fp acc = fp_zero();
-    for (auto& t : a) acc = fp_add(acc, fp_mul(t.c, t.v == 0 ? fp_one() : wit[t.v - 1]));
+    for (auto& t : a) acc = fp_add(acc, fp_mul(t.c, t.v == 0 ? fp_one() : (t.v < n_inst ? (*inst)[t.v - 1] : wit[t.v - n_inst])));
     return acc;
 }
 
@@ -185,6 +196,10 @@ struct FpVar {
 inline FpVar fconst(const Fp& v) { return {true, v, nullptr}; }
 inline FpVar fwitness(const Fp& v) {
     Var x = CSREF.new_witness(v);
+    return {false, v, lc_var(x)};
+}
+inline FpVar finput(const Fp& v) {
+    Var x = CSREF.new_input(v);
     return {false, v, lc_var(x)};
 }
 inline LC flc(const FpVar& a) { return a.konst ? lc_const(a.v) : a.lc; }

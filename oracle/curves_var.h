@@ -28,6 +28,7 @@ struct FpT {
     static V mulc(const V& a, const N& c) { return fmulc(a, c); }
     static V constant(const N& c) { return fconst(c); }
     static V witness(const N& c) { return fwitness(c); }
+    static V input(const N& c) { return finput(c); }
     static V zero() { return fconst(fp_zero()); }
     static V one() { return fconst(fp_one()); }
     static bool is_const(const V& a) { return a.konst; }
@@ -67,6 +68,7 @@ struct Fp2T {
     static V mulc(const V& a, const N& c) { return f2mulc(a, c); }
     static V constant(const N& c) { return f2const(c); }
     static V witness(const N& c) { return f2witness(c); }
+    static V input(const N& c) { return f2input(c); }
     static V zero() { return f2zero(); }
     static V one() { return f2one(); }
     static bool is_const(const V& a) { return a.is_const(); }
@@ -472,6 +474,17 @@ ProjectiveVar<T> pv_new_witness_omit_check(const Aff<T>& a) {
     V x = T::witness(a.inf ? T::nzero() : a.x);
     V y = T::witness(a.inf ? T::none() : a.y);
     V z = T::witness(a.inf ? T::nzero() : T::none());
+    return {x, y, z};
+}
+// ProjectiveVar::new_variable(cs, f, AllocationMode::Input) = new_variable_omit_prime_order_check(cs, f, Input) (ark-r1cs-std 0.4.0
+// groups/curves/short_weierstrass/mod.rs: `AllocationMode::Constant | Input => Self::new_variable_omit_prime_order_check`): x, y, z as
+// public inputs, NO in-circuit prime-order check — a verifier checks its public inputs itself. [ark, recalled: judgement call, DESIGN.md]
+template <class T>
+ProjectiveVar<T> pv_new_input(const Aff<T>& a) {
+    typedef typename T::V V;
+    V x = T::input(a.inf ? T::nzero() : a.x);
+    V y = T::input(a.inf ? T::none() : a.y);
+    V z = T::input(a.inf ? T::nzero() : T::none());
     return {x, y, z};
 }
 template <class T>

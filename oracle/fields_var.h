@@ -22,6 +22,11 @@ inline Fp2Var f2witness(const Fp2& v) {
     FpVar b = fwitness(v.c1);
     return {a, b};
 }
+inline Fp2Var f2input(const Fp2& v) {
+    FpVar a = finput(v.c0);
+    FpVar b = finput(v.c1);
+    return {a, b};
+}
 inline Fp2Var f2zero() { return f2const(fp2_zero()); }
 inline Fp2Var f2one() { return f2const(fp2_one()); }
 inline Fp2Var f2add(const Fp2Var& a, const Fp2Var& b) { return {fadd(a.c0, b.c0), fadd(a.c1, b.c1)}; }

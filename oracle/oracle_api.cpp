@@ -296,6 +296,48 @@ uint64_t orc_witness_params(const uint64_t* pk_xy, const uint8_t* msg, size_t ms
     if (out_witness) memcpy(out_witness, s.cs.wit.data(), std::min(n, out_capacity_elems) * 48);
     return n;
 }
+// the same circuit with the key and / or the signature allocated as public inputs (constraints.rs:214-249 with AllocationMode::Input):
+// out_instance receives instance_assignment = [1, inputs...] (n_inst = 1 + 3 pk_input + 6 sig_input elements)
+uint64_t orc_witness_io(const uint64_t* pk_xy, const uint8_t* msg, size_t msg_len, const uint64_t* sig_xy, int pk_input, int sig_input, uint64_t* out_witness,
+                        uint64_t out_capacity_elems, uint64_t* out_instance, uint64_t* n_constraints, int* result) {
+    ValueScope s;
+    s.cs.n_inst = 1 + (pk_input ? 3 : 0) + (sig_input ? 6 : 0);
+    Bool r = bls_verify_circuit(limbs_to_aff1(pk_xy), msg, msg_len, limbs_to_aff2(sig_xy), nullptr, false, pk_input != 0, sig_input != 0);
+    if (result) *result = r.val;
+    if (n_constraints) *n_constraints = s.cs.ncons;
+    uint64_t n = s.cs.wit.size();
+    if (out_witness) memcpy(out_witness, s.cs.wit.data(), std::min(n, out_capacity_elems) * 48);
+    if (out_instance) {
+        Fp one = fp_one();
+        memcpy(out_instance, &one, 48);
+        if (!s.cs.inst.empty()) memcpy(out_instance + 6, s.cs.inst.data(), s.cs.inst.size() * 48);
+    }
+    return n;
+}
+// segment marks of that circuit shape (as orc_layout_params)
+uint64_t orc_layout_io(size_t msg_len, int pk_input, int sig_input, uint64_t* starts, uint64_t cap, char* names_buf, size_t names_cap, uint64_t* n_wit, uint64_t* n_cons) {
+    std::vector<uint8_t> msg(msg_len, 0);
+    G2Aff h = hash_to_g2_native(msg.data(), msg_len);
+    ValueScope s;
+    s.cs.n_inst = 1 + (pk_input ? 3 : 0) + (sig_input ? 6 : 0);
+    bls_verify_circuit(g1_generator(), msg.data(), msg_len, h, nullptr, false, pk_input != 0, sig_input != 0);
+    std::string names;
+    uint64_t k = 0;
+    for (auto& m : s.cs.marks) {
+        if (k < cap) starts[k] = m.second;
+        names += m.first;
+        names += '\n';
+        k++;
+    }
+    if (names_buf && names_cap) {
+        size_t c = std::min(names.size(), names_cap - 1);
+        memcpy(names_buf, names.data(), c);
+        names_buf[c] = 0;
+    }
+    if (n_wit) *n_wit = s.cs.wit.size();
+    if (n_cons) *n_cons = s.cs.ncons;
+    return k;
+}
 uint64_t orc_layout_params(size_t msg_len, int params_witness, uint64_t* starts, uint64_t cap, char* names_buf, size_t names_cap, uint64_t* n_wit,
                            uint64_t* n_cons) {
     std::vector<uint8_t> msg(msg_len, 0);
@@ -470,6 +512,15 @@ uint64_t orc_matrices(size_t msg_len, uint64_t n_keys, uint64_t n_pairs, uint64_
         std::vector<G1Aff> pks(n_pairs, g1_generator());
         bls_verify_multi_circuit(pks, msg.data(), msg_len, h);
     }
+    return export_csr(s, nnz, n_witness, row_ptr, col, val);
+}
+// the single-key circuit with the key / the signature as public inputs; columns: 0 = One, 1 .. n_inst - 1 = the inputs, n_inst + k = witness k
+uint64_t orc_matrices_io(size_t msg_len, int pk_input, int sig_input, uint64_t* nnz, uint64_t* n_witness, uint64_t** row_ptr, uint32_t** col, uint64_t** val) {
+    std::vector<uint8_t> msg(msg_len + 1, 0);
+    G2Aff h = hash_to_g2_native(msg.data(), msg_len);
+    ValueScope s(true);
+    s.cs.n_inst = 1 + (pk_input ? 3 : 0) + (sig_input ? 6 : 0);
+    bls_verify_circuit(g1_generator(), msg.data(), msg_len, h, nullptr, false, pk_input != 0, sig_input != 0);
     return export_csr(s, nnz, n_witness, row_ptr, col, val);
 }
 // the single-key circuit, parameters Constant or allocated as witnesses (constraints.rs:198-211)

@@ -268,6 +268,63 @@ int hostsim_witness_params(const uint64_t* pk_xy, const uint8_t* msg, uint32_t m
     bool res = pairing_segment(base, L, g1.ax, g1.ay, cs.data(), ch.data());
     return res ? 1 : 0;
 }
+// PublicKeyVar / SignatureVar allocated as public inputs (constraints.rs:214-249 with AllocationMode::Input): the statements of k_g1's / k_prepare's
+// Input paths. out_instance: [n_instance_vars][6] = instance_assignment (element 0 = one)
+int hostsim_witness_io(const uint64_t* pk_xy, const uint8_t* msg, uint32_t msg_len, const uint64_t* sig_xy, uint32_t pk_mode, uint32_t sig_mode, uint64_t* out,
+                       uint64_t* out_instance) {
+    blsw_layout_t L;
+    make_layout(msg_len, &L, 0, 1, false, pk_mode == 1, sig_mode == 1);
+    uint32_t* base = reinterpret_cast<uint32_t*>(out);
+    Fp* inst = reinterpret_cast<Fp*>(out_instance);
+    inst[0] = fp_one();
+    Emitter em = {base, L.off_msg};
+    for (uint32_t i = 0; i < msg_len; i++)
+        for (int j = 0; j < 8; j++) em.put_bool((msg[i] >> j) & 1);
+    Fp pkx = load_fp(pk_xy), pky = load_fp(pk_xy + 6);
+    Proj<OpsFp> pk;
+    if (pk_mode) {
+        const bool inf = fp_is_zero(pkx) && fp_is_zero(pky);
+        pk = {inf ? fp_zero() : pkx, inf ? fp_one() : pky, inf ? fp_zero() : fp_one()};
+        inst[1] = pk.x;
+        inst[2] = pk.y;
+        inst[3] = pk.z;
+    } else {
+        pk = chain_g1_alloc_only({base, L.off_pk_alloc}, pkx, pky);
+    }
+    G1ChainOut g1 = chain_g1_post({base, L.off_pk_not_zero}, {base, L.off_prep_pk}, pk);
+    Fp2 sx = {load_fp(sig_xy), load_fp(sig_xy + 6)}, sy = {load_fp(sig_xy + 12), load_fp(sig_xy + 18)};
+    bool sinf = fp2_is_zero(sx) && fp2_is_zero(sy);
+    Proj<OpsFp2> sp = {sinf ? fp2_zero() : sx, sinf ? fp2_one() : sy, sinf ? fp2_zero() : fp2_one()};
+    if (sig_mode) {
+        const uint32_t k0 = 1 + (pk_mode ? 3 : 0);
+        const Fp v[6] = {sp.x.c0, sp.x.c1, sp.y.c0, sp.y.c1, sp.z.c0, sp.z.c1};
+        for (int k = 0; k < 6; k++) inst[k0 + k] = v[k];
+    } else {
+        g2_alloc_segment(base, L, sx, sy);
+    }
+    std::vector<uint32_t> bits((L.sha_bits + 31) / 32 + 1, 0);
+    BitSink s;
+    s.init(bits.data(), 1);
+    uint32_t uw[64];
+    expand_message_w(s, msg, msg_len, false, uw);
+    if (s.nbits != L.sha_bits) return -1;
+    Emitter ex = {base, L.off_expand};
+    for (uint32_t i = 0; i < L.sha_bits; i++) ex.put_bool((bits[i >> 5] >> (i & 31)) & 1);
+    Fp2 u0 = {hash_to_field_elem(uw), hash_to_field_elem(uw + 16)};
+    Fp2 u1 = {hash_to_field_elem(uw + 32), hash_to_field_elem(uw + 48)};
+    Proj<OpsFp2> q0 = chain_map_to_curve({base, L.off_map0}, u0);
+    Proj<OpsFp2> q1 = chain_map_to_curve({base, L.off_map1}, u1);
+    Proj<OpsFp2> h = run_cofactor({base, L.off_add}, {base, L.off_cofactor}, q0, q1);
+    std::vector<Fp> ch(68 * 4), cs(68 * 4);
+    run_prepare({base, L.off_prep_h}, h, CoeffLinear{ch.data()});
+    run_prepare({base, L.off_prep_sig}, sp, CoeffLinear{cs.data()});
+    bool res = pairing_segment(base, L, g1.ax, g1.ay, cs.data(), ch.data());
+    return res ? 1 : 0;
+}
+int hostsim_layout_io(uint32_t msg_len, uint32_t pk_mode, uint32_t sig_mode, blsw_layout_t* L) {
+    make_layout(msg_len, L, 0, 1, false, pk_mode == 1, sig_mode == 1);
+    return 0;
+}
 // N+1-pair product circuit for one instance (blsw_verify_multi_batch): pks_xy [K][12], msgs [K][msg_len]
 struct HostPairs {
     const std::vector<std::vector<Fp>>* coeff;
@@ -439,14 +496,16 @@ int hostsim_sign(const uint8_t* sk32, const uint64_t* h_xy, uint8_t* sig96, uint
 }
 // R1CS evaluator (test side): checks <A_i, z> * <B_i, z> = <C_i, z> for every constraint with z = [1] ++ witness, matrices in
 // the CSR form blsw_matrices_fill writes. Returns the index of the first unsatisfied constraint, or -1.
-int64_t hostsim_r1cs_check(uint64_t n_cons, const uint64_t* const* row_ptr, const uint32_t* const* col, const uint64_t* const* val, const uint64_t* witness,
-                           uint64_t n_witness) {
+// z = [instance (n_inst elements, instance[0] = 1) | witness]: ark-relations' column order. instance == nullptr: z = [1 | witness]
+int64_t hostsim_r1cs_check_io(uint64_t n_cons, const uint64_t* const* row_ptr, const uint32_t* const* col, const uint64_t* const* val, const uint64_t* witness,
+                              uint64_t n_witness, const uint64_t* instance, uint64_t n_inst) {
+    if (!instance) n_inst = 1;
     auto dot = [&](int m, uint64_t i) {
         Fp acc = fp_zero();
         for (uint64_t k = row_ptr[m][i]; k < row_ptr[m][i + 1]; k++) {
             const uint32_t c = col[m][k];
-            if (c > n_witness) return fp_from_u32(0xdead);  // out of range: forces a mismatch
-            Fp z = c == 0 ? fp_one() : load_fp(witness + (uint64_t)(c - 1) * 6);
+            if (c >= n_inst + n_witness) return fp_from_u32(0xdead);  // out of range: forces a mismatch
+            Fp z = c == 0 ? fp_one() : (c < n_inst ? load_fp(instance + (uint64_t)c * 6) : load_fp(witness + (uint64_t)(c - n_inst) * 6));
             acc = fp_add(acc, fp_mul(load_fp(val[m] + k * 6), z));
         }
         return acc;
@@ -454,6 +513,10 @@ int64_t hostsim_r1cs_check(uint64_t n_cons, const uint64_t* const* row_ptr, cons
     for (uint64_t i = 0; i < n_cons; i++)
         if (!fp_eq(fp_mul(dot(0, i), dot(1, i)), dot(2, i))) return (int64_t)i;
     return -1;
+}
+int64_t hostsim_r1cs_check(uint64_t n_cons, const uint64_t* const* row_ptr, const uint32_t* const* col, const uint64_t* const* val, const uint64_t* witness,
+                           uint64_t n_witness) {
+    return hostsim_r1cs_check_io(n_cons, row_ptr, col, val, witness, n_witness, nullptr, 1);
 }
 // value-only hash_to_g2 (vcurve.hpp: what blsw_hash_to_g2_batch / blsw_sign_batch run per lane): expand_message values,
 // hash_to_field, SSWU + isogeny x 2, Q0 + Q1, psi-based cofactor clearing; affine result (all zero = identity)

@@ -12,7 +12,7 @@ _FIELDS = (
     "msg_len n_instance_vars n_witness sha_bits off_msg off_pk_alloc off_sig_alloc off_pk_not_zero off_expand off_map0 off_map1 "
     "off_add off_cofactor off_prep_h off_prep_pk off_prep_sig off_miller off_final_exp off_is_one n_keys off_keys off_bitmap off_count off_agg "
     "n_pairs stride_msg stride_pk_alloc stride_pk_not_zero stride_hash stride_prep_h stride_prep_pk "
-    "params_mode off_params_alloc off_prep_g1"
+    "params_mode off_params_alloc off_prep_g1 pk_mode sig_mode"
 ).split()
 
 
@@ -46,6 +46,24 @@ def witness(pk_xy, msg, sig_xy, params_mode=0):
     buf = (ctypes.c_uint8 * max(1, len(msg))).from_buffer_copy(bytes(msg) if len(msg) else b"\0")
     r = load().hostsim_witness_params(pk_xy.ctypes.data_as(u64p), buf, len(msg), sig_xy.ctypes.data_as(u64p), params_mode, out.ctypes.data_as(u64p))
     return r, out
+
+
+def layout_io(msg_len, pk_mode, sig_mode):
+    L = Lay()
+    load().hostsim_layout_io(msg_len, pk_mode, sig_mode, ctypes.byref(L))
+    return {n: getattr(L, n) for n in _FIELDS}
+
+
+def witness_io(pk_xy, msg, sig_xy, pk_mode=0, sig_mode=0):
+    """PublicKeyVar / SignatureVar allocated as public inputs (AllocationMode::Input): -> (result, witness [n_witness, 6], instance [n_instance_vars, 6])"""
+    pk_xy = np.ascontiguousarray(pk_xy, dtype=np.uint64)
+    sig_xy = np.ascontiguousarray(sig_xy, dtype=np.uint64)
+    lay = layout_io(len(msg), pk_mode, sig_mode)
+    out = np.zeros((lay["n_witness"], 6), dtype=np.uint64)
+    inst = np.zeros((lay["n_instance_vars"], 6), dtype=np.uint64)
+    buf = (ctypes.c_uint8 * max(1, len(msg))).from_buffer_copy(bytes(msg) if len(msg) else b"\0")
+    r = load().hostsim_witness_io(pk_xy.ctypes.data_as(u64p), buf, len(msg), sig_xy.ctypes.data_as(u64p), pk_mode, sig_mode, out.ctypes.data_as(u64p), inst.ctypes.data_as(u64p))
+    return r, out, inst
 
 
 def witness_aggregate(pks_xy, bitmap, msg, sig_xy):
@@ -97,9 +115,20 @@ def sign(sk_le32, h_xy):
     return st, bytes(sig), bytes(pk)
 
 
-def r1cs_check(mats, witness):
-    """A z o B z = C z for the matrices dict of pkg.matrices() and a witness array [n_witness, 6] uint64 -> first bad row or -1"""
+def r1cs_check(mats, witness, instance=None):
+    """A z o B z = C z for the matrices dict of pkg.matrices() and a witness array [n_witness, 6] uint64 -> first bad row or -1.
+    instance: [n_instance_vars, 6] (element 0 = one) for circuits with public inputs: z = [instance | witness]."""
     witness = np.ascontiguousarray(witness, dtype=np.uint64)
+    if instance is not None:
+        instance = np.ascontiguousarray(instance, dtype=np.uint64)
+        u32p = ctypes.POINTER(ctypes.c_uint32)
+        rp = (u64p * 3)(*[mats[k][0].ctypes.data_as(u64p) for k in "ABC"])
+        col = (u32p * 3)(*[mats[k][1].ctypes.data_as(u32p) for k in "ABC"])
+        val = (u64p * 3)(*[mats[k][2].ctypes.data_as(u64p) for k in "ABC"])
+        fn = load().hostsim_r1cs_check_io
+        fn.restype = ctypes.c_int64
+        return fn(ctypes.c_uint64(mats["n_constraints"]), rp, col, val, witness.ctypes.data_as(u64p), ctypes.c_uint64(witness.shape[0]), instance.ctypes.data_as(u64p),
+                  ctypes.c_uint64(instance.shape[0]))
     u32p = ctypes.POINTER(ctypes.c_uint32)
     rp = (u64p * 3)(*[mats[k][0].ctypes.data_as(u64p) for k in "ABC"])
     col = (u32p * 3)(*[mats[k][1].ctypes.data_as(u32p) for k in "ABC"])

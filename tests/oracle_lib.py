@@ -129,6 +129,31 @@ class Oracle:
         self.lib.orc_witness(pk_xy.ctypes.data_as(u64p), self._buf(msg), ctypes.c_size_t(len(msg)), sig_xy.ctypes.data_as(u64p), w.ctypes.data_as(u64p), ctypes.c_uint64(n), ctypes.byref(ncons), ctypes.byref(res))
         return n, ncons.value, bool(res.value), w
 
+    def witness_io(self, pk_xy, msg, sig_xy, pk_input=False, sig_input=False):
+        """the single-key circuit with the key / the signature allocated as PUBLIC INPUTS (constraints.rs:214-249 with AllocationMode::Input):
+        -> (n_witness, n_constraints, result, witness [n_witness, 6], instance [1 + 3 pk_input + 6 sig_input, 6] = instance_assignment incl. the leading one)"""
+        pk_xy = np.ascontiguousarray(pk_xy, dtype=np.uint64)
+        sig_xy = np.ascontiguousarray(sig_xy, dtype=np.uint64)
+        ncons, res = ctypes.c_uint64(0), ctypes.c_int(0)
+        self.lib.orc_witness_io.restype = ctypes.c_uint64
+        call = lambda w, cap, inst: self.lib.orc_witness_io(pk_xy.ctypes.data_as(u64p), self._buf(msg), ctypes.c_size_t(len(msg)), sig_xy.ctypes.data_as(u64p), ctypes.c_int(int(pk_input)),
+                                                            ctypes.c_int(int(sig_input)), w, ctypes.c_uint64(cap), inst, ctypes.byref(ncons), ctypes.byref(res))
+        n = call(None, 0, None)
+        w = np.zeros((n, 6), dtype=np.uint64)
+        inst = np.zeros((1 + 3 * int(pk_input) + 6 * int(sig_input), 6), dtype=np.uint64)
+        call(w.ctypes.data_as(u64p), n, inst.ctypes.data_as(u64p))
+        return n, ncons.value, bool(res.value), w, inst
+
+    def layout_io(self, msg_len=32, pk_input=False, sig_input=False):
+        starts = (ctypes.c_uint64 * 64)()
+        names = ctypes.create_string_buffer(4096)
+        nw, nc = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        self.lib.orc_layout_io.restype = ctypes.c_uint64
+        k = self.lib.orc_layout_io(ctypes.c_size_t(msg_len), ctypes.c_int(int(pk_input)), ctypes.c_int(int(sig_input)), starts, ctypes.c_uint64(64), names, ctypes.c_size_t(4096),
+                                   ctypes.byref(nw), ctypes.byref(nc))
+        nm = names.value.decode().split("\n")[:k]
+        return [(nm[i], starts[i]) for i in range(k)], nw.value, nc.value
+
     def witness_aggregate(self, pks_xy, bitmap, msg, sig_xy, want_vector=True):
         pks_xy = np.ascontiguousarray(pks_xy, dtype=np.uint64)
         sig_xy = np.ascontiguousarray(sig_xy, dtype=np.uint64)
@@ -169,13 +194,17 @@ class Oracle:
             self.lib.orc_witness_multi(*args(w.ctypes.data_as(u64p), n))
         return n, bool(res.value), marks, w
 
-    def matrices(self, msg_len=32, n_keys=0, n_pairs=1, params_mode=0):
+    def matrices(self, msg_len=32, n_keys=0, n_pairs=1, params_mode=0, pk_input=False, sig_input=False):
         """(n_constraints, n_witness, [(row_ptr, col, val) for A, B, C]) of the oracle's recorded R1CS for a circuit shape"""
         nnz = (ctypes.c_uint64 * 3)()
         nw = ctypes.c_uint64(0)
         self.lib.orc_matrices.restype = ctypes.c_uint64
         self.lib.orc_matrices_params.restype = ctypes.c_uint64
-        if params_mode:
+        self.lib.orc_matrices_io.restype = ctypes.c_uint64
+        if pk_input or sig_input:
+            assert n_keys == 0 and n_pairs == 1 and not params_mode
+            run = lambda a, b, c: self.lib.orc_matrices_io(ctypes.c_size_t(msg_len), ctypes.c_int(int(pk_input)), ctypes.c_int(int(sig_input)), nnz, ctypes.byref(nw), a, b, c)
+        elif params_mode:
             assert n_keys == 0 and n_pairs == 1
             run = lambda a, b, c: self.lib.orc_matrices_params(ctypes.c_size_t(msg_len), ctypes.c_int(params_mode), nnz, ctypes.byref(nw), a, b, c)
         else:

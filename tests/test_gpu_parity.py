@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from tests import synth
+from tests import hostsim_lib, synth
 from tests.oracle_lib import GOLDEN, eth_cases, unhex
 
 pytestmark = pytest.mark.gpu
@@ -103,6 +103,52 @@ def test_latency_kernels_bit_exact(pkg, oracle, latency_mode):
     finds the chains idle and takes them, the second does not), 2 = every group, 3 = values-first cofactor only, 4 = quads only. Three steps
     (groups of two and one), ragged waves, one instance with the identity as key and signature."""
     _grouped_engine_against_oracle(pkg, oracle, n=35, steps=3, identity_at=37, latency_mode=latency_mode)
+
+
+@pytest.mark.parametrize("pk_mode,sig_mode,max_steps", [(1, 1, 1), (1, 0, 2), (0, 1, 2), (1, 1, 2)])
+def test_public_input_allocation_modes(pkg, oracle, pk_mode, sig_mode, max_steps):
+    """PublicKeyVar / SignatureVar::new_variable with AllocationMode::Input (constraints.rs:214-249; options.pk_mode / sig_mode, blsw_engine_submit_io):
+    witness vectors AND instance_assignment against the oracle, direct mode (max_steps 1) and through the grouped engine (latency kernels and the
+    ordinary ones), a ragged batch with tampered instances and one identity key + signature; the GPU assignment satisfies the product's matrices."""
+    import torch
+
+    n, steps = 35, 3 if max_steps > 1 else 1
+    pk, msg, sig, expect = synth.make_batch(oracle, n * steps)
+    pk, sig = pk.copy(), sig.copy()
+    pk[5] = 0
+    sig[5] = 0
+    dev = torch.device("cuda:0")
+    eng = pkg.WitnessEngine(n, 32, max_steps=max_steps, device=dev, n_buffers=2 if max_steps > 1 else 1, pk_mode=pk_mode, sig_mode=sig_mode)
+    lay = eng.layout
+    assert eng.n_instance_vars == 1 + 3 * pk_mode + 6 * sig_mode and eng.n_witness == pkg.layout(32)["n_witness"] - 1942 * pk_mode - 12413 * sig_mode
+    outs, insts, ress, keep = [], [], [], []
+    for k in range(steps):
+        sl = slice(k * n, (k + 1) * n)
+        d = (torch.from_numpy(pk[sl].view(np.int64)).to(dev), torch.from_numpy(sig[sl].view(np.int64)).to(dev), torch.from_numpy(msg[sl]).to(dev))
+        w, inst, r = eng.new_witness_tensor(), eng.new_instance_tensor(), torch.empty(n, dtype=torch.int32, device=dev)
+        eng.submit(d[0], d[1], d[2], witness=w, result=r, instance=inst)
+        outs.append(w), insts.append(inst), ress.append(r), keep.append(d)
+        if max_steps == 1:
+            eng.flush()
+    eng.flush()
+    torch.cuda.synchronize()
+    P = None
+    for k in range(steps):
+        got = ress[k].cpu().numpy().astype(bool)
+        w = outs[k].cpu().numpy().view(np.uint64)
+        inst = insts[k].cpu().numpy().view(np.uint64)
+        for i in sorted(set(range(0, n, 6)) | ({5} if k == 0 else set())):
+            g = k * n + i
+            nw, _, res, ow, oinst = oracle.witness_io(pk[g], msg[g].tobytes(), sig[g], pk_mode, sig_mode)
+            assert res == bool(got[i]) and nw == eng.n_witness, (k, i)
+            assert np.array_equal(inst[i], oinst), "instance_assignment of instance %d" % g
+            bad = np.nonzero((ow != w[i]).any(axis=1))[0]
+            assert len(bad) == 0, "instance %d: first mismatching witness index %d" % (g, bad[0])
+            if P is None and g != 5:
+                P = pkg.matrices(32, pk_mode=pk_mode, sig_mode=sig_mode)
+                assert hostsim_lib.r1cs_check(P, w[i], inst[i]) == -1
+        assert np.array_equal(got[np.arange(n) != 5] if k == 0 else got, expect[k * n:(k + 1) * n][np.arange(n) != 5] if k == 0 else expect[k * n:(k + 1) * n])
+    eng.close()
 
 
 def test_reference_gadget_case(pkg, oracle):
