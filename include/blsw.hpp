@@ -88,7 +88,8 @@ inline std::vector<uint8_t> unhex(std::string s, size_t want) {
 }
 }  // namespace detail
 
-// ark_r1cs_std::alloc::AllocationMode. Input would put a value into instance_assignment, which the engine does not produce.
+// ark_r1cs_std::alloc::AllocationMode. PublicKeyVar / SignatureVar: Witness (the reference's circuits) or Input (the point's coordinates become
+// instance_assignment[1..]); ParametersVar: Constant or Witness.
 enum class AllocationMode { Constant, Input, Witness };
 
 // bls.rs:23-38: Parameters::default() is the standard G1 generator — the only value the engine knows
@@ -137,7 +138,10 @@ class ConstraintSystem {
     // cs.num_constraints(): the library synthesises the system symbolically on the host (a few seconds, once per call)
     uint64_t num_constraints() const {
         blsw_matrices_info_t info;
-        check(layout_.params_mode ? blsw_matrices_info_params(msg_len_, layout_.params_mode, &info) : blsw_matrices_info(msg_len_, layout_.n_keys, 1, &info), "blsw_matrices_info");
+        check(layout_.pk_mode || layout_.sig_mode ? blsw_matrices_info_io(msg_len_, layout_.pk_mode, layout_.sig_mode, &info)
+              : layout_.params_mode              ? blsw_matrices_info_params(msg_len_, layout_.params_mode, &info)
+                                                 : blsw_matrices_info(msg_len_, layout_.n_keys, 1, &info),
+              "blsw_matrices_info");
         return info.n_constraints;
     }
     const blsw_layout_t& layout() const { return layout_; }
@@ -148,18 +152,40 @@ class ConstraintSystem {
         witness_.download(w.data(), w.size() * 8, i * (size_t)layout_.n_witness * 48);
         return w;
     }
+    // instance_assignment of system i after verify: n_instance_vars elements (element 0 = one; then the coordinates of the points allocated with
+    // AllocationMode::Input, in allocation order), same element encoding as witness_assignment
+    std::vector<uint64_t> instance_assignment(size_t i) const {
+        if (i >= n_) throw Error("instance_assignment out of range", BLSW_ERR_ARG);
+        std::vector<uint64_t> v((size_t)layout_.n_instance_vars * 6);
+        if (layout_.n_instance_vars == 1 || !instance_.get()) {  // the constant one (R mod p)
+            if (layout_.n_instance_vars != 1) throw Error("instance_assignment before verify", BLSW_ERR_ARG);
+            const uint64_t one[6] = {0x760900000002fffdull, 0xebf4000bc40c0002ull, 0x5f48985753c758baull, 0x77ce585370525745ull, 0x5c071a97a256ec6dull, 0x15f65ec3fa80e493ull};
+            std::memcpy(v.data(), one, 48);
+            return v;
+        }
+        instance_.download(v.data(), v.size() * 8, i * v.size() * 8);
+        return v;
+    }
     // decode statuses (BLSW_ST_*) of (public key, signature) of system i after verify
     std::array<int32_t, 2> status(size_t i) const { return {status_.at(2 * i), status_.at(2 * i + 1)}; }
 
    private:
     friend class ParametersVar;
+    friend class PublicKeyVar;
+    friend class SignatureVar;
     friend struct BlsSignatureVerifyGadget;
     size_t n_;
     uint32_t msg_len_;
     int device_;
     blsw_layout_t layout_;
     blsw_engine_t* engine_ = nullptr;
-    detail::DeviceBytes workspace_, witness_, result_, d_status_, pk_xy_, sig_xy_;
+    detail::DeviceBytes workspace_, witness_, instance_, result_, d_status_, pk_xy_, sig_xy_;
+    // AllocationMode of the key / the signature: part of the circuit shape (blsw_layout_io)
+    void set_io(uint32_t pk_mode, uint32_t sig_mode) {
+        if (engine_) throw Error("new_variable after verify", BLSW_ERR_ARG);
+        if ((pk_mode || sig_mode) && (layout_.params_mode || layout_.n_keys)) throw Error("AllocationMode::Input: the single-key circuit with Constant parameters", BLSW_ERR_ARG);
+        if (pk_mode || sig_mode || layout_.pk_mode || layout_.sig_mode) check(blsw_layout_io(msg_len_, pk_mode, sig_mode, &layout_), "blsw_layout_io");
+    }
     std::vector<int32_t> status_;
 };
 
@@ -201,12 +227,14 @@ class ParametersVar {
     friend struct BlsSignatureVerifyGadget;
     ConstraintSystem* cs_ = nullptr;
 };
-// constraints.rs:214-232 / 234-249: Witness mode (G1Var / G2Var::new_variable with their in-circuit subgroup checks)
+// constraints.rs:214-232 / 234-249: Witness (G1Var / G2Var::new_variable with their in-circuit subgroup checks) or Input (the coordinates are public
+// inputs: new_variable_omit_prime_order_check); Constant keys / signatures are a different circuit and not offered
 class PublicKeyVar {
    public:
     static PublicKeyVar new_variable(ConstraintSystem& cs, const std::vector<PublicKey>& keys, AllocationMode mode) {
-        if (mode != AllocationMode::Witness) throw Error("PublicKeyVar: only AllocationMode::Witness is on the GPU path", BLSW_ERR_ARG);
+        if (mode == AllocationMode::Constant) throw Error("PublicKeyVar: AllocationMode::Constant is not on the GPU path", BLSW_ERR_ARG);
         if (keys.size() != cs.num_instances()) throw Error("PublicKeyVar::new_variable: one key per system", BLSW_ERR_ARG);
+        cs.set_io(mode == AllocationMode::Input ? 1u : 0u, cs.layout_.sig_mode);
         PublicKeyVar v;
         v.keys_ = keys;
         return v;
@@ -219,8 +247,9 @@ class PublicKeyVar {
 class SignatureVar {
    public:
     static SignatureVar new_variable(ConstraintSystem& cs, const std::vector<Signature>& sigs, AllocationMode mode) {
-        if (mode != AllocationMode::Witness) throw Error("SignatureVar: only AllocationMode::Witness is on the GPU path", BLSW_ERR_ARG);
+        if (mode == AllocationMode::Constant) throw Error("SignatureVar: AllocationMode::Constant is not on the GPU path", BLSW_ERR_ARG);
         if (sigs.size() != cs.num_instances()) throw Error("SignatureVar::new_variable: one signature per system", BLSW_ERR_ARG);
+        cs.set_io(cs.layout_.pk_mode, mode == AllocationMode::Input ? 1u : 0u);
         SignatureVar v;
         v.sigs_ = sigs;
         return v;
@@ -272,11 +301,14 @@ struct BlsSignatureVerifyGadget {
             check(blsw_engine_options_default(&opt), "blsw_engine_options_default");
             opt.device = cs.device_;
             opt.params_mode = cs.layout_.params_mode;
+            opt.pk_mode = cs.layout_.pk_mode;
+            opt.sig_mode = cs.layout_.sig_mode;
             uint64_t bytes = 0;
             check(blsw_engine_workspace_bytes_ex(n, cs.msg_len_, 1, 1, &opt, &bytes), "blsw_engine_workspace_bytes_ex");
             if (cs.device_ >= 0) hip_check(hipSetDevice(cs.device_), "hipSetDevice");
             cs.workspace_ = detail::DeviceBytes(bytes);
             cs.witness_ = detail::DeviceBytes(n * (size_t)cs.layout_.n_witness * 48);
+            cs.instance_ = detail::DeviceBytes(n * (size_t)cs.layout_.n_instance_vars * 48);
             cs.result_ = detail::DeviceBytes(n * 4);
             cs.d_status_ = detail::DeviceBytes(n * 8);
             cs.pk_xy_ = detail::DeviceBytes(n * 96);
@@ -292,17 +324,31 @@ struct BlsSignatureVerifyGadget {
         d_pk.upload(pk.data(), pk.size());
         d_sg.upload(sg.data(), sg.size());
         if (!message.bytes().empty()) d_msg.upload(message.bytes().data(), message.bytes().size());
-        check(blsw_engine_submit_bytes(cs.engine_, static_cast<const uint8_t*>(d_pk.get()), static_cast<const uint8_t*>(d_sg.get()),
-                                       static_cast<const uint8_t*>(d_msg.get()), static_cast<uint64_t*>(cs.pk_xy_.get()), static_cast<uint64_t*>(cs.sig_xy_.get()),
-                                       static_cast<int32_t*>(cs.d_status_.get()), static_cast<uint64_t*>(cs.witness_.get()), cs.layout_.n_witness,
-                                       static_cast<int32_t*>(cs.result_.get()), nullptr),
-              "blsw_engine_submit_bytes");
+        const bool io = cs.layout_.pk_mode || cs.layout_.sig_mode;
+        if (io) {  // public inputs: decode, then the step that also writes instance_assignment; the fallback rule of tests/tests.rs:244-263 is applied below
+            check(blsw_decode_batch(static_cast<const uint8_t*>(d_pk.get()), static_cast<const uint8_t*>(d_sg.get()), n, static_cast<uint64_t*>(cs.pk_xy_.get()),
+                                    static_cast<uint64_t*>(cs.sig_xy_.get()), static_cast<int32_t*>(cs.d_status_.get()), nullptr),
+                  "blsw_decode_batch");
+            check(blsw_engine_submit_io(cs.engine_, static_cast<const uint64_t*>(cs.pk_xy_.get()), static_cast<const uint64_t*>(cs.sig_xy_.get()),
+                                        static_cast<const uint8_t*>(d_msg.get()), static_cast<uint64_t*>(cs.instance_.get()), static_cast<uint64_t*>(cs.witness_.get()),
+                                        cs.layout_.n_witness, static_cast<int32_t*>(cs.result_.get()), nullptr),
+                  "blsw_engine_submit_io");
+        } else {
+            check(blsw_engine_submit_bytes(cs.engine_, static_cast<const uint8_t*>(d_pk.get()), static_cast<const uint8_t*>(d_sg.get()),
+                                           static_cast<const uint8_t*>(d_msg.get()), static_cast<uint64_t*>(cs.pk_xy_.get()), static_cast<uint64_t*>(cs.sig_xy_.get()),
+                                           static_cast<int32_t*>(cs.d_status_.get()), static_cast<uint64_t*>(cs.witness_.get()), cs.layout_.n_witness,
+                                           static_cast<int32_t*>(cs.result_.get()), nullptr),
+                  "blsw_engine_submit_bytes");
+        }
         check(blsw_engine_flush(cs.engine_, nullptr), "blsw_engine_flush");
         hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
         std::vector<int32_t> r(n);
         cs.result_.download(r.data(), n * 4);
         cs.status_.resize(2 * n);
         cs.d_status_.download(cs.status_.data(), n * 8);
+        if (io)
+            for (size_t i = 0; i < n; i++)
+                if (cs.status_[2 * i] | cs.status_[2 * i + 1]) r[i] = 0;
         Boolean b;
         b.v_.resize(n);
         for (size_t i = 0; i < n; i++) b.v_[i] = r[i] == 1;

@@ -151,6 +151,8 @@ int main(int argc, char** argv) {
         }
     }
     const bool params_witness = argc > 1 && !strcmp(argv[1], "witness");
+    // "input": the same test with the key and the signature allocated as PUBLIC INPUTS (constraints.rs:214-249 take any AllocationMode)
+    const bool io_input = argc > 1 && !strcmp(argv[1], "input");
     const bool count = argc > 2 && !strcmp(argv[2], "count-constraints");
     try {
         // use case from tests/test_cases/verify (constraints.rs:320-324)
@@ -173,8 +175,8 @@ int main(int argc, char** argv) {
 
         const Boolean result = BlsSignatureVerifyGadget::verify(
             ParametersVar::new_variable(cs, Parameters{}, params_witness ? AllocationMode::Witness : AllocationMode::Constant),
-            PublicKeyVar::new_variable(cs, std::vector<PublicKey>(3, public_key), AllocationMode::Witness), msg,
-            SignatureVar::new_variable(cs, std::vector<Signature>(3, sig), AllocationMode::Witness));
+            PublicKeyVar::new_variable(cs, std::vector<PublicKey>(3, public_key), io_input ? AllocationMode::Input : AllocationMode::Witness), msg,
+            SignatureVar::new_variable(cs, std::vector<Signature>(3, sig), io_input ? AllocationMode::Input : AllocationMode::Witness));
 
         for (int i = 0; i < 3; i++) {
             printf("verification_result_%d=%d ", i, (int)result.value()[i]);
@@ -186,6 +188,7 @@ int main(int argc, char** argv) {
         const std::vector<uint64_t> w0 = cs.witness_assignment(0), w2 = cs.witness_assignment(2);
         printf("num_witness_variables=%llu num_instance_variables=%llu status_pk=%d status_sig=%d digest0=%llu digest2=%llu", (unsigned long long)cs.num_witness_variables(),
                (unsigned long long)cs.num_instance_variables(), cs.status(0)[0], cs.status(0)[1], (unsigned long long)digest(w0), (unsigned long long)digest(w2));
+        printf(" instance_digest0=%llu", (unsigned long long)digest(cs.instance_assignment(0)));
         if (count) printf(" constraint_size=%llu", (unsigned long long)cs.num_constraints());  // "constraint size" of constraints.rs:369-373
         printf("\n");
         // the argument rules of the mirror

@@ -1493,6 +1493,14 @@ def test_cpp_host_mirror_reference_gadget_test(pkg, oracle):
             assert int(kv[key]) == digest(w), "%s parameters, system %d" % (mode, k)
         if pm == 0:
             assert int(kv["constraint_size"]) == ncons
+    # the same test with PublicKeyVar / SignatureVar allocated as public inputs (AllocationMode::Input): instance_assignment and witness_assignment
+    out = subprocess.check_output([os.path.join(root, "tests", "cpp_caller", "gadget_test"), "input", "count-constraints"], text=True, timeout=600)
+    kv = dict(p.split("=") for p in out.split())
+    assert [kv["verification_result_%d" % i] for i in range(3)] == ["1", "0", "0"] and kv["num_instance_variables"] == "10"
+    for k, key in ((0, "digest0"), (2, "digest2")):
+        n, ncons, res, w, inst = oracle.witness_io(pk, bytes.fromhex(g["messages"][k]), sig, 1, 1)
+        assert int(kv["num_witness_variables"]) == n and res == g["expected"][k] and int(kv[key]) == digest(w)
+    assert int(kv["instance_digest0"]) == digest(inst) and int(kv["constraint_size"]) == ncons
     # the reference's two aggregate_verify tests (constraints.rs:378-521) as the two systems of one batch: 512 keys, bitmaps {first two} / {all}
     out = subprocess.check_output([os.path.join(root, "tests", "cpp_caller", "gadget_test"), "aggregate"], text=True, timeout=600)
     kv = dict(p.split("=") for p in out.split())

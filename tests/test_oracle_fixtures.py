@@ -176,3 +176,16 @@ def test_witness_digest_goldens(oracle):
         assert hashlib.sha256(b.tobytes()).hexdigest() == c["sha256_all"], name
         for sname, lo, hi in pw["segments"]:
             assert hashlib.sha256(b[lo:hi].tobytes()).hexdigest() == c["sha256_segments"][sname], (name, sname)
+    # the sections for PublicKeyVar / SignatureVar allocated as public inputs (tools/t3_dumper --pk-input / --sig-input)
+    pi = {k: v for k, v in gold["public_inputs"].items() if not k.startswith("_")}
+    assert sorted(pi) == ["pk_input_sig_input", "pk_input_sig_witness", "pk_witness_sig_input"]
+    for key, sec in pi.items():
+        segs = {s[0]: (s[1], s[2]) for s in sec["segments"]}
+        assert segs["pk_alloc"][1] - segs["pk_alloc"][0] == (0 if sec["pk_mode"] else 1942) and segs["sig_alloc"][1] - segs["sig_alloc"][0] == (0 if sec["sig_mode"] else 12413)
+        for name, c in sec["cases"].items():
+            _, pk, _ = oracle.g1_decompress(bytes.fromhex(c["pubkey"]))
+            _, sig, _ = oracle.g2_decompress(bytes.fromhex(c["signature"]))
+            n, nc, res, w, inst = oracle.witness_io(pk, bytes.fromhex(c["message"]), sig, sec["pk_mode"], sec["sig_mode"])
+            assert (n, nc, bool(res), inst.shape[0]) == (c["n_witness"], c["n_constraints"], c["result"], c["n_instance_vars"]), (key, name)
+            assert hashlib.sha256(np.ascontiguousarray(inst).tobytes()).hexdigest() == c["sha256_instance"], (key, name)
+            assert hashlib.sha256(np.ascontiguousarray(w).tobytes()).hexdigest() == c["sha256_all"], (key, name)
