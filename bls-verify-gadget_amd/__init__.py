@@ -116,6 +116,8 @@ def lib():
         L.blsw_aggregate_points_workspace_bytes.argtypes = [u32, u64, u32, ctypes.POINTER(u64)]
         L.blsw_aggregate_points_batch.argtypes = [u32, vp, u32, u64, vp, vp, vp, u64, vp]
         L.blsw_sign_batch.argtypes = [vp, vp, u32, u64, vp, vp, vp, vp, vp, vp, u64, vp]
+        L.blsw_verify_workspace_bytes.argtypes = [u64, u32, ctypes.POINTER(u64)]
+        L.blsw_verify_batch.argtypes = [vp, vp, vp, u32, u64, vp, vp, vp, u64, vp]
         L.blsw_microbench.argtypes = [ctypes.c_int, u32, u32, ctypes.POINTER(ctypes.c_double)]
         L.blsw_fill_rate.argtypes = [vp, u64, u32, ctypes.POINTER(ctypes.c_double)]
         _lib = L
@@ -126,7 +128,7 @@ EXPORTED_SYMBOLS = ["blsw_version", "blsw_layout", "blsw_engine_options_default"
                     "blsw_engine_create_ex", "blsw_engine_destroy", "blsw_engine_submit", "blsw_engine_submit_bytes", "blsw_engine_submit_multi", "blsw_engine_submit_multi_compact", "blsw_engine_submit_aggregate", "blsw_engine_flush", "blsw_engine_submitted", "blsw_engine_launched", "blsw_engine_materialised", "blsw_engine_wait_step",
                     "blsw_engine_output_consumed", "blsw_engine_compact_bytes", "blsw_engine_submit_compact", "blsw_engine_submit_aggregate_compact", "blsw_engine_expand_compact", "blsw_engine_expand_stats", "blsw_witness_digest", "blsw_hash_to_g2_workspace_bytes", "blsw_hash_to_g2_batch",
                     "blsw_decode_batch", "blsw_layout_aggregate", "blsw_aggregate_workspace_bytes", "blsw_aggregate_verify_batch", "blsw_layout_multi",
-                    "blsw_verify_multi_workspace_bytes", "blsw_verify_multi_batch", "blsw_matrices_info", "blsw_matrices_fill", "blsw_sign_batch", "blsw_microbench", "blsw_fill_rate", "blsw_layout_io", "blsw_engine_submit_io", "blsw_matrices_info_io", "blsw_matrices_fill_io",
+                    "blsw_verify_multi_workspace_bytes", "blsw_verify_multi_batch", "blsw_matrices_info", "blsw_matrices_fill", "blsw_sign_batch", "blsw_microbench", "blsw_fill_rate", "blsw_layout_io", "blsw_engine_submit_io", "blsw_verify_workspace_bytes", "blsw_verify_batch", "blsw_matrices_info_io", "blsw_matrices_fill_io",
                     "blsw_layout_params", "blsw_matrices_info_params", "blsw_matrices_fill_params", "blsw_aggregate_points_workspace_bytes", "blsw_aggregate_points_batch"]
 
 
@@ -626,6 +628,47 @@ def aggregate_signatures(sig96):
 
 def aggregate_public_keys(pk48):
     return aggregate_points(1, pk48)
+
+
+_VERIFY_WS = {}
+
+
+def verify_batch(pk48, msg, sig96, want_status=False):
+    """BLS::verify (bls.rs:427-458) for a batch as VALUES (blsw_verify_batch: the native algorithm — decode with subgroup checks, hash to G2, a two-pair
+    Miller loop over projective lines, final exponentiation — no circuit): uint8 cuda tensors pk48 [n, 48], msg [n, msg_len], sig96 [n, 96] ->
+    int32 [n] verdicts (1 / 0; every Err of the reference's verify counts as false), optionally with the decode statuses [n, 2]."""
+    torch = _require_cuda()
+    n, msg_len = pk48.shape[0], msg.shape[1]
+    assert pk48.shape == (n, 48) and sig96.shape == (n, 96) and msg.shape[0] == n and pk48.is_contiguous() and sig96.is_contiguous() and msg.is_contiguous()
+    dev = pk48.device
+    wb = ctypes.c_uint64(0)
+    rc = lib().blsw_verify_workspace_bytes(n, msg_len, ctypes.byref(wb))
+    if rc:
+        raise BlswError("blsw_verify_workspace_bytes failed: %d" % rc)
+    key = (str(dev), wb.value)
+    ws = _VERIFY_WS.get(key)
+    if ws is None:  # one workspace per (device, size): repeated calls of one batch shape (a verifier's loop) do not reallocate
+        _VERIFY_WS.clear()
+        ws = _VERIFY_WS[key] = torch.empty(wb.value, dtype=torch.uint8, device=dev)
+    res = torch.empty(n, dtype=torch.int32, device=dev)
+    status = torch.empty((n, 2), dtype=torch.int32, device=dev)
+    rc = lib().blsw_verify_batch(pk48.data_ptr(), sig96.data_ptr(), msg.data_ptr() if msg_len else None, msg_len, n, res.data_ptr(), status.data_ptr(), ws.data_ptr(), ws.numel(),
+                                 torch.cuda.current_stream(dev).cuda_stream)
+    if rc:
+        raise BlswError("blsw_verify_batch failed: %d" % rc)
+    return (res, status) if want_status else res
+
+
+def fast_aggregate_verify_batch(pks48, msg, sig96):
+    """tests/tests.rs:296-334: n instances of k compressed keys each signing ONE message: PublicKey::aggregate (blsw_aggregate_points_batch), then
+    BLS::verify on the aggregate (blsw_verify_batch). A key that does not decode, an empty list or an identity aggregate is false. -> int32 [n]"""
+    torch = _require_cuda()
+    n = pks48.shape[0]
+    if pks48.shape[1] == 0:
+        return torch.zeros(n, dtype=torch.int32, device=pks48.device)
+    agg, st = aggregate_points(1, pks48)
+    res = verify_batch(agg, msg, sig96)
+    return torch.where(st == 0, res, torch.zeros_like(res))
 
 
 def verify_bytes_batch(pk48, msg, sig96):

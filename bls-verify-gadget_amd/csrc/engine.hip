@@ -934,6 +934,54 @@ int blsw_hash_to_g2_batch(const uint8_t* d_msg, uint32_t msg_len, uint64_t n, ui
     hipLaunchKernelGGL(k_h_to_affine, dim3(g1), dim3(64), 0, st, n, g.ws, d_out_affine);
     return hip_ok(hipGetLastError(), "launch");
 }
+// BLS::verify (bls.rs:427-458) for a batch of compressed (pk, sig) and messages, as VALUES (no circuit): decode with the endomorphism subgroup checks,
+// the value-only hash to G2, projective line coefficients and a two-pair Miller loop + final exponentiation on the six-lane team (vpairing.hpp).
+// d_result[i] = 1 iff both points decode to non-identity subgroup points and e(-g1, sig) e(pk, H(m)) = 1; d_status [n][2] as blsw_decode_batch.
+static uint64_t verify_workspace(uint64_t n, const blsw_layout_t& L, uint64_t* off_pk, uint64_t* off_sig, uint64_t* off_ls, uint64_t* off_lh, uint64_t* off_ws) {
+    uint64_t o = 256;  // the step descriptor
+    *off_pk = o;
+    o = align_up(o + n * 96, 256);
+    *off_sig = o;
+    o = align_up(o + n * 192, 256);
+    *off_ls = o;
+    o = align_up(o + (uint64_t)BLSW_VLINE_ROWS * n * sizeof(Fp), 256);
+    *off_lh = o;
+    o = align_up(o + (uint64_t)BLSW_VLINE_ROWS * n * sizeof(Fp), 256);
+    *off_ws = o;
+    return o + carve(nullptr, n, L, false, DEFAULT_MODES).total_bytes;
+}
+int blsw_verify_workspace_bytes(uint64_t n, uint32_t msg_len, uint64_t* bytes) {
+    if (!bytes || n == 0 || n > 0x7fffffffu || msg_len > 65535) return BLSW_ERR_ARG;
+    blsw_layout_t L;
+    make_layout(msg_len, &L);
+    uint64_t a, b, c, d, e;
+    *bytes = verify_workspace(n, L, &a, &b, &c, &d, &e);
+    return BLSW_OK;
+}
+int blsw_verify_batch(const uint8_t* d_pk48, const uint8_t* d_sig96, const uint8_t* d_msg, uint32_t msg_len, uint64_t n, int32_t* d_result, int32_t* d_status,
+                      void* d_workspace, uint64_t workspace_bytes, void* stream_) {
+    if (!d_pk48 || !d_sig96 || (!d_msg && msg_len) || n == 0 || n > 0x7fffffffu || !d_result || !d_status || !d_workspace || msg_len > 65535) return BLSW_ERR_ARG;
+    blsw_layout_t L;
+    make_layout(msg_len, &L);
+    uint64_t off_pk, off_sig, off_ls, off_lh, off_ws;
+    if (verify_workspace(n, L, &off_pk, &off_sig, &off_ls, &off_lh, &off_ws) > workspace_bytes) return BLSW_ERR_WORKSPACE;
+    char* base = reinterpret_cast<char*>(d_workspace);
+    StepDesc* d_desc = reinterpret_cast<StepDesc*>(base);
+    uint64_t* pk_xy = reinterpret_cast<uint64_t*>(base + off_pk);
+    uint64_t* sig_xy = reinterpret_cast<uint64_t*>(base + off_sig);
+    Group g = direct_group(n, 1, msg_len, L, d_desc, carve(base + off_ws, n, L, false, DEFAULT_MODES));
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream_);
+    DeviceGuard guard(stream_device(st));
+    StepDesc h = {nullptr, nullptr, d_msg, nullptr, 0, nullptr, nullptr, nullptr, nullptr};
+    if (int rc = put_desc(d_desc, h, st)) return rc;
+    const unsigned g1 = (unsigned)((n + 63) / 64), g2 = (unsigned)((2 * n + 63) / 64);
+    hipLaunchKernelGGL(k_decode, dim3(g2), dim3(64), 0, st, d_pk48, d_sig96, n, pk_xy, sig_xy, d_status);
+    hipLaunchKernelGGL(k_sha_values, dim3(g1), dim3(64), 0, st, g);
+    hipLaunchKernelGGL(k_map_values, dim3(g2), dim3(64), 0, st, g);
+    hipLaunchKernelGGL(k_cofactor_values, dim3(g1), dim3(64), 0, st, g);
+    launch_verify_values(n, g.ws, pk_xy, sig_xy, reinterpret_cast<Fp*>(base + off_ls), reinterpret_cast<Fp*>(base + off_lh), d_status, d_result, st);
+    return hip_ok(hipGetLastError(), "launch");
+}
 // BLS::sign + PublicKey::from(&sk) for a batch (bls.rs:411-425, 183-195). Workspace: blsw_hash_to_g2_workspace_bytes.
 int blsw_sign_batch(const uint8_t* d_sk32_le, const uint8_t* d_msg, uint32_t msg_len, uint64_t n, uint8_t* d_sig96, uint64_t* d_sig_xy, uint8_t* d_pk48,
                     uint64_t* d_pk_xy, int32_t* d_status, void* d_workspace, uint64_t workspace_bytes, void* stream_) {

@@ -125,6 +125,58 @@ __global__ __launch_bounds__(64) void k_pairing_team_multi(Group gs, uint32_t K,
     int32_t* r = gs.desc[id.s].result;
     if (active && j == 0 && r) r[id.i] = step_result(gs.desc[id.s], id.i, res);
 }
+// blsw_verify_batch, phase 1: the projective line coefficients of the two G2 points of an instance (vpairing.hpp). Lanes [0, n): the signature against
+// -g1; lanes [n, 2 n): H(m) (ws.h, homogeneous) against the public key. A point that is the identity (or failed to decode: zeros) gets zero lines —
+// the verdict of such an instance is false by its status.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_vlines(uint64_t n, Workspace ws, const uint64_t* __restrict__ pk_xy, const uint64_t* __restrict__ sig_xy,
+                                                                                      Fp* lines_sig, Fp* lines_h) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 2 * n) return;
+    const bool is_h = t >= n;
+    const uint64_t i = is_h ? t - n : t;
+    Fp2 qx, qy;
+    Fp px, py;
+    if (!is_h) {
+        const Fp* p = reinterpret_cast<const Fp*>(sig_xy + i * 24);
+        qx = {ld_fp(p), ld_fp(p + 1)};
+        qy = {ld_fp(p + 2), ld_fp(p + 3)};
+        px = K_G1_GEN_X();
+        py = K_G1_GEN_NEG_Y();
+    } else {
+        const Proj<OpsFp2> h = ld_proj2(ws.h + i, n);
+        const Fp2 zi = fp2_inv_inl(h.z);  // 0 for the identity
+        qx = fp2_mul_inl(h.x, zi);
+        qy = fp2_mul_inl(h.y, zi);
+        const Fp* p = reinterpret_cast<const Fp*>(pk_xy + i * 12);
+        px = ld_fp(p);
+        py = ld_fp(p + 1);
+    }
+    vline_chain(qx, qy, px, py, CoeffStrided{(is_h ? lines_h : lines_sig) + i, n});
+}
+// phase 2: six lanes per instance fold the 2 x 68 lines (value-only Miller loop), final exponentiation, is_one; the verdict also needs both decode
+// statuses BLSW_ST_OK (bls.rs:431-447: identity key, on-curve and subgroup checks are errors, which tests/tests.rs:244-263 count as false)
+__global__ __launch_bounds__(64) void k_verify_team(uint64_t n, const Fp* lines_sig, const Fp* lines_h, const int32_t* __restrict__ status, int32_t* __restrict__ result) {
+    __shared__ Fp2 lds[BLSW_TEAMS_PER_WAVE * TS_NSLOTS];
+    const uint32_t team = threadIdx.x / 6, j = threadIdx.x % 6;
+    const uint64_t I0 = (uint64_t)blockIdx.x * BLSW_TEAMS_PER_WAVE + team;
+    const bool active = team < BLSW_TEAMS_PER_WAVE && I0 < n;
+    const uint64_t I = active ? I0 : 0;
+    TeamLanesValues t;
+    t.slots = lds + (active ? team : 0) * TS_NSLOTS;
+    t.j = j;
+    t.active = active;
+    t.coeff_sig = {const_cast<Fp*>(lines_sig) + I, n};
+    t.coeff_h = {const_cast<Fp*>(lines_h) + I, n};
+    t.e = {nullptr, 0};
+    Fp2 f = team_miller_values(t);
+    const bool one = team_final_exp_is_one(t, f, Emitter{nullptr, 0});
+    if (active && j == 0) result[I] = (one && status[2 * I] == BLSW_ST_OK && status[2 * I + 1] == BLSW_ST_OK) ? 1 : 0;
+}
+void launch_verify_values(uint64_t n, const Workspace& ws, const uint64_t* pk_xy, const uint64_t* sig_xy, Fp* lines_sig, Fp* lines_h, const int32_t* status, int32_t* result,
+                          hipStream_t st) {
+    hipLaunchKernelGGL(k_vlines, dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, st, n, ws, pk_xy, sig_xy, lines_sig, lines_h);
+    hipLaunchKernelGGL(k_verify_team, dim3((unsigned)((n + BLSW_TEAMS_PER_WAVE - 1) / BLSW_TEAMS_PER_WAVE)), dim3(64), 0, st, n, (const Fp*)lines_sig, (const Fp*)lines_h, status, result);
+}
 void launch_pairing(const Group& g, const Modes& m, hipStream_t st) {
     if (g.L.params_mode)
         hipLaunchKernelGGL(k_pairing_team_pv, dim3((unsigned)((g.N + BLSW_TEAMS_PER_WAVE - 1) / BLSW_TEAMS_PER_WAVE)), dim3(64), 0, st, g);

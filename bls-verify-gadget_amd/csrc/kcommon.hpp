@@ -545,5 +545,9 @@ inline void launch_g2_alloc(const ChainKernels& ck, Latency lat, const Group& g,
 // host-side launch helpers that live next to their (templated) kernels
 void launch_expand(uint32_t variant, uint32_t store, unsigned lds, hipStream_t st, ExpandArgs a, unsigned n_y);
 void launch_pairing(const Group& g, const Modes& m, hipStream_t st);
+#define BLSW_VLINE_ROWS (6u * 68u)  // vpairing.hpp: per G2 point, 68 steps x (c0, c1 x_P, c2 y_P), two Fp each
+// blsw_verify_batch: projective lines of (sig, H(m)) then the six-lane value-only pairing check (k_team.hip, vpairing.hpp)
+void launch_verify_values(uint64_t n, const Workspace& ws, const uint64_t* pk_xy, const uint64_t* sig_xy, Fp* lines_sig, Fp* lines_h, const int32_t* status, int32_t* result,
+                          hipStream_t st);
 
 }  // namespace blsw

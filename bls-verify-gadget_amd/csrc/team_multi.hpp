@@ -2,6 +2,7 @@
 #pragma once
 #include "kcommon.hpp"
 #include "team.hpp"
+#include "vpairing.hpp"
 
 namespace blsw {
 
@@ -21,6 +22,15 @@ struct TeamLanesMulti : TeamLanes<CoeffStrided> {
             if (j == 4) py = ld_fp(pkaff + n_h + t);
             team_load_pair_lane(j, slots, CoeffStrided{const_cast<Fp*>(coeff_h_all) + t, n_h}, k, px, py);
         }
+        team_sync();
+    }
+};
+
+// the native pairing of blsw_verify_batch (vpairing.hpp): coeff_sig / coeff_h hold the 68 projective line triples of the two G2 points
+struct TeamLanesValues : TeamLanes<CoeffStrided> {
+    BLSW_TEAM_DEV Reg one() const { return j == 0 ? fp2_one() : fp2_zero(); }
+    BLSW_TEAM_DEV void load_lines(uint32_t k) {
+        if (active) team_load_lines_lane(j, slots, coeff_sig, coeff_h, k);
         team_sync();
     }
 };

@@ -360,6 +360,17 @@ int blsw_hash_to_g2_batch(const uint8_t* d_msg, uint32_t msg_len, uint64_t n, ui
 int blsw_sign_batch(const uint8_t* d_sk32_le, const uint8_t* d_msg, uint32_t msg_len, uint64_t n, uint8_t* d_sig96, uint64_t* d_sig_xy, uint8_t* d_pk48,
                     uint64_t* d_pk_xy, int32_t* d_status, void* d_workspace, uint64_t workspace_bytes, void* stream);
 
+/* BLS::verify (src/bls.rs:427-458; tests/tests.rs:239-268) for a batch, as VALUES — the native algorithm, not the circuit: decode of the compressed key and
+ * signature with the endomorphism subgroup checks (as blsw_decode_batch), hash_to_g2 (as blsw_hash_to_g2_batch), a two-pair Miller loop over projective
+ * line coefficients (no inversion per step) and the final exponentiation on six lanes per instance, is_one.
+ *   d_pk48 [n][48], d_sig96 [n][96], d_msg [n][msg_len];  d_result [n] int32: 1 iff both points decode to non-identity points of the prime-order
+ *   subgroups and e(-g1, sig) * e(pk, H(msg)) == 1 (every Err of the reference's verify counts as false, as tests/tests.rs:244-263 does);
+ *   d_status [n][2] BLSW_ST_* of key and signature. Asynchronous on `stream` after one synchronising descriptor copy. fast_aggregate_verify
+ *   (tests/tests.rs:296-334) = blsw_aggregate_points_batch over the keys, then this. */
+int blsw_verify_workspace_bytes(uint64_t n, uint32_t msg_len, uint64_t* bytes);
+int blsw_verify_batch(const uint8_t* d_pk48, const uint8_t* d_sig96, const uint8_t* d_msg, uint32_t msg_len, uint64_t n, int32_t* d_result, int32_t* d_status,
+                      void* d_workspace, uint64_t workspace_bytes, void* stream);
+
 /* Device micro-benchmarks that give the VALU roofline its MEASURED denominator:
  * which = 0: v_mad_u64_u32 rate (32x32+64 multiply-adds per second, all CUs); 1: Fp Montgomery products per second;
  * 2: Fp inversions (safegcd) per second; 3: Fp products per second inside witness-emitting Fp2 mul + sqr;

@@ -13,6 +13,7 @@
 #include "../../bls-verify-gadget_amd/csrc/cofactor_par.hpp"
 #include "../../bls-verify-gadget_amd/csrc/cofactor_vf.hpp"
 #include "../../bls-verify-gadget_amd/csrc/prepare_vf.hpp"
+#include "../../bls-verify-gadget_amd/csrc/vpairing.hpp"
 #include <array>
 
 using namespace blsw;
@@ -69,6 +70,15 @@ struct TeamHost {
         Reg r;
         for (uint32_t j = 0; j < 6; j++) r[j] = team_first_f(j, slots);
         return r;
+    }
+    // native pairing (vpairing.hpp: team_miller_values)
+    Reg one() const {
+        Reg r = zero();
+        r[0] = fp2_one();
+        return r;
+    }
+    void load_lines(uint32_t k) {
+        for (uint32_t j = 0; j < 6; j++) team_load_lines_lane(j, slots, coeff_sig, coeff_h, k);
     }
     // ParametersVar allocated as witnesses (team_miller_pv)
     Fp pkx, pky;
@@ -538,6 +548,26 @@ void hostsim_hash_to_g2_values(const uint8_t* msg, uint32_t msg_len, uint64_t* o
     memcpy(out_xy + 6, x.c1.l, 48);
     memcpy(out_xy + 12, y.c0.l, 48);
     memcpy(out_xy + 18, y.c1.l, 48);
+}
+// blsw_verify_batch's per-instance logic (k_decode, the value-only hash, k_vlines, k_verify_team): verdict from compressed bytes; st[2] = decode statuses
+int hostsim_verify_values(const uint8_t* pk48, const uint8_t* sig96, const uint8_t* msg, uint32_t msg_len, int32_t* st) {
+    Fp px, py;
+    Fp2 sx, sy;
+    st[0] = g1_decode(pk48, px, py);
+    st[1] = g2_decode(sig96, sx, sy);
+    uint64_t h_xy[24];
+    hostsim_hash_to_g2_values(msg, msg_len, h_xy);
+    const Fp2 hx = {load_fp(h_xy), load_fp(h_xy + 6)}, hy = {load_fp(h_xy + 12), load_fp(h_xy + 18)};
+    std::vector<Fp> ls(BLSW_VLINE_ROWS), lh(BLSW_VLINE_ROWS);
+    vline_chain(sx, sy, K_G1_GEN_X(), K_G1_GEN_NEG_Y(), CoeffLinear{ls.data()});
+    vline_chain(hx, hy, px, py, CoeffLinear{lh.data()});
+    TeamHost t;
+    t.coeff_sig = CoeffLinear{ls.data()};
+    t.coeff_h = CoeffLinear{lh.data()};
+    t.e = {nullptr, 0};
+    TeamHost::Reg f = team_miller_values(t);
+    const bool one = team_final_exp_is_one(t, f, Emitter{nullptr, 0});
+    return (one && st[0] == 0 && st[1] == 0) ? 1 : 0;
 }
 // clear_cofactor2 of a given pair (Q0, Q1) of affine points (z = 1; all zero = the identity (0, 0, 0)): the serial chain and the
 // chunked one write their "add" + "cofactor" segments (36 + 8979 elements each) and results; returns 1 if everything is equal

@@ -105,6 +105,16 @@ def hash_to_g2_values(msg):
     return out
 
 
+def verify_values(pk48, sig96, msg):
+    """blsw_verify_batch's per-instance logic on the host: (verdict, status_pk, status_sig)"""
+    st = (ctypes.c_int32 * 2)()
+    pk = (ctypes.c_uint8 * 48).from_buffer_copy(bytes(pk48).ljust(48, b"\0")[:48])
+    sg = (ctypes.c_uint8 * 96).from_buffer_copy(bytes(sig96).ljust(96, b"\0")[:96])
+    m = (ctypes.c_uint8 * max(1, len(msg))).from_buffer_copy(bytes(msg) if len(msg) else b"\0")
+    r = load().hostsim_verify_values(pk, sg, m, len(msg), st)
+    return r, st[0], st[1]
+
+
 def sign(sk_le32, h_xy):
     """device signer logic on the host: (status, sig96, pk48)"""
     h_xy = np.ascontiguousarray(h_xy, dtype=np.uint64)

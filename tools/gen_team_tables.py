@@ -82,8 +82,9 @@ ZERO = LC()
 
 
 class Op:
-    def __init__(self, name):
+    def __init__(self, name, value_only=False):
         self.name = name
+        self.value_only = value_only  # every product as the value-only kind (no witness): the native pairing of blsw_verify_batch
         self.tasks = []  # dicts in emission order
         self.woff = 0
         self.np = 0
@@ -100,7 +101,7 @@ class Op:
         return LC.slot(dst) if want_result else None
 
     def mul3(self, a, b):
-        return self._task(K3, a, b)
+        return self._task(K3V if self.value_only else K3, a, b)
 
     def mul2(self, a, y, witness):  # Fp2 x (y, 0)
         return self._task(K2 if witness else K2V, a, y)
@@ -201,6 +202,17 @@ def fp12_mul_by_014_w(op, f, c0, c1, y, yvar):
     return [new_c0, new_c1]
 
 
+def fp12_mul_by_014_general(op, f, c0, c1, c4):
+    """f * (c0 + c1 v + c4 v w) with THREE general Fp2 coefficients (ark-ff Fp12::mul_by_014): 13 Fp2 products, value only"""
+    aa = fp6_mul_by_c0_c1_0_w(op, f[0], c0, c1)
+    v1 = op.mul3(f[1][1], c4)  # f.c1 * (0, c4, 0)
+    t0 = op.mul3(f[1][1] + f[1][2], c4)
+    t1 = op.mul3(f[1][0] + f[1][1], c4)
+    bb = [(t0 - v1).xi(), t1 - v1, v1]
+    t = fp6_mul_by_c0_c1_0_w(op, fp6_add(f[0], f[1]), c0, c1 + c4)
+    return [fp6_add(fp6_mul_v(bb), aa), fp6_sub(fp6_sub(t, aa), bb)]
+
+
 def reg(base):
     s = [LC.slot(base + j) for j in range(6)]
     return [s[0:3], s[3:6]]
@@ -254,6 +266,12 @@ def build_ops():
     op = Op("ELLV")  # ell for (pk, H(m)): k0 = c1.c0*px, k1 = c1.c1*px are witnesses, y = pk.y variable
     c1 = op.mul2b(LC.slot(XH1), LC.slot(XPX))
     ops.append(finish(op, fp12_mul_by_014_w(op, a, LC.slot(XH0), c1, LC.slot(XYV), True)))
+
+    # ---- native (value-only) pairing of blsw_verify_batch: ell with projective line coefficients (c0, c1 * p.x, c2 * p.y) in the pair slots
+    op = Op("ELLGS", value_only=True)  # the (-g1, sig) pair: XS0, XS1, XYC
+    ops.append(finish(op, fp12_mul_by_014_general(op, a, LC.slot(XS0), LC.slot(XS1), LC.slot(XYC))))
+    op = Op("ELLGH", value_only=True)  # the (pk, H(m)) pair: XH0, XH1, XYV
+    ops.append(finish(op, fp12_mul_by_014_general(op, a, LC.slot(XH0), LC.slot(XH1), LC.slot(XYV))))
 
     # ---- G2 points, homogeneous projective (x, y, z) on lanes 0..2 (curve.hpp: proj_double_w / proj_add_w<0> over Fp2;
     # 3b = 12 xi). IN0 = p (slots 0..2), IN1 = q (slots 6..8).
