@@ -180,6 +180,7 @@ def side_legs(args, pkg, workload, dev, fpmul_peak, opc):
                       groups of 4, three in flight, ring of two 67 GB tensors, free running) — HBM-bound: output bytes / time against 8 TB/s
       hash_to_g2_1M   configs[4]: SSWU + cofactor clearing for 1 M messages (value-only kernels) — VALU-bound: executed Fp products against the measured rate
       compact_form    configs[1] with the steps leaving in the compact wire form (2.6 MB per instance, what a sharded run ships) — VALU-bound
+      verify_batch    BLS::verify as values for 65 536 triples from compressed bytes (the native batch verifier) — VALU-bound
     """
     import numpy as np
     import torch
@@ -255,6 +256,36 @@ def side_legs(args, pkg, workload, dev, fpmul_peak, opc):
         del eng, cbufs
     except Exception as exc:  # noqa: BLE001
         legs["compact_form"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+    torch.cuda.empty_cache()
+
+    # ---- BLS::verify as values (bls.rs:427-458; tests/tests.rs:239-268): the native batch verifier, 65 536 (pk, msg, sig) triples from compressed bytes
+    try:
+        nv = 1 << 16
+        sk = np.frombuffer(b"".join(workload.secret_keys(0x5EED, 16)[i % 16].to_bytes(32, "little") for i in range(nv)), dtype=np.uint8).reshape(nv, 32).copy()
+        vmsg_h = workload.messages(0x5EED, 0, nv)
+        vmsg_h[15::16, 31] ^= 1  # every 16th message tampered after signing
+        signed = pkg.sign_batch(torch.from_numpy(sk).to(dev), torch.from_numpy(workload.messages(0x5EED, 0, nv)).to(dev))
+        vmsg = torch.from_numpy(vmsg_h).to(dev)
+        res = pkg.verify_batch(signed["pk48"], vmsg, signed["sig96"])
+        dt = min(timed(lambda: pkg.verify_batch(signed["pk48"], vmsg, signed["sig96"])) for _ in range(3))
+        verdicts = res.cpu().numpy().astype(bool)
+        # executed Fp products per verdict (estimate): decode + subgroup checks ~7 k, hash 7.5 k, projective lines 5.2 k, Miller loop 7.5 k, final exponentiation 9.5 k
+        fpmul_per_verdict = 36700
+        ns = 2 * cores
+        pk_b, sig_b = signed["pk48"][:ns].cpu().numpy(), signed["sig96"][:ns].cpu().numpy()
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=cores) as ex:
+            cpu = list(ex.map(lambda i: oracle.verify_bytes(pk_b[i].tobytes(), vmsg_h[i].tobytes(), sig_b[i].tobytes()), range(ns)))
+        cdt = time.perf_counter() - t0
+        legs["verify_batch"] = {"workload": "BLS::verify as values (blsw_verify_batch): 65 536 (pk, msg, sig) triples from compressed bytes, every 16th tampered", "value": nv / dt, "unit": "verdicts/s",
+                                "seconds": dt, "verdicts_ok": bool((verdicts == (np.arange(nv) % 16 != 15)).all()), "equals_oracle_on_sample": bool(cpu == verdicts[:ns].tolist()),
+                                "roofline": {"bound": "valu-fp-mul", "executed_fpmul_per_verdict": fpmul_per_verdict, "achieved": nv / dt * fpmul_per_verdict, "peak": fpmul_peak,
+                                             "unit": "Fp products/s (peak = blsw_microbench 1, measured on this box)", "frac": nv / dt * fpmul_per_verdict / fpmul_peak},
+                                "cpu_baseline": {"value": ns / cdt, "unit": "verdicts/s", "cores": cores, "kind": "port",
+                                                 "sample": "%d triples through the oracle's native verify on %d threads: %.2f s" % (ns, cores, cdt)}}
+        del signed, vmsg, res
+    except Exception as exc:  # noqa: BLE001
+        legs["verify_batch"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
     torch.cuda.empty_cache()
 
     # ---- configs[3]: one signature over 128 pairs; with distinct messages the signature of pair 0 stands in (result false, identical witness work)

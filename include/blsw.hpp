@@ -488,7 +488,7 @@ struct BLS {
         }
         return out;
     }
-    // BLS::verify (bls.rs:427-458) for n (pk, msg, sig) triples: the same pairing check the gadget witnesses, values only (no witness tensor).
+    // BLS::verify (bls.rs:427-458) for n (pk, msg, sig) triples: the native pairing check as values (no circuit, no witness tensor).
     // An identity or undecodable key / signature is Err(..) in the reference and `false` here, with the reason in `status` ([n][2], BLSW_ST_*).
     static std::vector<bool> verify(const Parameters&, const std::vector<PublicKey>& pks, const std::vector<std::vector<uint8_t>>& messages,
                                     const std::vector<Signature>& sigs, std::vector<int32_t>* status = nullptr) {
@@ -502,24 +502,17 @@ struct BLS {
             std::memcpy(&sg[96 * i], sigs[i].bytes.data(), 96);
             if (msg_len) std::memcpy(&msg[(size_t)msg_len * i], messages[i].data(), msg_len);
         }
-        blsw_engine_options_t opt;
-        check(blsw_engine_options_default(&opt), "blsw_engine_options_default");
         uint64_t bytes = 0;
-        check(blsw_engine_workspace_bytes_ex(n, msg_len, 1, 1, &opt, &bytes), "blsw_engine_workspace_bytes_ex");
-        detail::DeviceBytes ws(bytes), d_pk(pk.size()), d_sg(sg.size()), d_msg(msg.size()), d_pk_xy(n * 96), d_sg_xy(n * 192), d_st(n * 8), d_res(n * 4);
+        check(blsw_verify_workspace_bytes(n, msg_len, &bytes), "blsw_verify_workspace_bytes");
+        detail::DeviceBytes ws(bytes), d_pk(pk.size()), d_sg(sg.size()), d_msg(msg.size()), d_st(n * 8), d_res(n * 4);
         d_pk.upload(pk.data(), pk.size());
         d_sg.upload(sg.data(), sg.size());
         if (!msg.empty()) d_msg.upload(msg.data(), msg.size());
-        blsw_engine_t* e = nullptr;
-        check(blsw_engine_create_ex(&e, n, msg_len, 1, 1, &opt, ws.get(), bytes), "blsw_engine_create_ex");
-        int rc = blsw_engine_submit_bytes(e, static_cast<const uint8_t*>(d_pk.get()), static_cast<const uint8_t*>(d_sg.get()), static_cast<const uint8_t*>(d_msg.get()),
-                                          static_cast<uint64_t*>(d_pk_xy.get()), static_cast<uint64_t*>(d_sg_xy.get()), static_cast<int32_t*>(d_st.get()), nullptr, 0,
-                                          static_cast<int32_t*>(d_res.get()), nullptr);
-        if (rc == BLSW_OK) rc = blsw_engine_flush(e, nullptr);
-        hipError_t he = hipDeviceSynchronize();
-        blsw_engine_destroy(e);
-        check(rc, "blsw_engine_submit_bytes / flush");
-        hip_check(he, "hipDeviceSynchronize");
+        // the native algorithm as values (blsw_verify_batch): decode + subgroup checks, hash to G2, projective two-pair Miller loop, final exponentiation
+        check(blsw_verify_batch(static_cast<const uint8_t*>(d_pk.get()), static_cast<const uint8_t*>(d_sg.get()), static_cast<const uint8_t*>(d_msg.get()), msg_len, n,
+                                static_cast<int32_t*>(d_res.get()), static_cast<int32_t*>(d_st.get()), ws.get(), bytes, nullptr),
+              "blsw_verify_batch");
+        hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
         std::vector<int32_t> r(n);
         d_res.download(r.data(), n * 4);
         if (status) {
