@@ -1,6 +1,6 @@
 #!/bin/bash
 # after `gpurun -- tools/prof_round.sh <tag>`: copies the summaries the judge reads from gpurun_out/<tag>prof into profiles/ (tracked)
-TAG=${1:-r04}
+TAG=${1:-r05}
 O=gpurun_out/${TAG}prof
 P=profiles
 cp $O/bench_default.json $P/${TAG}_bench_default.json

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Round 4 probe: the consumer-mode shard legs of bench.py (tools/shard_rehearsal.py: stream_shard) repeated in one process — run-to-run spread, the
+"""The consumer-mode shard legs of bench.py (tools/shard_rehearsal.py: stream_shard) repeated in one process — run-to-run spread, the
 group ramp on / off, group sizes. One line per run."""
 import importlib
 import json

@@ -1,8 +1,8 @@
 #!/bin/bash
-# Round evidence (run on the GPU box: gpurun -- tools/prof_round.sh r04): bench lines, rocprofv3 kernel stats of the default command, PMC passes
+# Round evidence (run on the GPU box: gpurun -- tools/prof_round.sh r05): bench lines, rocprofv3 kernel stats of the default command, PMC passes
 # (memory side and SQ side, separate passes, no trace domains beside --kernel-trace), the digest kernel alone and its VALU count, timelines.
 # tools/collect_profiles.sh <tag> copies the summaries into profiles/.
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/${TAG}prof
 mkdir -p $O
