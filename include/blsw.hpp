@@ -217,7 +217,12 @@ class ParametersVar {
     static ParametersVar new_variable(ConstraintSystem& cs, const Parameters&, AllocationMode mode) {
         if (mode == AllocationMode::Input) throw Error("ParametersVar: AllocationMode::Input (instance variables are not produced)", BLSW_ERR_ARG);
         if (cs.engine_) throw Error("ParametersVar::new_variable after verify", BLSW_ERR_ARG);
-        check(blsw_layout_params(cs.msg_len_, mode == AllocationMode::Witness ? 1u : 0u, &cs.layout_), "blsw_layout_params");
+        // the allocation modes together fix the circuit shape, whatever the order the three new_variable calls run in (C++ argument evaluation order)
+        if (cs.layout_.pk_mode || cs.layout_.sig_mode) {
+            if (mode == AllocationMode::Witness) throw Error("ParametersVar: AllocationMode::Witness together with Input keys / signatures", BLSW_ERR_ARG);
+        } else {
+            check(blsw_layout_params(cs.msg_len_, mode == AllocationMode::Witness ? 1u : 0u, &cs.layout_), "blsw_layout_params");
+        }
         ParametersVar p;
         p.cs_ = &cs;
         return p;
