@@ -327,7 +327,7 @@ static int launch_group(blsw_engine* e) {
     bool idle = true;
     for (int k = 0; k < e->nbuf; k++)
         if (k != e->cur && e->buf[k].used && hipEventQuery(e->buf[k].ev_chains) != hipSuccess) idle = false;
-    const bool small = e->staged && g.ws.cofv != nullptr;
+    const bool small = g.ws.cofv != nullptr;  // staged or direct mode (a direct-mode engine is one small group at a time: always latency-bound)
     const uint32_t lm = e->opt.latency_mode;
     Latency lat = {false, false};
     if (small && (lm >= 2 || (lm == 0 && idle))) lat = {lm != 3, lm != 4};
