@@ -19,7 +19,11 @@
 // Degenerate inputs: Q0 + Q1 = identity runs as the circuit does (all-zero chain: Z = 0, every hint 0). A point of order two inside the
 // doubling chain or acc = +-mopt inside an addition chain (probability ~2^-250 for hash outputs) would differ from the circuit's zero-hint
 // arithmetic, exactly as cofactor_par.hpp's Jacobian chunk starts already do.
-// Compiles for the host as well: tests/hostsim runs the five phases in order against the oracle.
+// Pipelined in SEGMENTS of the doubling chain (cofv_seg: six ranges (D0, D1] that end at the chunks' ends): the forward doublings of a segment are the
+// only thing the next segment waits for; the segment's inversion + backward recurrence (cofv_bwd), its affine points and the part of its chunk's
+// addition chain run BESIDE the following segments (kcommon.hpp: launch_cofactor puts them on other streams), so the critical path is the forward
+// doubling chain plus the last segment's short tail instead of chain + recurrence + affine points + the longest addition chain.
+// Compiles for the host as well: tests/hostsim runs the phases in order against the oracle.
 #pragma once
 #include "cofactor_par.hpp"
 
@@ -79,6 +83,45 @@ constexpr CofvPlan cofv_plan() {
     p.total = (uint16_t)pos;
     return p;
 }
+// segments of the doubling chain: segment s covers the points D in (bnd[s], bnd[s + 1]] (segment 0 also D = 0) and belongs to chunk chunk[s]; a chunk's
+// loop additions, its first point and its tail operands all lie in its own segments. [j_lo[s], j_hi[s]): the additions of that chunk in segment s.
+// The later chunks are cut finer: what follows the last doubling (the last segment's inversion, affine points and additions) is the exposed tail.
+#define BLSW_COFV_NSEG 8
+struct CofvSeg {
+    uint16_t bnd[BLSW_COFV_NSEG + 1];
+    uint8_t chunk[BLSW_COFV_NSEG];
+    uint16_t j_lo[BLSW_COFV_NSEG], j_hi[BLSW_COFV_NSEG];
+    constexpr bool first(int s) const { return s == 0 || chunk[s - 1] != chunk[s]; }
+    constexpr bool last(int s) const { return s == BLSW_COFV_NSEG - 1 || chunk[s + 1] != chunk[s]; }
+};
+constexpr CofvSeg cofv_seg() {
+    CofvSeg g = {{0, 128, 254, 340, 425, 509, 552, 594, BLSW_H_EFF_NBITS}, {0, 0, 1, 1, 1, 2, 2, 2}, {}, {}};
+    const CofvPlan p = cofv_plan();
+    for (int s = 0; s < BLSW_COFV_NSEG; s++) {
+        const int c = g.chunk[s];
+        uint16_t lo = 0, hi = 0;
+        for (uint16_t j = 0; j < p.n_adds[c]; j++) {
+            if (p.add_bit[c][j] <= g.bnd[s]) lo = (uint16_t)(j + 1);
+            if (p.add_bit[c][j] <= g.bnd[s + 1]) hi = (uint16_t)(j + 1);
+        }
+        g.j_lo[s] = lo;
+        g.j_hi[s] = hi;
+    }
+    return g;
+}
+constexpr bool cofv_seg_ok() {
+    const CofvSeg g = cofv_seg();
+    const CofvPlan p = cofv_plan();
+    for (int s = 0; s < BLSW_COFV_NSEG; s++) {
+        const int c = g.chunk[s], off = 255 * c;
+        if (g.first(s) && (g.j_lo[s] != 0 || g.bnd[s] >= off || g.bnd[s + 1] < off) && s != 0) return false;  // the chunk's first point lies in its first segment
+        if (g.last(s) && g.j_hi[s] != p.n_adds[c]) return false;
+        if (g.last(s) && c < 2 && g.bnd[s + 1] != off + 254) return false;  // ... and its tail operands in its last
+        if (!g.first(s) && g.j_lo[s] != g.j_hi[s - 1]) return false;
+    }
+    return g.bnd[0] == 0 && g.bnd[BLSW_COFV_NSEG] == BLSW_H_EFF_NBITS;
+}
+static_assert(cofv_seg_ok(), "cofv: every addition, first point and tail operand of a chunk lies in the chunk's own segments");
 static_assert(cofv_plan().total == 8979, "cofactor segment: the plan must count what chain_cofactor emits");
 static_assert(cofv_plan().n_adds[0] < BLSW_COFV_MAX_ADDS && cofv_plan().n_adds[1] < BLSW_COFV_MAX_ADDS && cofv_plan().n_adds[2] < BLSW_COFV_MAX_ADDS, "cofv: additions per chunk");
 
@@ -86,6 +129,7 @@ static_assert(cofv_plan().n_adds[0] < BLSW_COFV_MAX_ADDS && cofv_plan().n_adds[1
 //   XY(D)   Jacobian (X, Y) of 2^D P (phase 1);  AF(D) the affine point (phase 2a)
 //   ZI(D)   1 / Z_D, D = 0 .. 636 (ZI(0) = 1)
 //   AC(c,j) addition j of chunk c: X1, Y1 (the accumulator before it), r, H; AZ(c,j) = 1 / Z1 before addition j (AZ(c, 0) = 1)
+//   RES, ZE(s), ACS(c): what one segment's programs leave for the next
 #define BLSW_COFV_XY(D) (4u * (uint32_t)(D))
 #define BLSW_COFV_ZI(D) (4u * BLSW_H_EFF_NBITS + 2u * (uint32_t)(D))
 #define BLSW_COFV_ACC0 (4u * BLSW_H_EFF_NBITS + 2u * (BLSW_H_EFF_NBITS + 1))
@@ -93,7 +137,10 @@ static_assert(cofv_plan().n_adds[0] < BLSW_COFV_MAX_ADDS && cofv_plan().n_adds[1
 #define BLSW_COFV_AZ(c, j) (BLSW_COFV_AC(c, j) + 8u)
 #define BLSW_COFV_AFF0 (BLSW_COFV_ACC0 + 3u * 10u * (BLSW_COFV_MAX_ADDS + 1))
 #define BLSW_COFV_AF(D) (BLSW_COFV_AFF0 + 4u * (uint32_t)(D))
-#define BLSW_COFV_ELEMS (BLSW_COFV_AFF0 + 4u * BLSW_H_EFF_NBITS)
+#define BLSW_COFV_RES (BLSW_COFV_AFF0 + 4u * BLSW_H_EFF_NBITS)           // X, Y, Z of the doubling chain between two segments
+#define BLSW_COFV_ZE(s) (BLSW_COFV_RES + 6u + 2u * (uint32_t)(s))        // Z of segment s's last point
+#define BLSW_COFV_ACS(c) (BLSW_COFV_RES + 6u + 2u * BLSW_COFV_NSEG + 6u * (uint32_t)(c))  // X1, Y1, Z1 of chunk c's addition chain between two segments
+#define BLSW_COFV_ELEMS (BLSW_COFV_RES + 6u + 2u * BLSW_COFV_NSEG + 18u)
 
 template <class S>
 BLSW_HD void cofv_st2(const S& s, uint32_t el, const Fp2& v) {
@@ -105,32 +152,60 @@ BLSW_HD Fp2 cofv_ld2(const S& s, uint32_t el) {
     return {s.ld(el), s.ld(el + 1)};
 }
 
-// ---- phase 1 (one lane, or one quad, per instance): Q0 + Q1 and to_affine with their witnesses, then the doubling chain as values.
-// `rows`: what the join reads (cofactor_par.hpp: row 36 = infinity flag)
-template <class S, class ST>
-BLSW_FN void cofv_chain(Emitter e_add, Emitter e, const Proj<OpsFp2>& q0, const Proj<OpsFp2>& q1, const S& scr, const ST& rows) {
-    Proj<OpsFp2> r = proj_add_w<OpsFp2, 0>(e_add, q0, q1);
-    Aff2Inf ra = g2_to_affine_w(e, r);
-    rows.st(36, ra.infinity ? fp_one() : fp_zero());
-    Fp2 X = ra.x, Y = ra.y, Z = fp2_one();
-#pragma unroll 1
-    for (int D = 0; D < BLSW_H_EFF_NBITS; D++) {  // dbl-2009-l, a = 0 (vcurve.hpp: on a quad, four product rounds per step)
-        cofv_st2(scr, BLSW_COFV_XY(D), X);
-        cofv_st2(scr, BLSW_COFV_XY(D) + 2, Y);
-        v_dbl_inplace(X, Y, Z);
+// ---- phase 1, segment s (one lane, or one quad, per instance): [s = 0: Q0 + Q1 and to_affine with their witnesses, then] the segment's Jacobian doublings
+// as values. `rows`: what the join reads (cofactor_par.hpp: row 36 = infinity flag)
+template <class S, class ST, class Q>
+BLSW_FN void cofv_chain_seg(int s, Emitter e_add, Emitter e, const Q& load_q, const S& scr, const ST& rows) {
+    constexpr CofvSeg seg = cofv_seg();
+    Fp2 X, Y, Z;
+    if (s == 0) {
+        Proj<OpsFp2> q0, q1;
+        load_q(q0, q1);
+        Proj<OpsFp2> r = proj_add_w<OpsFp2, 0>(e_add, q0, q1);
+        Aff2Inf ra = g2_to_affine_w(e, r);
+        rows.st(36, ra.infinity ? fp_one() : fp_zero());
+        X = ra.x;
+        Y = ra.y;
+        Z = fp2_one();
+        cofv_st2(scr, BLSW_COFV_XY(0), X);
+        cofv_st2(scr, BLSW_COFV_XY(0) + 2, Y);
+    } else {
+        X = cofv_ld2(scr, BLSW_COFV_RES);
+        Y = cofv_ld2(scr, BLSW_COFV_RES + 2);
+        Z = cofv_ld2(scr, BLSW_COFV_RES + 4);
     }
-    // 1 / Z_D backwards from the last: Z_{D+1} = 2 Y_D Z_D
-    Fp2 zi = fp2_inv_inl(Z);
-    cofv_st2(scr, BLSW_COFV_ZI(BLSW_H_EFF_NBITS), zi);
+    const int D1 = seg.bnd[s + 1];
 #pragma unroll 1
-    for (int D = BLSW_H_EFF_NBITS - 1; D >= 1; D--) {
+    for (int D = seg.bnd[s]; D < D1; D++) {  // dbl-2009-l, a = 0 (vcurve.hpp: on a quad, four product rounds per step)
+        v_dbl_inplace(X, Y, Z);
+        if (D + 1 < BLSW_H_EFF_NBITS) {
+            cofv_st2(scr, BLSW_COFV_XY(D + 1), X);
+            cofv_st2(scr, BLSW_COFV_XY(D + 1) + 2, Y);
+        }
+    }
+    cofv_st2(scr, BLSW_COFV_ZE(s), Z);
+    if (s + 1 < BLSW_COFV_NSEG) {
+        cofv_st2(scr, BLSW_COFV_RES, X);
+        cofv_st2(scr, BLSW_COFV_RES + 2, Y);
+        cofv_st2(scr, BLSW_COFV_RES + 4, Z);
+    }
+}
+// ---- phase 1b, segment s (one lane, or one quad, per instance): 1 / Z_D for D in (D0, D1], backwards from the segment's last point (Z_{D+1} = 2 Y_D Z_D)
+template <class S>
+BLSW_FN void cofv_bwd(int s, const S& scr) {
+    constexpr CofvSeg seg = cofv_seg();
+    const int D0 = seg.bnd[s], D1 = seg.bnd[s + 1];
+    Fp2 zi = fp2_inv_inl(cofv_ld2(scr, BLSW_COFV_ZE(s)));
+    cofv_st2(scr, BLSW_COFV_ZI(D1), zi);
+#pragma unroll 1
+    for (int D = D1 - 1; D > D0; D--) {
         zi = fp2_mul_inl(fp2_dbl(cofv_ld2(scr, BLSW_COFV_XY(D) + 2)), zi);
         cofv_st2(scr, BLSW_COFV_ZI(D), zi);
     }
-    cofv_st2(scr, BLSW_COFV_ZI(0), fp2_one());
+    if (s == 0) cofv_st2(scr, BLSW_COFV_ZI(0), fp2_one());
 }
 
-// ---- phase 2a (one lane per doubling index D of an instance): the affine 2^D P — what the addition chains wait for
+// ---- phase 2a (one lane per doubling index D of a segment, of an instance): the affine 2^D P — what the addition chains wait for
 template <class S>
 BLSW_FN void cofv_affine(uint32_t D, const S& scr) {
     const Fp2 X = cofv_ld2(scr, BLSW_COFV_XY(D)), Y = cofv_ld2(scr, BLSW_COFV_XY(D) + 2), zi = cofv_ld2(scr, BLSW_COFV_ZI(D));
@@ -157,17 +232,27 @@ BLSW_FN void cofv_dbl_w(Emitter e, uint32_t D, const S& scr) {
     (void)fp2_mul_w(e, lambda, fp2_sub(p.x, x3));
 }
 
-// ---- phase 3 (one lane, or one quad, per chunk of an instance): the additions of the chunk's loop as a mixed Jacobian chain.
-// Leaves (acc, init) in the join's rows 12 c + {0.., 4..}
+// ---- phase 3, segment s (one lane, or one quad, per instance): the additions of the segment's chunk whose operand lies in the segment, as a mixed
+// Jacobian chain; the chunk's last segment ends with the inversion and (acc, init) in the join's rows 12 c + {0.., 4..}
 template <class S, class ST>
-BLSW_FN void cofv_acc_chain(int c, const S& scr, const ST& rows) {
+BLSW_FN void cofv_acc_seg(int s, const S& scr, const ST& rows) {
     constexpr CofvPlan plan = cofv_plan();
+    constexpr CofvSeg seg = cofv_seg();
+    const int c = seg.chunk[s];
     const int off = 255 * c;
-    const Fp2 x0 = cofv_ld2(scr, BLSW_COFV_AF(off)), y0 = cofv_ld2(scr, BLSW_COFV_AF(off) + 2);
-    Fp2 X1 = x0, Y1 = y0, Z1 = fp2_one();
-    const uint32_t na = plan.n_adds[c];
+    Fp2 X1, Y1, Z1;
+    if (seg.first(s)) {
+        X1 = cofv_ld2(scr, BLSW_COFV_AF(off));
+        Y1 = cofv_ld2(scr, BLSW_COFV_AF(off) + 2);
+        Z1 = fp2_one();
+    } else {
+        X1 = cofv_ld2(scr, BLSW_COFV_ACS(c));
+        Y1 = cofv_ld2(scr, BLSW_COFV_ACS(c) + 2);
+        Z1 = cofv_ld2(scr, BLSW_COFV_ACS(c) + 4);
+    }
+    const uint32_t j1 = seg.j_hi[s];
 #pragma unroll 1
-    for (uint32_t j = 0; j < na; j++) {  // madd-2007-bl with Z3 = 2 Z1 H
+    for (uint32_t j = seg.j_lo[s]; j < j1; j++) {  // madd-2007-bl with Z3 = 2 Z1 H
         const uint32_t D = plan.add_bit[c][j];
         const Fp2 x2 = cofv_ld2(scr, BLSW_COFV_AF(D)), y2 = cofv_ld2(scr, BLSW_COFV_AF(D) + 2);
         const Fp2 z1z1 = v_sqr(Z1);
@@ -189,20 +274,37 @@ BLSW_FN void cofv_acc_chain(int c, const S& scr, const ST& rows) {
         X1 = x3;
         Y1 = y3;
     }
+    if (!seg.last(s)) {
+        cofv_st2(scr, BLSW_COFV_ACS(c), X1);
+        cofv_st2(scr, BLSW_COFV_ACS(c) + 2, Y1);
+        cofv_st2(scr, BLSW_COFV_ACS(c) + 4, Z1);
+        return;
+    }
+    const uint32_t na = plan.n_adds[c];
+    const Aff2 init = {cofv_ld2(scr, BLSW_COFV_AF(off)), cofv_ld2(scr, BLSW_COFV_AF(off) + 2)};
     Fp2 zi = fp2_inv_inl(Z1);
     {  // the accumulator after the loop, affine
         const Fp2 zi2 = v_sqr(zi);
         const Aff2 acc = {fp2_mul_inl(X1, zi2), fp2_mul_inl(Y1, fp2_mul_inl(zi2, zi))};
-        cof_st_aff(rows, 12 * c, na ? acc : Aff2{x0, y0});
+        cof_st_aff(rows, 12 * c, na ? acc : init);
     }
+    cof_st_aff(rows, 12 * c + 4, init);  // (the join takes the tail's operands from AF)
     cofv_st2(scr, BLSW_COFV_AZ(c, na), zi);
+}
+// ---- phase 3b (one lane, or one quad, per chunk of an instance): 1 / Z1 before every addition of the chunk, backwards from the one after the last
+// (Z1_{j+1} = 2 Z1_j H_j). Only the additions' witnesses read it: off the critical path
+template <class S>
+BLSW_FN void cofv_acc_az(int c, const S& scr) {
+    constexpr CofvPlan plan = cofv_plan();
+    const uint32_t na = plan.n_adds[c];
+    if (na == 0) return;
+    Fp2 zi = cofv_ld2(scr, BLSW_COFV_AZ(c, na));
 #pragma unroll 1
     for (int j = (int)na - 1; j >= 1; j--) {
         zi = fp2_mul_inl(fp2_dbl(cofv_ld2(scr, BLSW_COFV_AC(c, j) + 6)), zi);
         cofv_st2(scr, BLSW_COFV_AZ(c, j), zi);
     }
-    if (na) cofv_st2(scr, BLSW_COFV_AZ(c, 0), fp2_one());
-    cof_st_aff(rows, 12 * c + 4, {x0, y0});  // init (the join takes the tail's operands from XY)
+    cofv_st2(scr, BLSW_COFV_AZ(c, 0), fp2_one());
 }
 
 // ---- phase 4 (one lane per addition j of chunk c of an instance): the eight witnesses of nz_add_unchecked_pre_inl

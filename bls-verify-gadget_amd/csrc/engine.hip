@@ -76,7 +76,8 @@ struct GroupBuf {
     hipStream_t st[2] = {nullptr, nullptr};  // main, aux (a second aux stream for prepare(sig) / the key chains beside the G2 allocation measured slower:
                                              // profiles/r03_ab_chain_builds.txt section 7)
     hipEvent_t ev_start = nullptr, ev_aux = nullptr, ev_sha = nullptr, ev_chains = nullptr, ev_done = nullptr;
-    hipEvent_t ev_cof_aff = nullptr, ev_cof_acc = nullptr, ev_side = nullptr;  // values-first cofactor chain: its witness phases run on the aux stream
+    hipEvent_t ev_side = nullptr;
+    hipEvent_t ev_cof[BLSW_COFV_EVENTS] = {};  // values-first cofactor chain (kcommon.hpp: CofactorSide): segments, their points, chunks, join
     hipEvent_t* ev_in = nullptr;    // [max_steps] inputs of step s valid (recorded on the submitting stream)
     hipEvent_t* ev_x = nullptr;     // [max_steps] expansion of step s issued and finished
     hipEvent_t* ev_step = nullptr;  // [max_steps] step s complete (witness tensor + results)
@@ -103,7 +104,7 @@ struct blsw_engine {
     uint32_t pending = 0;
     uint64_t submitted = 0, launched = 0, materialised = 0;
     std::deque<Job> jobs;  // steps whose chains are issued, in submission order, waiting for their output to be free (consumer mode)
-    hipStream_t sha = nullptr, expand = nullptr, place = nullptr;
+    hipStream_t sha = nullptr, expand = nullptr, place = nullptr, lat = nullptr;  // lat: the points of a latency group's cofactor segments
     // HIP event pairs around every k_sha_expand launch since the last stats reset (live roofline measurement)
     hipEvent_t* ev_exp = nullptr;  // 2 * BLSW_MAX_TIMED events
     uint32_t n_timed = 0;
@@ -127,8 +128,10 @@ static void engine_free(blsw_engine* e) {
         if (b.d_desc) hipFree(b.d_desc);
         for (int i = 0; i < 2; i++)
             if (b.st[i]) hipStreamDestroy(b.st[i]);
-        hipEvent_t single[] = {b.ev_start, b.ev_aux, b.ev_sha, b.ev_chains, b.ev_done, b.ev_cof_aff, b.ev_cof_acc, b.ev_side};
+        hipEvent_t single[] = {b.ev_start, b.ev_aux, b.ev_sha, b.ev_chains, b.ev_done, b.ev_side};
         for (hipEvent_t ev : single)
+            if (ev) hipEventDestroy(ev);
+        for (hipEvent_t ev : b.ev_cof)
             if (ev) hipEventDestroy(ev);
         hipEvent_t* arrays[] = {b.ev_in, b.ev_x, b.ev_step};
         for (hipEvent_t* arr : arrays) {
@@ -141,6 +144,7 @@ static void engine_free(blsw_engine* e) {
     if (e->sha) hipStreamDestroy(e->sha);
     if (e->expand) hipStreamDestroy(e->expand);
     if (e->place) hipStreamDestroy(e->place);
+    if (e->lat) hipStreamDestroy(e->lat);
     if (e->ev_exp) {
         for (int i = 0; i < 2 * BLSW_MAX_TIMED; i++)
             if (e->ev_exp[i]) hipEventDestroy(e->ev_exp[i]);
@@ -336,8 +340,22 @@ static int launch_group(blsw_engine* e) {
     const ChainKernels ck = chain_kernels(e->chains_inlined || cold_small);
     const bool chunked = e->cofactor_mode == 2 || (e->cofactor_mode == 0 && g.N <= BLSW_COFACTOR_CHUNKED_MAX_LANES);
     // values-first cofactor chain: its per-doubling / per-addition witness phases go to the aux stream, behind the aux chains (enqueued below)
-    const CofactorSide cof_side = {b.st[1], b.ev_cof_aff, b.ev_cof_acc};
+    // ... and the pipelines of its chunks run beside the doubling chain on the engine's latency stream (the segments' points) and its sha and place
+    // streams (the addition chains): high-priority streams with nothing to do while a cold group's chains run (its SHA bits are enqueued before;
+    // placement starts after the chains)
+    CofactorSide cof_side;
+    cof_side.side = b.st[1];
+    cof_side.pts = e->lat;
+    cof_side.acc[0] = e->place;
+    cof_side.acc[1] = e->sha;
+    for (int i = 0; i < BLSW_COFV_NSEG; i++) cof_side.ev_seg[i] = b.ev_cof[i], cof_side.ev_pts[i] = b.ev_cof[BLSW_COFV_NSEG + i];
+    for (int i = 0; i < 3; i++) cof_side.ev_acc[i] = b.ev_cof[2 * BLSW_COFV_NSEG + i];
+    cof_side.ev_join = b.ev_cof[2 * BLSW_COFV_NSEG + 3];
     const bool cof_deferred = lat.vf && g.ws.cofv != nullptr;
+    // the waves of a latency group's critical path (hash-to-G2, prepare(H), pairing) raise their priority: the streams beside them — the first
+    // expansions, the next group's chains, this group's aux chains — have slack, they have none
+    Group gm = g;
+    if (lat.quad || lat.vf) gm.chain_prio = 1;
     hipStream_t st = b.st[0];
     // inputs of every step are ready once its submitting stream reached the point of the submit
     for (uint32_t s = 0; s < steps; s++) hipStreamWaitEvent(st, b.ev_in[s], 0);
@@ -358,16 +376,18 @@ static int launch_group(blsw_engine* e) {
         Group gs = g;
         gs.N = (uint64_t)steps * e->n;
         gs.K = 1;
-        hipLaunchKernelGGL(k_sha_values, dim3(g1), dim3(64), 0, st, g);
-        launch_map(ck, lat, g, st);
-        launch_cofactor(ck, lat, chunked, g, st, &cof_side);
-        launch_prepare(ck, lat, g, 0, st);
-        launch_g2_alloc(ck, lat, gs, b.st[1]);
+        hipLaunchKernelGGL(k_sha_values, dim3(g1), dim3(64), 0, st, gm);
+        launch_map(ck, lat, gm, st);
+        launch_cofactor(ck, lat, chunked, gm, st, &cof_side);
+        launch_prepare(ck, lat, gm, 0, st);
+        // aux: what the Miller product waits for (prepare(sig), the keys' prepare_g1) first, then the signature's allocation chain, which only the
+        // end of the group waits for (ev_side)
         launch_prepare(ck, lat, gs, 1, b.st[1]);
         hipLaunchKernelGGL(ck.g1, dim3(g1), dim3(64), 0, b.st[1], g);
         hipEventRecord(b.ev_aux, b.st[1]);
+        launch_g2_alloc(ck, lat, gs, b.st[1]);
         hipStreamWaitEvent(st, b.ev_aux, 0);
-        if (cof_deferred) launch_cofactor_witness(g, cof_side);
+        if (cof_deferred) launch_cofactor_witness(lat, g, cof_side);
         if (K < BLSW_MILLER_PAR_MIN_PAIRS) {
             hipLaunchKernelGGL(k_pairing_team_multi, dim3((unsigned)((gs.N + BLSW_TEAMS_PER_WAVE - 1) / BLSW_TEAMS_PER_WAVE)), dim3(64), 0, st, gs, K, g.N);
         } else {
@@ -392,11 +412,12 @@ static int launch_group(blsw_engine* e) {
         }
     } else {
         // main, first part: the hash-to-G2 critical path
-        hipLaunchKernelGGL(k_sha_values, dim3(g1), dim3(64), 0, st, g);
-        launch_map(ck, lat, g, st);
-        launch_cofactor(ck, lat, chunked, g, st, &cof_side);
-        launch_prepare(ck, lat, g, 0, st);
-        // aux: prepare_g2(sig) and the group allocations (53 ms alone beside the 86 ms of the main stream's first part)
+        hipLaunchKernelGGL(k_sha_values, dim3(g1), dim3(64), 0, st, gm);
+        launch_map(ck, lat, gm, st);
+        launch_cofactor(ck, lat, chunked, gm, st, &cof_side);
+        launch_prepare(ck, lat, gm, 0, st);
+        // aux: prepare_g2(sig) and the key's allocation + prepare_g1 — what the pairing waits for (ev_aux) — then the signature's allocation chain, which
+        // only the end of the group waits for (ev_side): the longest aux kernel no longer delays the pairing of a latency-bound group
         hipStream_t sb = b.st[1];
         launch_prepare(ck, lat, g, 1, sb);
         if (e->L.n_keys) {  // aggregate_verify: one lane per (instance, key) allocates, then mapped_aggregate + pk != 0 + prepare_g1 per instance
@@ -404,6 +425,7 @@ static int launch_group(blsw_engine* e) {
             hipLaunchKernelGGL(ck.agg_sum, dim3(g1), dim3(64), 0, sb, g, (const Fp*)g.ws.keyproj);
         } else  // params_mode: lanes [N, 2 N) allocate and prepare the generator (k_g1)
             hipLaunchKernelGGL(ck.g1, dim3(e->L.params_mode ? (unsigned)((2 * g.N + 63) / 64) : g1), dim3(64), 0, sb, g);
+        hipEventRecord(b.ev_aux, sb);
         if (e->L.sig_mode) {
             // SignatureVar::new_variable(Input): no allocation chain (prepare(sig) wrote the instance variables)
         } else if (e->modes.g2_team)
@@ -412,16 +434,14 @@ static int launch_group(blsw_engine* e) {
             launch_g2_alloc(ck, lat, g, b.st[1]);
     }
     if (K == 1) {
-        hipEventRecord(b.ev_aux, b.st[1]);
-        if (cof_deferred) launch_cofactor_witness(g, cof_side);
+        if (cof_deferred) launch_cofactor_witness(lat, g, cof_side);
         // main, second part: the pairing
         hipStreamWaitEvent(st, b.ev_aux, 0);
-        launch_pairing(g, e->modes, st);
+        launch_pairing(gm, e->modes, st);
     }
-    if (cof_deferred) {  // the group's chains are done when the deferred witness phases are
-        hipEventRecord(b.ev_side, b.st[1]);
-        hipStreamWaitEvent(st, b.ev_side, 0);
-    }
+    // the group's chains are done when the aux stream's tail (G2 allocation, deferred witness phases of the cofactor chain) is
+    hipEventRecord(b.ev_side, b.st[1]);
+    hipStreamWaitEvent(st, b.ev_side, 0);
     hipStreamWaitEvent(st, b.ev_sha, 0);
     hipEventRecord(b.ev_chains, st);
     // expansion + placement of the group's steps: queued, issued in submission order (at once unless a consumer holds an output)
@@ -609,8 +629,9 @@ int blsw_engine_create_ex(blsw_engine_t** out, uint64_t n, uint32_t msg_len, uin
         chk(hipMalloc(reinterpret_cast<void**>(&b.d_desc), sizeof(StepDesc) * max_steps), "desc alloc");
         chk(hipStreamCreateWithPriority(&b.st[0], hipStreamNonBlocking, main_prio), "stream create");
         chk(hipStreamCreateWithPriority(&b.st[1], hipStreamNonBlocking, aux_prio), "stream create");
-        hipEvent_t* single[] = {&b.ev_start, &b.ev_aux, &b.ev_sha, &b.ev_chains, &b.ev_done, &b.ev_cof_aff, &b.ev_cof_acc, &b.ev_side};
+        hipEvent_t* single[] = {&b.ev_start, &b.ev_aux, &b.ev_sha, &b.ev_chains, &b.ev_done, &b.ev_side};
         for (hipEvent_t* ev : single) chk(hipEventCreateWithFlags(ev, hipEventDisableTiming), "event create");
+        for (hipEvent_t& ev : b.ev_cof) chk(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "event create");
         b.ev_in = new hipEvent_t[max_steps]();
         b.ev_x = new hipEvent_t[max_steps]();
         b.ev_step = new hipEvent_t[max_steps]();
@@ -623,6 +644,7 @@ int blsw_engine_create_ex(blsw_engine_t** out, uint64_t n, uint32_t msg_len, uin
     chk(hipStreamCreateWithPriority(&e->sha, hipStreamNonBlocking, place_prio), "stream create");
     chk(hipStreamCreateWithPriority(&e->expand, hipStreamNonBlocking, place_prio), "stream create");
     chk(hipStreamCreateWithPriority(&e->place, hipStreamNonBlocking, place_prio), "stream create");
+    chk(hipStreamCreateWithPriority(&e->lat, hipStreamNonBlocking, place_prio), "stream create");
     // Scratch pre-warm. The pairing kernel has the largest stack (4.5 KB per lane): the first launch of a full-size group on
     // a queue makes the runtime grow that queue's scratch, which stalls the queue for ~60 ms (measured: the pairing of the
     // first group of every buffer started 60 ms late). One launch of the same grid with N = 0 (every wave exits at once)

@@ -1,47 +1,64 @@
 // libblsw.so, one translation unit per kernel family (see kcommon.hpp, build.py).
 // clear_cofactor2 "values first" (cofactor_vf.hpp): the latency form of the cofactor segment, for small launch groups.
-//   k_cofv_chain   phase 1, one lane per (pk, msg) pair: Q0 + Q1, to_affine (witnesses), the 636 Jacobian doublings and 1 / Z_D as values
-//   k_cofv_aff     phase 2a, one lane per doubling index: the affine 2^D P
-//   k_cofv_dbl_w   phase 2b, one lane per doubling: its ten witnesses (off the critical path: the engine runs it beside phase 3)
-//   k_cofv_acc     phase 3, one lane per chunk: the chunk's additions as a mixed Jacobian chain, 1 / Z as values
-//   k_cofv_add_w   phase 4, one lane per addition: its eight witnesses
+//   k_cofv_chain   phase 1, segment s, one lane per (pk, msg) pair: [Q0 + Q1, to_affine (witnesses),] the segment's Jacobian doublings as values
+//   k_cofv_bwd     phase 1b, segment s, one lane per pair: 1 / Z_D backwards from the segment's last point (one inversion)
+//   k_cofv_aff     phase 2a, one lane per doubling index of the segment: the affine 2^D P
+//   k_cofv_acc     phase 3, segment s, one lane per pair: the additions of the segment's chunk in the segment as a mixed Jacobian chain
+//   k_cofv_dbl_w   phase 2b, one lane per doubling: its ten witnesses                           } off the critical path: after the join,
+//   k_cofv_az      phase 3b, one lane per chunk: 1 / Z1 before every addition, backwards        } on another stream
+//   k_cofv_add_w   phase 4, one lane per addition: its eight witnesses                          }
 //   k_cofv_join    phase 5, one lane per pair: folds the chunks (the statements of k_cofactor_join)
+// kcommon.hpp's launch_cofactor pipelines the segments over four streams: phases 1b / 2a / 3 of a segment run beside phase 1 of the next ones.
 // Two compilations (build.py): this one (programs inlined; the parallel phases at two waves per SIMD) and the latency compilation (-DBLSW_KVARIANT_QUAD:
-// k_cofv_chain_q, k_cofv_acc_q — the two serial phases on the four lanes of a quad, fp.hpp).
+// k_cofv_chain_q, k_cofv_bwd_q, k_cofv_acc_q, k_cofv_az_q — the serial phases on the four lanes of a quad, fp.hpp).
 #define BLSW_INLINE_CHAINS 1
 #include "kcommon.hpp"
 #define BLSW_CHAIN_ATTR  // the serial phases and the join: the whole register file (at 256 registers the join spills 2 000 into its additions)
 
 namespace blsw {
 
-__global__ __launch_bounds__(64) BLSW_CHAIN_ATTR void BLSW_K(k_cofv_chain)(Group g) {
+__global__ __launch_bounds__(64) BLSW_CHAIN_ATTR void BLSW_K(k_cofv_chain)(Group g, int s) {
     if (g.chain_prio) __builtin_amdgcn_s_setprio(3);
     const uint64_t I = item_index(), N = g.N;
     if (I >= N) return;
     LaneId id = lane_id(g, I);
-    Proj<OpsFp2> q0 = ld_proj2(g.ws.q + I, N), q1 = ld_proj2(g.ws.q + 6 * N + I, N);
-    cofv_chain(EMITJ(g, id, off_add, stride_hash), EMITJ(g, id, off_cofactor, stride_hash), q0, q1, CoeffStrided{g.ws.cofv + I, N}, CoeffStrided{g.ws.coeff_h + I, N});
+    auto load_q = [&](Proj<OpsFp2>& q0, Proj<OpsFp2>& q1) {
+        q0 = ld_proj2(g.ws.q + I, N);
+        q1 = ld_proj2(g.ws.q + 6 * N + I, N);
+    };
+    cofv_chain_seg(s, EMITJ(g, id, off_add, stride_hash), EMITJ(g, id, off_cofactor, stride_hash), load_q, CoeffStrided{g.ws.cofv + I, N}, CoeffStrided{g.ws.coeff_h + I, N});
+}
+__global__ __launch_bounds__(64) BLSW_CHAIN_ATTR void BLSW_K(k_cofv_bwd)(Group g, int s) {
+    if (g.chain_prio) __builtin_amdgcn_s_setprio(3);
+    const uint64_t I = item_index(), N = g.N;
+    if (I >= N) return;
+    cofv_bwd(s, CoeffStrided{g.ws.cofv + I, N});
+}
+__global__ __launch_bounds__(64) BLSW_CHAIN_ATTR void BLSW_K(k_cofv_acc)(Group g, int s) {
+    if (g.chain_prio) __builtin_amdgcn_s_setprio(3);
+    const uint64_t I = item_index(), N = g.N;
+    if (I >= N) return;
+    cofv_acc_seg(s, CoeffStrided{g.ws.cofv + I, N}, CoeffStrided{g.ws.coeff_h + I, N});
 }
 
 // lanes [0, N) chunk 0, [N, 2 N) chunk 1, [2 N, 3 N) chunk 2 (chunk-homogeneous waves)
-__global__ __launch_bounds__(64) BLSW_CHAIN_ATTR void BLSW_K(k_cofv_acc)(Group g) {
-    if (g.chain_prio) __builtin_amdgcn_s_setprio(3);
+__global__ __launch_bounds__(64) BLSW_CHAIN_ATTR void BLSW_K(k_cofv_az)(Group g) {
     const uint64_t t = item_index(), N = g.N;
     if (t >= 3 * N) return;
     const int c = t >= 2 * N ? 2 : (t >= N ? 1 : 0);
     const uint64_t I = t - (uint64_t)c * N;
-    cofv_acc_chain(c, CoeffStrided{g.ws.cofv + I, N}, CoeffStrided{g.ws.coeff_h + I, N});
+    cofv_acc_az(c, CoeffStrided{g.ws.cofv + I, N});
 }
 
 #ifndef BLSW_KVARIANT_QUAD
 // thread t -> (doubling D = t / N, pair I = t % N): the lanes of a wave share D (N is a multiple of 64, or the tail wave mixes two), so its ten
 // witness rows are whole 3 KiB rows of the wave's staging tile and its scratch reads are contiguous
-__global__ __launch_bounds__(64) BLSW_ATTR_W2 void k_cofv_aff(Group g) {
+__global__ __launch_bounds__(64) BLSW_ATTR_W2 void k_cofv_aff(Group g, uint32_t lo, uint32_t cnt) {  // the points D in [lo, lo + cnt)
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, N = g.N;
-    if (t >= (uint64_t)BLSW_H_EFF_NBITS * N) return;
-    const uint32_t D = (uint32_t)(t / N);
-    const uint64_t I = t - (uint64_t)D * N;
-    cofv_affine(D, CoeffStrided{g.ws.cofv + I, N});
+    if (t >= (uint64_t)cnt * N) return;
+    const uint32_t d = (uint32_t)(t / N);
+    const uint64_t I = t - (uint64_t)d * N;
+    cofv_affine(lo + d, CoeffStrided{g.ws.cofv + I, N});
 }
 __global__ __launch_bounds__(64) BLSW_ATTR_W2 void k_cofv_dbl_w(Group g) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, N = g.N;

@@ -395,11 +395,15 @@ __global__ void k_prepv_chain(Group g, int which);
 __global__ void k_prepv_chain_q(Group g, int which);
 __global__ void k_prepv_step_w(Group g, int which);
 // values-first cofactor chain (cofactor_vf.hpp; k_cofv.hip): serial value phases (one lane or one quad per item), parallel witness phases, join
-__global__ void k_cofv_chain(Group g);
-__global__ void k_cofv_chain_q(Group g);
-__global__ void k_cofv_acc(Group g);
-__global__ void k_cofv_acc_q(Group g);
-__global__ void k_cofv_aff(Group g);
+__global__ void k_cofv_chain(Group g, int s);
+__global__ void k_cofv_chain_q(Group g, int s);
+__global__ void k_cofv_bwd(Group g, int s);
+__global__ void k_cofv_bwd_q(Group g, int s);
+__global__ void k_cofv_acc(Group g, int s);
+__global__ void k_cofv_acc_q(Group g, int s);
+__global__ void k_cofv_az(Group g);
+__global__ void k_cofv_az_q(Group g);
+__global__ void k_cofv_aff(Group g, uint32_t lo, uint32_t cnt);
 __global__ void k_cofv_dbl_w(Group g);
 __global__ void k_cofv_add_w(Group g);
 __global__ void k_cofv_join(Group g);
@@ -472,38 +476,86 @@ struct Latency {
     bool quad, vf;
 };
 // clear_cofactor2 of N lanes on `st`: values first, chunked (three lanes per (pk, msg) pair + the join) or as one chain per lane.
-// Values first with a side stream: the two parallel witness phases (one lane per doubling / addition: nothing but the segment's placement waits for
-// them) are left to launch_cofactor_witness on `side`, after ev_aff / ev_acc which this function records; side == nullptr: everything on `st`.
+// Values first with side streams (CofactorSide): `st` carries the forward doubling chain in its segments and the last segment's tail. Beside it, as soon
+// as a segment's doublings are done (ev_seg): its inversion / affine points on pts, in segment order (ev_pts), and its part of its chunk's addition chain
+// on acc[0] (chunks 0 and 2) or acc[1] (chunk 1); the join waits for the chunks (ev_acc). The witness phases (one lane per doubling / addition, and the
+// chunks' 1 / Z1 sweeps: nothing but the segment's placement waits for them) are left to launch_cofactor_witness on `side`, after ev_join.
+// side == nullptr: everything on `st`.
 struct CofactorSide {
-    hipStream_t side;
-    hipEvent_t ev_aff, ev_acc;
+    hipStream_t side, pts, acc[2];
+    hipEvent_t ev_seg[BLSW_COFV_NSEG], ev_pts[BLSW_COFV_NSEG], ev_acc[3], ev_join;
 };
+#define BLSW_COFV_EVENTS (2 * BLSW_COFV_NSEG + 4)
 inline uint64_t cofv_total_adds() {
     constexpr CofvPlan plan = cofv_plan();
     return (uint64_t)plan.n_adds[0] + plan.n_adds[1] + plan.n_adds[2];
 }
+inline void launch_cofv_chain(Latency lat, const Group& g, int s, hipStream_t q) {
+    if (lat.quad)
+        hipLaunchKernelGGL(k_cofv_chain_q, dim3(item_grid(g.N, 4)), dim3(64), 0, q, g, s);
+    else
+        hipLaunchKernelGGL(k_cofv_chain, dim3(item_grid(g.N, 1)), dim3(64), 0, q, g, s);
+}
+// phases 1b and 2a of segment s: 1 / Z of its points, then the points in affine form
+inline void launch_cofv_points(Latency lat, const Group& g, int s, hipStream_t q) {
+    constexpr CofvSeg seg = cofv_seg();
+    if (lat.quad)
+        hipLaunchKernelGGL(k_cofv_bwd_q, dim3(item_grid(g.N, 4)), dim3(64), 0, q, g, s);
+    else
+        hipLaunchKernelGGL(k_cofv_bwd, dim3(item_grid(g.N, 1)), dim3(64), 0, q, g, s);
+    const uint32_t lo = s == 0 ? 0 : seg.bnd[s] + 1u;
+    const uint32_t hi = seg.bnd[s + 1] < BLSW_H_EFF_NBITS ? seg.bnd[s + 1] : BLSW_H_EFF_NBITS - 1;  // the last point of the chain is not an operand
+    hipLaunchKernelGGL(k_cofv_aff, dim3(item_grid((uint64_t)(hi - lo + 1) * g.N, 1)), dim3(64), 0, q, g, lo, hi - lo + 1);
+}
+inline void launch_cofv_acc(Latency lat, const Group& g, int s, hipStream_t q) {
+    if (lat.quad)
+        hipLaunchKernelGGL(k_cofv_acc_q, dim3(item_grid(g.N, 4)), dim3(64), 0, q, g, s);
+    else
+        hipLaunchKernelGGL(k_cofv_acc, dim3(item_grid(g.N, 1)), dim3(64), 0, q, g, s);
+}
+inline void launch_cofv_witness_phases(Latency lat, const Group& g, hipStream_t q) {
+    hipLaunchKernelGGL(k_cofv_dbl_w, dim3(item_grid((uint64_t)BLSW_H_EFF_NBITS * g.N, 1)), dim3(64), 0, q, g);
+    if (lat.quad)
+        hipLaunchKernelGGL(k_cofv_az_q, dim3(item_grid(3 * g.N, 4)), dim3(64), 0, q, g);
+    else
+        hipLaunchKernelGGL(k_cofv_az, dim3(item_grid(3 * g.N, 1)), dim3(64), 0, q, g);
+    hipLaunchKernelGGL(k_cofv_add_w, dim3(item_grid(cofv_total_adds() * g.N, 1)), dim3(64), 0, q, g);
+}
 inline void launch_cofactor(const ChainKernels& ck, Latency lat, bool chunked, const Group& g, hipStream_t st, const CofactorSide* side = nullptr) {
     const unsigned g1 = item_grid(g.N, 1), g3 = item_grid(3 * g.N, 1);
     if (lat.vf && g.ws.cofv) {
-        const unsigned gd = item_grid((uint64_t)BLSW_H_EFF_NBITS * g.N, 1);
-        if (lat.quad)
-            hipLaunchKernelGGL(k_cofv_chain_q, dim3(item_grid(g.N, 4)), dim3(64), 0, st, g);
-        else
-            hipLaunchKernelGGL(k_cofv_chain, dim3(g1), dim3(64), 0, st, g);
-        hipLaunchKernelGGL(k_cofv_aff, dim3(gd), dim3(64), 0, st, g);
-        if (side)
-            hipEventRecord(side->ev_aff, st);
-        else
-            hipLaunchKernelGGL(k_cofv_dbl_w, dim3(gd), dim3(64), 0, st, g);
-        if (lat.quad)
-            hipLaunchKernelGGL(k_cofv_acc_q, dim3(item_grid(3 * g.N, 4)), dim3(64), 0, st, g);
-        else
-            hipLaunchKernelGGL(k_cofv_acc, dim3(g3), dim3(64), 0, st, g);
-        if (side)
-            hipEventRecord(side->ev_acc, st);
-        else
-            hipLaunchKernelGGL(k_cofv_add_w, dim3(item_grid(cofv_total_adds() * g.N, 1)), dim3(64), 0, st, g);
+        constexpr CofvSeg seg = cofv_seg();
+        constexpr int last = BLSW_COFV_NSEG - 1;
+        if (!side) {
+            for (int s = 0; s <= last; s++) {
+                launch_cofv_chain(lat, g, s, st);
+                launch_cofv_points(lat, g, s, st);
+                launch_cofv_acc(lat, g, s, st);
+            }
+            hipLaunchKernelGGL(k_cofv_join, dim3(g1), dim3(64), 0, st, g);
+            launch_cofv_witness_phases(lat, g, st);
+            return;
+        }
+        for (int s = 0; s <= last; s++) {
+            launch_cofv_chain(lat, g, s, st);
+            hipEventRecord(side->ev_seg[s], st);
+        }
+        for (int s = 0; s < last; s++) {
+            hipStreamWaitEvent(side->pts, side->ev_seg[s], 0);
+            launch_cofv_points(lat, g, s, side->pts);
+            hipEventRecord(side->ev_pts[s], side->pts);
+            hipStream_t q = side->acc[seg.chunk[s] == 1 ? 1 : 0];
+            hipStreamWaitEvent(q, side->ev_pts[s], 0);
+            launch_cofv_acc(lat, g, s, q);
+            if (seg.last(s) || s == last - 1) hipEventRecord(side->ev_acc[seg.chunk[s]], q);
+        }
+        launch_cofv_points(lat, g, last, st);
+        hipStreamWaitEvent(st, side->ev_acc[2], 0);  // the chunk's additions before the last segment's
+        launch_cofv_acc(lat, g, last, st);
+        hipStreamWaitEvent(st, side->ev_acc[0], 0);
+        hipStreamWaitEvent(st, side->ev_acc[1], 0);
         hipLaunchKernelGGL(k_cofv_join, dim3(g1), dim3(64), 0, st, g);
+        hipEventRecord(side->ev_join, st);
     } else if (chunked) {
         hipLaunchKernelGGL(ck.cofactor_chunk, dim3(g3), dim3(64), 0, st, g);
         hipLaunchKernelGGL(ck.cofactor_join, dim3(g1), dim3(64), 0, st, g);
@@ -511,12 +563,10 @@ inline void launch_cofactor(const ChainKernels& ck, Latency lat, bool chunked, c
         hipLaunchKernelGGL(ck.cofactor, dim3(g1), dim3(64), 0, st, g);
     }
 }
-// the deferred witness phases of a values-first cofactor chain (launch_cofactor with a side stream), enqueued on the side stream
-inline void launch_cofactor_witness(const Group& g, const CofactorSide& side) {
-    hipStreamWaitEvent(side.side, side.ev_aff, 0);
-    hipLaunchKernelGGL(k_cofv_dbl_w, dim3(item_grid((uint64_t)BLSW_H_EFF_NBITS * g.N, 1)), dim3(64), 0, side.side, g);
-    hipStreamWaitEvent(side.side, side.ev_acc, 0);
-    hipLaunchKernelGGL(k_cofv_add_w, dim3(item_grid(cofv_total_adds() * g.N, 1)), dim3(64), 0, side.side, g);
+// the deferred witness phases of a values-first cofactor chain (launch_cofactor with side streams), enqueued on the side stream
+inline void launch_cofactor_witness(Latency lat, const Group& g, const CofactorSide& side) {
+    hipStreamWaitEvent(side.side, side.ev_join, 0);
+    launch_cofv_witness_phases(lat, g, side.side);
 }
 inline void launch_map(const ChainKernels& ck, Latency lat, const Group& g, hipStream_t st) {
     if (lat.quad)

@@ -204,9 +204,21 @@ static Proj<OpsFp2> run_cofactor(Emitter e_add, Emitter e, const Proj<OpsFp2>& q
         constexpr CofvPlan vp = cofv_plan();
         std::vector<Fp> scr(BLSW_COFV_ELEMS);
         const CoeffLinear S{scr.data()}, R{rows};
-        cofv_chain(e_add, e, q0, q1, S, R);
-        for (int D = BLSW_H_EFF_NBITS - 1; D >= 0; D--) cofv_affine((uint32_t)D, S);
-        for (int c = 2; c >= 0; c--) cofv_acc_chain(c, S, R);
+        constexpr CofvSeg sg = cofv_seg();
+        // the forward doubling chain first (the device's main stream), then each chunk's pipeline (other streams), the chunks in an arbitrary order
+        for (int s = 0; s < BLSW_COFV_NSEG; s++)
+            cofv_chain_seg(s, e_add, e, [&](Proj<OpsFp2>& a, Proj<OpsFp2>& b) { a = q0; b = q1; }, S, R);
+        const int chunk_order[3] = {2, 0, 1};
+        for (int k = 0; k < 3; k++)
+            for (int s = 0; s < BLSW_COFV_NSEG; s++) {
+                if (sg.chunk[s] != chunk_order[k]) continue;
+                cofv_bwd(s, S);
+                const int hi = sg.bnd[s + 1] < BLSW_H_EFF_NBITS ? sg.bnd[s + 1] : BLSW_H_EFF_NBITS - 1;
+                for (int D = hi; D > sg.bnd[s]; D--) cofv_affine((uint32_t)D, S);
+                if (s == 0) cofv_affine(0, S);
+                cofv_acc_seg(s, S, R);
+            }
+        for (int c = 0; c < 3; c++) cofv_acc_az(c, S);
         for (int D = BLSW_H_EFF_NBITS - 1; D >= 0; D--) cofv_dbl_w(e, (uint32_t)D, S);  // beside the addition chains on the device
         for (int c = 2; c >= 0; c--)
             for (int j = (int)vp.n_adds[c] - 1; j >= 0; j--) cofv_add_w(e, c, (uint32_t)j, S);
