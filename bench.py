@@ -71,6 +71,7 @@ def parse_args():
     ap.add_argument("--allgather-overlap", type=int, default=-1,
                     help="compact form: 1 = the gather of step k + 1 on a communication stream beside expansion + digest of step k; 0 = one stream; -1 = 1 when there "
                          "is something to overlap (world > 1): at world 1 the gather is a local copy and the second stream only adds contention (48.5 k vs 44.2 k instances/s)")
+    ap.add_argument("--consumer-reps", type=int, default=3, help="runs of the consumer-mode leg (the median is reported)")
     ap.add_argument("--consumer-steady-shard", type=int, default=32768, help="a second, longer consumer-mode run (steady state: HBM-bound rather than chain-latency-bound; 0 = skip)")
     ap.add_argument("--side-legs", type=int, default=1, help="N = 1: bounded legs for BASELINE configs[3] (one signature over 128 pairs), configs[4] (hash-to-G2, 1 M messages) and "
                     "the compact wire form of configs[1], each with its own roofline and CPU baseline (0 = skip)")
@@ -615,11 +616,24 @@ def main():
         try:
             shard = args.consumer_shard // n * n
             stream_shard = importlib.import_module("tools.shard_rehearsal").stream_shard  # the measurement harness of the consumer legs (not product code)
-            stream_shard(pkg, 2 * n, n, 2, 0, 1, device=dev)  # warm-up: code objects, scratch, allocator
+            # warm-up: the same shard once, untimed — the first run on an engine's fresh hardware queues pays the runtime's one-time costs (per-queue scratch
+            # for every chain kernel of this group shape, code objects, allocator): 0.3-2.9 s measured against 0.14 s for the runs after it
+            stream_shard(pkg, shard, n, 2, 0, 1, device=dev)
             torch.cuda.empty_cache()
-            cs = stream_shard(pkg, shard, n, 2, 0, 1, device=dev)
+            # the shard is a 0.14 s job: one stall of the runtime (a queue's scratch re-allocation, a clock ramp) moves a single shot by tens of per cent,
+            # so it runs `--consumer-reps` times; value = the MEDIAN run, every run's seconds are in the line
+            runs = []
+            for _ in range(max(1, args.consumer_reps)):
+                cs = stream_shard(pkg, shard, n, 2, 0, 1, device=dev)
+                runs.append((cs["seconds"], cs))
+                cs = None
+                torch.cuda.empty_cache()
+            runs_seconds = [r[0] for r in runs]
+            runs_ok = all(bool(r[1]["results_ok"]) for r in runs)
+            cs = sorted(runs, key=lambda r: r[0])[len(runs) // 2][1]
+            del runs
             consumer = {"value": cs["instances_per_s"], "unit": "instances/s", "shard_instances": shard, "steps": cs["steps"], "ring": 2, "group_steps": cs["group_steps"],
-                        "seconds": cs["seconds"], "results_ok": cs["results_ok"],
+                        "seconds": cs["seconds"], "first_step_ms": cs["first_step_ms"], "runs_seconds": runs_seconds, "statistic": "median of %d runs" % len(runs_seconds), "results_ok": runs_ok,
                         "digests_equal_free_running": bool((cs["digests"][:n].view("int64") == ref_digest.numpy()).all()) if cs["first_instance"] == 0 else None,
                         "consumer": "blsw_witness_digest reads every witness tensor before the engine may overwrite it (consumer-mode engine: late materialisation)",
                         "hbm_bytes_per_instance": 2 * lay["n_witness"] * 48}

@@ -1,6 +1,9 @@
 // libblsw.so — the execution engine and the C ABI of include/blsw.h (host code; the kernels are in k_*.hip).
+#include <cstdio>
+#include <cstdlib>
 #include <deque>
 #include <map>
+#include <vector>
 #include "kcommon.hpp"
 
 using namespace blsw;
@@ -84,6 +87,7 @@ struct GroupBuf {
     uint64_t first_seq = 0;
     uint32_t steps = 0;
     bool used = false;
+    bool lat_group = false;  // the group launched last from this buffer took the latency kernels
     Workspace ws;            // of the group launched last from this buffer
     uint32_t jobs_left = 0;  // its steps whose expansion / placement has not been issued yet
 };
@@ -104,7 +108,7 @@ struct blsw_engine {
     uint32_t pending = 0;
     uint64_t submitted = 0, launched = 0, materialised = 0;
     std::deque<Job> jobs;  // steps whose chains are issued, in submission order, waiting for their output to be free (consumer mode)
-    hipStream_t sha = nullptr, expand = nullptr, place = nullptr, lat = nullptr;  // lat: the points of a latency group's cofactor segments
+    hipStream_t sha = nullptr, expand = nullptr, place = nullptr, lat = nullptr;  // lat: the main path of a latency group
     // HIP event pairs around every k_sha_expand launch since the last stats reset (live roofline measurement)
     hipEvent_t* ev_exp = nullptr;  // 2 * BLSW_MAX_TIMED events
     uint32_t n_timed = 0;
@@ -247,7 +251,15 @@ static void materialise(blsw_engine* e, int k, uint32_t s) {
         if (timed) hipEventRecord(e->ev_exp[2 * e->n_timed], e->expand);
         const uint32_t K = e->L.n_pairs;  // 1 except for the N+1-pair product: one SHA segment per (instance, pair)
         ExpandArgs xa = {ws.bits, ws.sha_words, (uint64_t)s * e->n * K, e->L.sha_bits, e->L.off_expand, d.out, d.out_stride, K, K > 1 ? e->L.stride_hash : 0u, 0, (int)e->opt.output_form};
-        launch_expand(e->opt.expand_variant, e->opt.expand_store, e->opt.place_lds, e->expand, xa, (unsigned)(e->n * K));
+        // The expansions of a LATENCY group start when its cofactor segment is done (ev_join), beside prepare(H) and the pairing — two expansions long.
+        // Beside the map and cofactor kernels they cost what they hide (BLSW_TRACE_GROUP, 4 x 1024 instances, no profiler attached): the cofactor
+        // segment's serial kernels load and store their scratch rows through the write path an expansion saturates (17-20 ms instead of 11-13, also with
+        // the expansion dispatched at once as a resident grid, expand_variant 13: 20-28 ms), k_map_q 5.7-9.8 ms instead of 4.4. The pairing kernel
+        // gives 5 ms (16.5 instead of 11.4) for 13 ms of expansion. First tensor after 36-39 ms instead of 39-42, shard rate equal within its spread.
+        if (b.lat_group) hipStreamWaitEvent(e->expand, b.ev_cof[2 * BLSW_COFV_NSEG + 3], 0);
+        const uint32_t variant = e->opt.expand_variant;
+        const unsigned lds = e->opt.place_lds;
+        launch_expand(variant, e->opt.expand_store, lds, e->expand, xa, (unsigned)(e->n * K));
         if (timed) {
             hipEventRecord(e->ev_exp[2 * e->n_timed + 1], e->expand);
             e->n_timed++;
@@ -306,6 +318,42 @@ static int pump(blsw_engine* e) {
     return hip_ok(hipGetLastError(), "materialise");
 }
 
+// BLSW_TRACE_GROUP=1 (diagnostic; not an option of the ABI): timing events after the stages of the K == 1 main stream of every launch group, printed to
+// stderr when the engine is destroyed — what a kernel trace shows, without a profiler attached
+struct GroupTrace {
+    static constexpr int kMarks = 6;
+    hipEvent_t ev[kMarks];
+    uint64_t lanes;
+    bool lat;
+};
+static std::vector<GroupTrace> g_group_trace;
+static bool group_trace_on() {
+    static const bool on = getenv("BLSW_TRACE_GROUP") != nullptr;
+    return on;
+}
+static void group_trace_mark(GroupTrace* t, int i, hipStream_t st) {
+    if (!t) return;
+    hipEventCreate(&t->ev[i]);
+    hipEventRecord(t->ev[i], st);
+}
+static void group_trace_dump() {
+    static const char* names[GroupTrace::kMarks - 1] = {"sha_values+map", "cofactor", "prepare(H)", "wait aux", "pairing"};
+    for (const GroupTrace& t : g_group_trace) {
+        hipEventSynchronize(t.ev[GroupTrace::kMarks - 1]);
+        fprintf(stderr, "[blsw group] %llu lanes%s:", (unsigned long long)t.lanes, t.lat ? " (latency kernels)" : "");
+        float total = 0;
+        for (int i = 0; i + 1 < GroupTrace::kMarks; i++) {
+            float ms = 0;
+            hipEventElapsedTime(&ms, t.ev[i], t.ev[i + 1]);
+            total += ms;
+            fprintf(stderr, " %s %.2f", names[i], ms);
+        }
+        fprintf(stderr, " | total %.2f ms\n", total);
+        for (hipEvent_t ev : t.ev) hipEventDestroy(ev);
+    }
+    g_group_trace.clear();
+}
+
 static int launch_group(blsw_engine* e) {
     GroupBuf& b = e->buf[e->cur];
     const uint32_t steps = e->pending;
@@ -328,6 +376,8 @@ static int launch_group(blsw_engine* e) {
     // runs beside it, and its latency — one wave's instruction stream, whatever the group's size — is what a consumer waits for before the first
     // tensors exist. Such a group takes the latency kernels (options.latency_mode 0): map / prepare / G2 allocation on quads and the cofactor chain
     // values first (kcommon.hpp: Latency). "Idle" is the state of the other group buffers' chains, not a count of groups since the last flush.
+    // (Letting the second small group of a starting pipeline take them too was measured: 56-57 k against 58-60 k instances/s for an 8 192-instance
+    // shard in groups of 4 — two latency groups at once contend for the SIMDs the first one needs.)
     bool idle = true;
     for (int k = 0; k < e->nbuf; k++)
         if (k != e->cur && e->buf[k].used && hipEventQuery(e->buf[k].ev_chains) != hipSuccess) idle = false;
@@ -340,12 +390,12 @@ static int launch_group(blsw_engine* e) {
     const ChainKernels ck = chain_kernels(e->chains_inlined || cold_small);
     const bool chunked = e->cofactor_mode == 2 || (e->cofactor_mode == 0 && g.N <= BLSW_COFACTOR_CHUNKED_MAX_LANES);
     // values-first cofactor chain: its per-doubling / per-addition witness phases go to the aux stream, behind the aux chains (enqueued below)
-    // ... and the pipelines of its chunks run beside the doubling chain on the engine's latency stream (the segments' points) and its sha and place
-    // streams (the addition chains): high-priority streams with nothing to do while a cold group's chains run (its SHA bits are enqueued before;
-    // placement starts after the chains)
+    // ... and the pipelines of its chunks run beside the doubling chain on the buffer's main stream (the segments' points) and the engine's sha and
+    // place streams (the addition chains): streams with nothing to do while a cold group's chains run (its SHA bits are enqueued before; placement
+    // starts after the chains)
     CofactorSide cof_side;
     cof_side.side = b.st[1];
-    cof_side.pts = e->lat;
+    cof_side.pts = b.st[0];
     cof_side.acc[0] = e->place;
     cof_side.acc[1] = e->sha;
     for (int i = 0; i < BLSW_COFV_NSEG; i++) cof_side.ev_seg[i] = b.ev_cof[i], cof_side.ev_pts[i] = b.ev_cof[BLSW_COFV_NSEG + i];
@@ -356,7 +406,13 @@ static int launch_group(blsw_engine* e) {
     // expansions, the next group's chains, this group's aux chains — have slack, they have none
     Group gm = g;
     if (lat.quad || lat.vf) gm.chain_prio = 1;
-    hipStream_t st = b.st[0];
+    // The main path of a latency group runs on the engine's HIGH-priority latency stream: a pipe of the command processor hands its dispatcher to the
+    // highest-priority queue that has a kernel ready, so beside an expansion (high-priority stream, 246 144 workgroups) a kernel launched on a
+    // normal-priority stream waits until the expansion has been dispatched to its end (BLSW_TRACE_GROUP: prepare(H) 13 ms instead of 1.8). The
+    // buffer's own main stream carries the points of the cofactor segments instead.
+    const bool lat_any = lat.quad || lat.vf;
+    hipStream_t st = lat_any ? e->lat : b.st[0];
+    GroupTrace* trace = nullptr;
     // inputs of every step are ready once its submitting stream reached the point of the submit
     for (uint32_t s = 0; s < steps; s++) hipStreamWaitEvent(st, b.ev_in[s], 0);
     bool any_out = false;
@@ -412,10 +468,18 @@ static int launch_group(blsw_engine* e) {
         }
     } else {
         // main, first part: the hash-to-G2 critical path
+        if (group_trace_on()) {
+            g_group_trace.push_back(GroupTrace{{}, g.N, lat.quad || lat.vf});
+            trace = &g_group_trace.back();
+        }
+        group_trace_mark(trace, 0, st);
         hipLaunchKernelGGL(k_sha_values, dim3(g1), dim3(64), 0, st, gm);
         launch_map(ck, lat, gm, st);
+        group_trace_mark(trace, 1, st);
         launch_cofactor(ck, lat, chunked, gm, st, &cof_side);
+        group_trace_mark(trace, 2, st);
         launch_prepare(ck, lat, gm, 0, st);
+        group_trace_mark(trace, 3, st);
         // aux: prepare_g2(sig) and the key's allocation + prepare_g1 — what the pairing waits for (ev_aux) — then the signature's allocation chain, which
         // only the end of the group waits for (ev_side): the longest aux kernel no longer delays the pairing of a latency-bound group
         hipStream_t sb = b.st[1];
@@ -437,7 +501,9 @@ static int launch_group(blsw_engine* e) {
         if (cof_deferred) launch_cofactor_witness(lat, g, cof_side);
         // main, second part: the pairing
         hipStreamWaitEvent(st, b.ev_aux, 0);
+        group_trace_mark(trace, 4, st);
         launch_pairing(gm, e->modes, st);
+        group_trace_mark(trace, 5, st);
     }
     // the group's chains are done when the aux stream's tail (G2 allocation, deferred witness phases of the cofactor chain) is
     hipEventRecord(b.ev_side, b.st[1]);
@@ -449,6 +515,7 @@ static int launch_group(blsw_engine* e) {
     b.jobs_left = steps;
     for (uint32_t s = 0; s < steps; s++) e->jobs.push_back({e->cur, s});
     b.used = true;
+    b.lat_group = lat.quad || lat.vf;
     b.first_seq = e->launched;
     b.steps = steps;
     e->launched += steps;
@@ -547,7 +614,7 @@ int blsw_engine_create_ex(blsw_engine_t** out, uint64_t n, uint32_t msg_len, uin
     // place while the chains run and could not honour a held output
     if (options->consumer_mode > 1 || (options->consumer_mode == 1 && max_steps == 1 && n_buffers == 1)) return BLSW_ERR_ARG;
     if (options->pairing_mode > 1 || options->g2_mode > 1 || (options->g2_mode == 1 && options->pairing_mode != 0) || options->expand_store > 3 ||
-        options->prio_mode > 2 || options->group_ramp > 1 || options->latency_mode > 4 || options->output_form > 1 || options->chain_variant > 2 || options->cofactor_mode > 2 || (options->expand_variant & 0xff) > 12 || (options->expand_variant >> 9) || options->n_keys > 65535 ||
+        options->prio_mode > 2 || options->group_ramp > 1 || options->latency_mode > 4 || options->output_form > 1 || options->chain_variant > 2 || options->cofactor_mode > 2 || (options->expand_variant & 0xff) > 13 || (options->expand_variant >> 9) || options->n_keys > 65535 ||
         (options->n_keys && options->g2_mode) || options->n_pairs > 4096)
         return BLSW_ERR_ARG;
     // N+1-pair product (options.n_pairs = K > 1): a staged engine with the default kernel modes; its expansion launch has one row of
@@ -682,6 +749,7 @@ int blsw_engine_destroy(blsw_engine_t* e) {
     if (!e) return BLSW_ERR_ARG;
     DeviceGuard guard(e->device);
     hipDeviceSynchronize();
+    if (group_trace_on()) group_trace_dump();
     engine_free(e);
     return BLSW_OK;
 }

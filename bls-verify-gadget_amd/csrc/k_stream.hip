@@ -55,24 +55,31 @@ __device__ __forceinline__ void expand_head(uint4* out, const uint32_t* b, uint3
     }
 }
 // variant 0 (and, with THREADS = 768 and 4 KiB alignment, variants 2 / 3): THREADS is a multiple of 192, so a thread's column is a
-// loop invariant; a workgroup writes THREADS * ITERS consecutive pieces, THREADS of them per iteration
+// loop invariant; a workgroup writes THREADS * ITERS consecutive pieces, THREADS of them per iteration. (bx, by) = the block's place in the
+// (blocks per instance, instances) grid: blockIdx of variant 0, a loop variable of the persistent variant 13.
 template <int THREADS, int ITERS, int ALIGN_PIECES, int NT>
-__global__ __launch_bounds__(THREADS) void k_sha_expand(ExpandArgs a) {
-    if (a.prio) __builtin_amdgcn_s_setprio(3);
-    uint4* out;
-    const uint32_t* b;
-    expand_locate(a, out, b);
+__device__ __forceinline__ void expand_block(const ExpandArgs& a, uint32_t bx, uint32_t by) {
+    const uint64_t inst = a.K == 1 ? by : by / a.K;
+    const uint32_t pair = a.K == 1 ? 0u : by - (uint32_t)inst * a.K;
+    uint4* out = reinterpret_cast<uint4*>(a.d_witness + (inst * a.stride + a.off_expand + (uint64_t)pair * a.stride_hash) * 6);
+    const uint64_t lane = a.first + by;
+    const uint32_t* b = a.bits + (lane >> 6) * bits_tile_words(a.sha_words) + (lane & 63) * BLSW_BITS_CHUNK_WORDS;
     const uint32_t n_pieces = a.sha_bits * 3;
     const uint32_t P0 = (ALIGN_PIECES - (uint32_t)((reinterpret_cast<uintptr_t>(out) >> 4) % ALIGN_PIECES)) % ALIGN_PIECES;
-    expand_head<NT>(out, b, P0, n_pieces, a.canonical);
+    if (bx == 0 && threadIdx.x < P0 && threadIdx.x < n_pieces) {  // the pieces in front of the first boundary
+        const uint32_t e = threadIdx.x / 3, c = threadIdx.x - 3 * e;
+        const uint32_t m = 0u - ((expand_word(b, e >> 5) >> (e & 31)) & 1u);
+        const uint4 rc = expand_column(c, a.canonical);
+        expand_store<NT>(&out[threadIdx.x], make_uint4(rc.x & m, rc.y & m, rc.z & m, rc.w & m));
+    }
     const uint32_t pt = P0 + threadIdx.x, c = pt % 3;
-    const uint32_t e0 = blockIdx.x * ((THREADS / 3) * ITERS) + pt / 3;
+    const uint32_t e0 = bx * ((THREADS / 3) * ITERS) + pt / 3;
     const uint4 rc = expand_column(c, a.canonical);
     // THREADS / 3 is a multiple of 32: the bit position of a thread is a loop invariant too, its word advances by THREADS / 96
     static_assert((THREADS / 3) % 32 == 0, "bit position must be loop invariant");
     const uint32_t sh = e0 & 31, w0 = e0 >> 5;
     uint4* dst = out + (uint64_t)e0 * 3 + c;
-    if (blockIdx.x * ((THREADS / 3) * ITERS) + (P0 + THREADS - 1) / 3 + (THREADS / 3) * (ITERS - 1) < a.sha_bits) {
+    if (bx * ((THREADS / 3) * ITERS) + (P0 + THREADS - 1) / 3 + (THREADS / 3) * (ITERS - 1) < a.sha_bits) {
         // whole workgroup in range (all but the last one or two of an instance): all bit words first, then the stores back to
         // back — no bounds checks, no wait between a store and the next load
         uint32_t w[ITERS];
@@ -92,6 +99,25 @@ __global__ __launch_bounds__(THREADS) void k_sha_expand(ExpandArgs a) {
             const uint32_t m = 0u - ((expand_word(b, w0 + k * (THREADS / 96)) >> sh) & 1u);
             expand_store<NT>(dst + (uint64_t)k * THREADS, make_uint4(rc.x & m, rc.y & m, rc.z & m, rc.w & m));
         }
+    }
+}
+template <int THREADS, int ITERS, int ALIGN_PIECES, int NT>
+__global__ __launch_bounds__(THREADS) void k_sha_expand(ExpandArgs a) {
+    if (a.prio) __builtin_amdgcn_s_setprio(3);
+    expand_block<THREADS, ITERS, ALIGN_PIECES, NT>(a, blockIdx.x, blockIdx.y);
+}
+// variant 13: the blocks of variant 0 walked by a RESIDENT grid (BLSW_EXPAND_RESIDENT_WGS workgroups, block = blockIdx.x + k * gridDim.x). A grid of
+// 246 144 workgroups keeps the dispatcher of its hardware queue's pipe busy for the whole run of the kernel, and kernels of other queues on that pipe
+// are not dispatched meanwhile (a chain kernel launched beside an expansion waited for the expansion's END: engine.hip, materialise); this grid is
+// dispatched in microseconds. Two workgroups (twelve 24-register waves) per compute unit leave every SIMD five wave slots and 440 registers.
+template <int THREADS, int ITERS, int ALIGN_PIECES, int NT>
+__global__ __launch_bounds__(THREADS) void k_sha_expand_resident(ExpandArgs a, uint32_t blocks_x, uint32_t n_y) {
+    if (a.prio) __builtin_amdgcn_s_setprio(3);
+    const uint64_t total = (uint64_t)blocks_x * n_y;
+#pragma unroll 1
+    for (uint64_t blk = blockIdx.x; blk < total; blk += gridDim.x) {
+        const uint32_t by = (uint32_t)(blk / blocks_x);
+        expand_block<THREADS, ITERS, ALIGN_PIECES, NT>(a, (uint32_t)(blk - (uint64_t)by * blocks_x), by);
     }
 }
 // variants 1 / 6 / 7: one piece per thread, workgroup b >= 1 writes exactly one chunk of THREADS pieces aligned to its own size
@@ -232,6 +258,7 @@ void launch_expand(uint32_t variant, uint32_t store, unsigned lds, hipStream_t s
         case 10: hipLaunchKernelGGL(k_sha_expand_l<8>, grid(384 * 8), dim3(384), lds, st, a); break;
         case 11: hipLaunchKernelGGL(k_sha_expand_l<16>, grid(384 * 16), dim3(384), lds, st, a); break;
         case 12: hipLaunchKernelGGL(k_sha_expand_l<32>, grid(384 * 32), dim3(384), lds, st, a); break;
+        case 13: hipLaunchKernelGGL((k_sha_expand_resident<384, 8, 16, 0>), dim3(BLSW_EXPAND_RESIDENT_WGS), dim3(384), lds, st, a, grid(384 * 8).x, n_y); break;
         case 2: hipLaunchKernelGGL((k_sha_expand<768, 8, 256, 0>), grid(768 * 8), dim3(768), lds, st, a); break;
         case 3: hipLaunchKernelGGL((k_sha_expand<768, 4, 256, 0>), grid(768 * 4), dim3(768), lds, st, a); break;
         case 4: hipLaunchKernelGGL((k_sha_expand<768, 16, 256, 0>), grid(768 * 16), dim3(768), lds, st, a); break;

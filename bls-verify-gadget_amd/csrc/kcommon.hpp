@@ -335,6 +335,7 @@ struct ExpandArgs {
     int prio;                 // raise the wave priority (s_setprio 3): wins VALU issue arbitration against the chain waves
     int canonical;            // elements as canonical integers (true = 1) instead of Montgomery form (true = R mod p)
 };
+#define BLSW_EXPAND_RESIDENT_WGS 512u  // expand_variant 13 (k_stream.hip): two 384-thread workgroups per compute unit
 
 #define BLSW_TEAMS_PER_WAVE 10
 #define BLSW_ATTR_W2 __attribute__((amdgpu_waves_per_eu(2, 2)))  // register budget of a kernel: two waves per SIMD

@@ -129,7 +129,8 @@ typedef struct {
                               * chunk per 256-thread workgroup, 2 / 3 / 4 = 768 threads x 8 / 4 / 16 pieces in 4 KiB-aligned chunks, 5 = 384 x 16, 6 / 7 = one
                               * 8 / 16 KiB-aligned chunk per 512- / 1024-thread workgroup, 8 / 9 = 384 x 8 / 4 with the bit words in scalar registers
                               * (14 vector registers per lane), 10 / 11 / 12 = 384 x 8 / 16 / 32 with a light instruction stream (scalar bit window, scalar store base: 5 vector
-                              * instructions per store instead of ~20); | 0x100 = raised wave priority.
+                              * instructions per store instead of ~20), 13 = the blocks of 0 walked by a resident grid of 512 workgroups (a grid that is dispatched at once:
+                              * the engine takes it by itself for the expansions it issues beside a latency group's chains); | 0x100 = raised wave priority.
                               * Only 0 is the shipped path. 10 / 11 / 12 (and expand_store 2 / 3) are EXPERIMENTAL, non-default measurement variants: their inline
                               * assembly carries hand-counted hazard wait states for gfx950 (the unit refuses to compile for another target) and only
                               * test_expansion_geometries_bit_exact guards them */

@@ -921,7 +921,7 @@ def test_engine_bench_shape_against_oracle(pkg, oracle):
 
 @pytest.mark.parametrize("msg_len", [32, 3])
 def test_expansion_geometries_bit_exact(pkg, oracle, msg_len):
-    """Every store geometry of the SHA expansion (options.expand_variant 1 .. 12: one piece per thread in 4 / 8 / 16 KiB chunks, 768-thread variants, scalar
+    """Every store geometry of the SHA expansion (options.expand_variant 1 .. 13: one piece per thread in 4 / 8 / 16 KiB chunks, 768-thread variants, scalar
     bit words, the light instruction stream at 8 / 16 / 32 pieces per thread) and the canonical output form through the light kernel write the tensors
     of the default engine, byte for byte; one instance per message length against the oracle. 70 instances (a ragged tile), two steps, two message lengths (different segment alignments and tail workgroups)."""
     import torch
@@ -954,7 +954,7 @@ def test_expansion_geometries_bit_exact(pkg, oracle, msg_len):
     assert torch.equal(ref[0], ref[1])
     nw, _, r, ow = oracle.witness(pk[69], msg[69].tobytes(), sig[69])
     assert nw == ref[0].shape[1] and np.array_equal(ref[0][69].cpu().numpy().view(np.uint64), ow) and bool(ref_res[0][69].item()) == r
-    for variant in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12):
+    for variant in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13):
         got, res = run(expand_variant=variant)
         for k in range(2):
             assert torch.equal(got[k], ref[k]), "expand_variant %d, step %d" % (variant, k)

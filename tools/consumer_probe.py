@@ -8,6 +8,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+# as bench.py: more hardware queues per priority level than the runtime's default of 4, so that the engine's streams and the consumer's do not share one
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 
 def main():
@@ -27,7 +29,7 @@ def main():
         shard, group, ramp = plan[:3]
         ring = plan[3] if len(plan) > 3 else 2
         cs = sharding.stream_shard(pkg, shard, n, ring, 0, 1, device=dev, group=group, ramp=ramp)
-        print(json.dumps({"shard": shard, "ring": ring, "group": cs["group_steps"], "ramp": cs["group_ramp"], "instances_per_s": round(cs["instances_per_s"]), "seconds": round(cs["seconds"], 4),
+        print(json.dumps({"shard": shard, "ring": ring, "group": cs["group_steps"], "ramp": cs["group_ramp"], "instances_per_s": round(cs["instances_per_s"]), "seconds": round(cs["seconds"], 4), "first_step_ms": round(cs["first_step_ms"], 2),
                           "results_ok": cs["results_ok"]}), flush=True)
         del cs
         torch.cuda.empty_cache()

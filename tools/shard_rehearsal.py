@@ -69,15 +69,20 @@ def stream_shard(pkg, n_shard=8192, batch=1024, ring=2, rank=0, world=8, buffers
     torch.cuda.synchronize(dev)
     state = {"next": 0}
 
+    ev_t0, ev_first = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
     def drain():
         while state["next"] < eng.materialised():
             s = state["next"]
             eng.wait_step(s, consumer)
+            if s == 0:
+                ev_first.record(consumer)  # the first witness tensor exists: what a consumer waits for before it can start
             pkg.witness_digest(outs[s % ring], out=digests[s], stream=consumer)
             eng.output_consumed(outs[s % ring], consumer)
             state["next"] += 1
 
     t0 = time.perf_counter()
+    ev_t0.record(torch.cuda.current_stream(dev))
     for k in range(steps):
         pk, msg, sig = inputs[k]
         while True:
@@ -97,7 +102,7 @@ def stream_shard(pkg, n_shard=8192, batch=1024, ring=2, rank=0, world=8, buffers
     expect = np.stack(expects)
     eng.close()
     return {"rank": rank, "world": world, "first_instance": lo, "n_shard": n_shard, "batch": batch, "ring": ring, "group_steps": group or ring,
-            "consumer_mode": bool(group), "group_ramp": bool(group and ramp), "steps": steps, "seconds": dt,
+            "consumer_mode": bool(group), "group_ramp": bool(group and ramp), "steps": steps, "seconds": dt, "first_step_ms": ev_t0.elapsed_time(ev_first),
             "instances_per_s": n_shard / dt, "results_ok": bool((res == expect).all()), "digests": digests.cpu().numpy().view(np.uint64).reshape(n_shard, 2),
             "inputs": inputs, "sampled": 0}
 
