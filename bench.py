@@ -47,7 +47,7 @@ FPMUL_PER_INV = 570
 # what the kernels execute instead of a Fermat inversion: one safegcd inversion = 26.9 Fp-product times (blsw_microbench 2 / 1);
 # 636 of the 940 cofactor-chain inversions are shared with a neighbour (Montgomery's trick: +9 products each, -1 inversion)
 FPMUL_PER_INV_EXECUTED = 27
-TRAFFIC_FILES = ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json")
+TRAFFIC_FILES = ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json")
 
 
 def parse_args():
@@ -71,7 +71,7 @@ def parse_args():
     ap.add_argument("--allgather-overlap", type=int, default=-1,
                     help="compact form: 1 = the gather of step k + 1 on a communication stream beside expansion + digest of step k; 0 = one stream; -1 = 1 when there "
                          "is something to overlap (world > 1): at world 1 the gather is a local copy and the second stream only adds contention (48.5 k vs 44.2 k instances/s)")
-    ap.add_argument("--consumer-reps", type=int, default=3, help="runs of the consumer-mode leg (the median is reported)")
+    ap.add_argument("--consumer-reps", type=int, default=5, help="runs of the consumer-mode leg (the median is reported)")
     ap.add_argument("--consumer-steady-shard", type=int, default=32768, help="a second, longer consumer-mode run (steady state: HBM-bound rather than chain-latency-bound; 0 = skip)")
     ap.add_argument("--side-legs", type=int, default=1, help="N = 1: bounded legs for BASELINE configs[3] (one signature over 128 pairs), configs[4] (hash-to-G2, 1 M messages) and "
                     "the compact wire form of configs[1], each with its own roofline and CPU baseline (0 = skip)")

@@ -256,7 +256,9 @@ static void materialise(blsw_engine* e, int k, uint32_t s) {
         // segment's serial kernels load and store their scratch rows through the write path an expansion saturates (17-20 ms instead of 11-13, also with
         // the expansion dispatched at once as a resident grid, expand_variant 13: 20-28 ms), k_map_q 5.7-9.8 ms instead of 4.4. The pairing kernel
         // gives 5 ms (16.5 instead of 11.4) for 13 ms of expansion. First tensor after 36-39 ms instead of 39-42, shard rate equal within its spread.
-        if (b.lat_group) hipStreamWaitEvent(e->expand, b.ev_cof[2 * BLSW_COFV_NSEG + 3], 0);
+        // Consumer mode only: a free-running engine has all of the group's expansions to write, and holding them back is HBM time lost (configs[3],
+        // 12 steps: 950 instead of 1 050 instances/s).
+        if (b.lat_group && e->opt.consumer_mode) hipStreamWaitEvent(e->expand, b.ev_cof[2 * BLSW_COFV_NSEG + 3], 0);
         const uint32_t variant = e->opt.expand_variant;
         const unsigned lds = e->opt.place_lds;
         launch_expand(variant, e->opt.expand_store, lds, e->expand, xa, (unsigned)(e->n * K));
@@ -524,6 +526,47 @@ static int launch_group(blsw_engine* e) {
     e->cur = (e->cur + 1) % e->nbuf;
     if (hip_ok(hipGetLastError(), "launch")) return BLSW_ERR_HIP;
     return pump(e);
+}
+
+// Side streams of a DIRECT call's values-first cofactor chain (kcommon.hpp: CofactorSide), created once per host thread and device and kept (an event
+// is re-recorded per call; a wait refers to the record that preceded it). Without them the segments' phases run one after the other on the caller's stream.
+struct DirectLanes {
+    int device = -1;
+    hipStream_t st[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[BLSW_COFV_EVENTS + 1] = {};
+    bool ok = false;
+};
+static DirectLanes* direct_lanes(int dev) {
+    static thread_local std::map<int, DirectLanes> lanes;
+    DirectLanes& d = lanes[dev];
+    if (d.device != dev) {
+        d.device = dev;
+        d.ok = true;
+        for (hipStream_t& q : d.st) d.ok = d.ok && hipStreamCreateWithFlags(&q, hipStreamNonBlocking) == hipSuccess;
+        for (hipEvent_t& ev : d.ev) d.ok = d.ok && hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess;
+    }
+    return d.ok ? &d : nullptr;
+}
+// launch_cofactor of a direct call on `st`, with its pipelines on the thread's side streams; `st` has waited for all of it on return
+static void launch_cofactor_direct(const ChainKernels& ck, Latency lat, const Group& g, hipStream_t st, int dev) {
+    const bool chunked = g.N <= BLSW_COFACTOR_CHUNKED_MAX_LANES;
+    DirectLanes* d = (lat.vf && g.ws.cofv) ? direct_lanes(dev) : nullptr;
+    if (!d) {
+        launch_cofactor(ck, lat, chunked, g, st);
+        return;
+    }
+    CofactorSide cs;
+    cs.side = d->st[0];
+    cs.pts = d->st[1];
+    cs.acc[0] = d->st[2];
+    cs.acc[1] = d->st[3];
+    for (int i = 0; i < BLSW_COFV_NSEG; i++) cs.ev_seg[i] = d->ev[i], cs.ev_pts[i] = d->ev[BLSW_COFV_NSEG + i];
+    for (int i = 0; i < 3; i++) cs.ev_acc[i] = d->ev[2 * BLSW_COFV_NSEG + i];
+    cs.ev_join = d->ev[2 * BLSW_COFV_NSEG + 3];
+    launch_cofactor(ck, lat, chunked, g, st, &cs);
+    launch_cofactor_witness(lat, g, cs);
+    hipEventRecord(d->ev[BLSW_COFV_EVENTS], cs.side);
+    hipStreamWaitEvent(st, d->ev[BLSW_COFV_EVENTS], 0);
 }
 
 extern "C" {
@@ -1145,7 +1188,7 @@ int blsw_aggregate_verify_batch(const uint64_t* d_pks_xy, const uint8_t* d_bitma
         launch_expand(BLSW_DEFAULT_EXPAND_VARIANT, 0, 0, st, xa, (unsigned)n);
     }
     launch_map(ck, lat, g, st);
-    launch_cofactor(ck, lat, g.N <= BLSW_COFACTOR_CHUNKED_MAX_LANES, g, st);
+    launch_cofactor_direct(ck, lat, g, st, stream_device(st));
     launch_prepare(ck, lat, g, 0, st);
     launch_pairing(g, DEFAULT_MODES, st);
     return hip_ok(hipGetLastError(), "launch");
@@ -1233,7 +1276,7 @@ int blsw_verify_multi_batch(const uint64_t* d_pks_xy, const uint8_t* d_msgs, uin
     }
     hipLaunchKernelGGL(k_sha_values, dim3(p1), dim3(64), 0, st, gp);
     launch_map(ck, lat, gp, st);
-    launch_cofactor(ck, lat, gp.N <= BLSW_COFACTOR_CHUNKED_MAX_LANES, gp, st);
+    launch_cofactor_direct(ck, lat, gp, st, dev);
     launch_prepare(ck, lat, gp, 0, st);
     if (forked) {
         hipEventRecord(ev_join[0], s_sig);

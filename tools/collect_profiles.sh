@@ -11,6 +11,8 @@ cp $O/pmc_sq.txt $P/${TAG}_pmc_sq.txt
 { echo "# k_digest alone (tools/digest_rate.py): rate from HIP events, then SQ_INSTS_VALU / SQ_WAVES per launch of 1024 instances (rocprofv3 --pmc, own pass)"; cat $O/digest_rate.json; cat $O/pmc_digest.txt; } > $P/${TAG}_digest.txt
 cp $O/short_timeline.txt $P/${TAG}_short_job_timeline.txt
 [ -s $O/consumer_timeline_full.txt ] && cp $O/consumer_probe.txt $P/${TAG}_consumer_probe.txt
+[ -s $O/consumer_timeline_full.txt ] && python3 tools/consumer_timeline_excerpt.py $O/consumer_timeline_full.txt > $P/${TAG}_consumer_timeline.txt
+[ -s $O/consumer_group_trace.txt ] && grep "blsw group\|instances_per_s" $O/consumer_group_trace.txt > $P/${TAG}_consumer_group_trace.txt
 [ -s $O/verify_rate.txt ] && cp $O/verify_rate.txt $P/${TAG}_verify_rate.txt
 [ -s $O/side_configs.jsonl ] && cp $O/side_configs.jsonl $P/${TAG}_side_configs.jsonl
 [ -s $O/engine_bench_c.json ] && cp $O/engine_bench_c.json $P/${TAG}_engine_bench_c.json

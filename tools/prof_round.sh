@@ -23,6 +23,8 @@ rocprofv3 --kernel-trace --output-format csv -d $O/consumer -o t -- python3 $R/t
 cd $R
 python3 tools/timeline.py $(ls $O/consumer/*kernel_trace.csv $O/consumer/*/*kernel_trace.csv 2>/dev/null | head -1) > $O/consumer_timeline_full.txt
 rm -rf $O/consumer
+# the same shard with no profiler attached: stage times of every launch group from the engine's own HIP events (BLSW_TRACE_GROUP) + first_step_ms
+BLSW_TRACE_GROUP=1 python3 tools/consumer_probe.py "[8192,null,false]" "[8192,null,false]" "[8192,null,false]" "[8192,null,false]" "[8192,null,false]" "[32768,null,false]" > $O/consumer_group_trace.txt 2>&1
 python3 tools/verify_rate.py > $O/verify_rate.txt 2> $O/verify_rate.err
 python3 tools/pmc_summary.py $O/pmc_WRITE_SIZE $O/pmc_FETCH_SIZE --json > $O/pmc_hbm.txt
 python3 tools/pmc_summary.py $O/pmc_SQ_WAVE_CYCLES > $O/pmc_sq.txt
