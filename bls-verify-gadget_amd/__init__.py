@@ -187,7 +187,7 @@ def check_capacity(device, what, *byte_counts):
 def engine_options(**overrides):
     """blsw_engine_options_default with keyword overrides: device, pairing_mode ("team"/"lane" or 0/1), g2_mode ("lane"/"team"
     or 0/1), expand_variant, expand_store, prio_mode, place_lds, consumer_mode, output_form, n_keys. The library itself reads no
-    environment; for A/B runs of measurement scripts THIS function applies BLSW_PAIRING=lane, BLSW_G2=team, BLSW_EXPAND_VARIANT,
+    environment for its options (one diagnostic: BLSW_TRACE_GROUP=1 prints every launch group's stage times at engine destruction); for A/B runs of measurement scripts THIS function applies BLSW_PAIRING=lane, BLSW_G2=team, BLSW_EXPAND_VARIANT,
     BLSW_EXPAND_NT, BLSW_PRIO_MODE, BLSW_PLACE_LDS (explicit keyword arguments win)."""
     o = blsw_engine_options_t()
     rc = lib().blsw_engine_options_default(ctypes.byref(o))
