@@ -616,18 +616,20 @@ def main():
         try:
             shard = args.consumer_shard // n * n
             stream_shard = importlib.import_module("tools.shard_rehearsal").stream_shard  # the measurement harness of the consumer legs (not product code)
-            # warm-up: the same shard once, untimed — the first run on an engine's fresh hardware queues pays the runtime's one-time costs (per-queue scratch
-            # for every chain kernel of this group shape, code objects, allocator): 0.3-2.9 s measured against 0.14 s for the runs after it
-            stream_shard(pkg, shard, n, 2, 0, 1, device=dev)
-            torch.cuda.empty_cache()
-            # the shard is a 0.14 s job: one stall of the runtime (a queue's scratch re-allocation, a clock ramp) moves a single shot by tens of per cent,
-            # so it runs `--consumer-reps` times; value = the MEDIAN run, every run's seconds are in the line
+            # ONE engine for the warm-up and the timed runs, as a consumer that streams shard after shard uses it: an engine's fresh streams pay the
+            # runtime's one-time costs (per-queue scratch for every chain kernel of this group shape, first dispatches): the first shard on a new engine
+            # took 0.19-2.9 s against 0.14 s for the shards after it. Warm-up: the same shard once, untimed. The shard is a 0.14 s job, so it then
+            # runs `--consumer-reps` times; value = the MEDIAN run, every run's seconds are in the line
+            kept = {}
+            stream_shard(pkg, shard, n, 2, 0, 1, device=dev, keep=kept)
             runs = []
             for _ in range(max(1, args.consumer_reps)):
-                cs = stream_shard(pkg, shard, n, 2, 0, 1, device=dev)
+                cs = stream_shard(pkg, shard, n, 2, 0, 1, device=dev, keep=kept)
                 runs.append((cs["seconds"], cs))
                 cs = None
-                torch.cuda.empty_cache()
+            kept["eng"].close()
+            kept.clear()
+            torch.cuda.empty_cache()
             runs_seconds = [r[0] for r in runs]
             runs_ok = all(bool(r[1]["results_ok"]) for r in runs)
             cs = sorted(runs, key=lambda r: r[0])[len(runs) // 2][1]

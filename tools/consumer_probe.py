@@ -25,14 +25,22 @@ def main():
              (32768, None, True), (32768, None, False), (32768, None, True), (32768, 8, True), (32768, 10, True)]
     if len(sys.argv) > 1:
         plans = [tuple(json.loads(a)) for a in sys.argv[1:]]
+    kept, kept_plan = {}, None
     for plan in plans:
         shard, group, ramp = plan[:3]
         ring = plan[3] if len(plan) > 3 else 2
-        cs = sharding.stream_shard(pkg, shard, n, ring, 0, 1, device=dev, group=group, ramp=ramp)
+        if kept_plan != (shard, group, ramp, ring):  # consecutive runs of one plan share an engine (as a consumer streaming shards would)
+            if kept:
+                kept["eng"].close()
+            kept, kept_plan = {}, (shard, group, ramp, ring)
+            torch.cuda.empty_cache()
+        cs = sharding.stream_shard(pkg, shard, n, ring, 0, 1, device=dev, group=group, ramp=ramp, keep=kept)
         print(json.dumps({"shard": shard, "ring": ring, "group": cs["group_steps"], "ramp": cs["group_ramp"], "instances_per_s": round(cs["instances_per_s"]), "seconds": round(cs["seconds"], 4), "first_step_ms": round(cs["first_step_ms"], 2),
                           "results_ok": cs["results_ok"]}), flush=True)
         del cs
         torch.cuda.empty_cache()
+    if kept:
+        kept["eng"].close()
 
 
 if __name__ == "__main__":

@@ -29,7 +29,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-def stream_shard(pkg, n_shard=8192, batch=1024, ring=2, rank=0, world=8, buffers=6, seed=0x5EED, device=None, group=None, ramp=False):
+def stream_shard(pkg, n_shard=8192, batch=1024, ring=2, rank=0, world=8, buffers=6, seed=0x5EED, device=None, group=None, ramp=False, keep=None):
     """One rank's shard of a sharded batch (BASELINE configs[2]: 65 536 instances over 8 GPUs = 8 192 per rank) streamed in
     micro-batches of `batch` instances through a ring of `ring` witness tensors: every tensor is drained by a consumer (the digest
     kernel blsw_witness_digest, standing in for a per-GPU prover or the gather of a micro-batch) before the engine may overwrite it.
@@ -37,6 +37,9 @@ def stream_shard(pkg, n_shard=8192, batch=1024, ring=2, rank=0, world=8, buffers
     ring tensor when the consumer has released that tensor's previous user); group = 0: free-running engine with groups of `ring`.
     ramp: the consumer-mode engine starts with groups of 2, 4, 8, ... steps (options.group_ramp); measured useless (a group's chain latency is one
     wave's latency, 59 ms for 2 x 1024 instances and 63 ms for 4 x 1024: profiles/r04_consumer_probe.txt), off by default.
+    keep: a dict that carries the engine, its ring and the consumer's stream from one call to the next (same shard geometry): a consumer streams
+    many shards through ONE engine, and an engine's fresh streams pay the runtime's one-time costs (per-queue scratch, first dispatches) once.
+    The last caller closes keep["eng"].
     Inputs are minted on the GPU before the timed region. -> dict (instances_per_s, digests [n_shard, 2] uint64, ...)."""
     import torch
 
@@ -48,19 +51,25 @@ def stream_shard(pkg, n_shard=8192, batch=1024, ring=2, rank=0, world=8, buffers
     steps = n_shard // batch
     if group is None:
         group = max(1, min(16, steps // 2))
-    if group:
-        n_groups = (steps + group - 1) // group + (2 if ramp and group > 2 else 0)
-        eng = pkg.WitnessEngine(batch, 32, max_steps=group, device=dev, n_buffers=max(2, min(3, n_groups)), consumer_mode=1, group_ramp=1 if ramp else 0)
+    if keep is not None and "eng" in keep:
+        eng, outs = keep["eng"], keep["outs"]
     else:
-        eng = pkg.WitnessEngine(batch, 32, max_steps=ring, device=dev, n_buffers=min(buffers, max(1, steps // ring)))
-    outs = [eng.new_witness_tensor() for _ in range(ring)]
+        if group:
+            n_groups = (steps + group - 1) // group + (2 if ramp and group > 2 else 0)
+            eng = pkg.WitnessEngine(batch, 32, max_steps=group, device=dev, n_buffers=max(2, min(3, n_groups)), consumer_mode=1, group_ramp=1 if ramp else 0)
+        else:
+            eng = pkg.WitnessEngine(batch, 32, max_steps=ring, device=dev, n_buffers=min(buffers, max(1, steps // ring)))
+        outs = [eng.new_witness_tensor() for _ in range(ring)]
     digests = torch.zeros((steps, batch, 2), dtype=torch.int64, device=dev)
     results = torch.zeros((steps, batch), dtype=torch.int32, device=dev)
     # the consumer's stream in the HIGH-priority pool of hardware queues (with the engine's sha / expand / place streams): the runtime backs each
     # priority level with four hardware queues, and a fifth normal-priority stream (null stream + three group buffers' main streams + this one) shares
     # a queue with the null stream — every submit's input-ready marker then queues behind the consumer's waiting digests and the next launch group
     # starts ~70 ms late (profiles/r04_consumer_timeline.txt)
-    consumer = torch.cuda.Stream(device=dev, priority=-1)
+    consumer = keep["consumer"] if keep is not None and "consumer" in keep else torch.cuda.Stream(device=dev, priority=-1)
+    if keep is not None:
+        keep.update(eng=eng, outs=outs, consumer=consumer)
+    base = eng.submitted()  # global step number of this shard's first step (a kept engine has served shards before)
     inputs, expects = [], []
     for k in range(steps):  # inputs are resident before the timed region (minted by the product's signer)
         pk, msg, sig, expect = workload.make_batch(pkg, batch, seed=seed, device=dev, start=lo + k * batch)
@@ -72,9 +81,9 @@ def stream_shard(pkg, n_shard=8192, batch=1024, ring=2, rank=0, world=8, buffers
     ev_t0, ev_first = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
     def drain():
-        while state["next"] < eng.materialised():
+        while state["next"] < eng.materialised() - base:
             s = state["next"]
-            eng.wait_step(s, consumer)
+            eng.wait_step(base + s, consumer)
             if s == 0:
                 ev_first.record(consumer)  # the first witness tensor exists: what a consumer waits for before it can start
             pkg.witness_digest(outs[s % ring], out=digests[s], stream=consumer)
@@ -100,7 +109,8 @@ def stream_shard(pkg, n_shard=8192, batch=1024, ring=2, rank=0, world=8, buffers
     dt = time.perf_counter() - t0
     res = results.cpu().numpy().astype(bool)
     expect = np.stack(expects)
-    eng.close()
+    if keep is None:
+        eng.close()
     return {"rank": rank, "world": world, "first_instance": lo, "n_shard": n_shard, "batch": batch, "ring": ring, "group_steps": group or ring,
             "consumer_mode": bool(group), "group_ramp": bool(group and ramp), "steps": steps, "seconds": dt, "first_step_ms": ev_t0.elapsed_time(ev_first),
             "instances_per_s": n_shard / dt, "results_ok": bool((res == expect).all()), "digests": digests.cpu().numpy().view(np.uint64).reshape(n_shard, 2),
