@@ -54,6 +54,9 @@ inline int stream_device(hipStream_t st) {
 //                                         pairing chains, so a short job does not pay their latency before its HBM stream
 //                                place  : k_place_field per step (staging -> its place around the SHA segment), once the
 //                                         group's chains are done and the step's expansion has finished
+//                                lat    : the main path of a LATENCY group (a small group that starts a pipeline: launch_group);
+//                                         sha and place then also carry the addition chains of its cofactor segments, and the
+//                                         buffer's main stream their points (kcommon.hpp: CofactorSide)
 //   per group buffer:   normal   main : sha_values -> map -> cofactor -> prepare(H) .......... -> pairing   -> ev_chains
 //                       low      aux  : prepare(sig), g1_alloc, g2_alloc  (need only pk / sig)   -> ev_aux
 // Field witnesses go to a staging area (coalesced stores). n_buffers group buffers rotate, so the next groups' chains
